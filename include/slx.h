@@ -1,0 +1,167 @@
+/*
+ * slx.h -- C ABI of the MI355X-native DynaFrame static depth path.
+ *
+ * Frame-in / depth-out surface of elevenface/Structured-Light-Calculation
+ * (DynaFrame), re-presented as plain C so that any host loop (C, C++, ctypes,
+ * cgo, JNI ...) can bind it.  The reference has no FFI of its own; each entry
+ * point below names the reference call it replaces.  R/ =
+ * DynaFrame/DynaFrame/ of the reference repository.
+ *
+ *   reference call (file:line)                         -> C ABI
+ *   -------------------------------------------------------------------------
+ *   CCalculation::Init            R/CCalculation.cpp:77   -> slx_create
+ *   CDecodeGray::SetNumDigit      R/CDecodeGray.cpp:36    -> slx_config.gray_bits
+ *   CDecodeGray::SetMatFileName   R/CDecodeGray.cpp:56    -> slx_config.gray_lut
+ *   CDecodePhase::SetNumMat       R/CDecodePhase.cpp:119  -> slx_config.n_steps/period
+ *   CSensor::LoadDatas(group)     R/CSensorV.cpp:60       -> `group` of slx_set_frame
+ *   CDecode{Gray,Phase}::SetMat   R/CDecodeGray.cpp:24,
+ *                                 R/CDecodePhase.cpp:107  -> slx_set_frame
+ *   CDecode{Gray,Phase}::Decode + merge + FillCoordinate
+ *        R/CDecodeGray.cpp:108, R/CDecodePhase.cpp:83,
+ *        R/CCalculation.cpp:525-592, :666-785            -> slx_decode / slx_decode_batch
+ *   CDecode*::GetResult, m_x/y/zMat, m_ProjectorU
+ *        R/CDecodePhase.cpp:99, R/CCalculation.h:29-38    -> slx_get_output / slx_get_depth
+ *   ~CCalculation / ReleaseSpace  R/CCalculation.cpp:30   -> slx_destroy
+ *   ErrorHandling(msg)            R/GlobalFunction.cpp:3  -> int status + slx_last_error
+ *                                                           (never prints, never blocks)
+ *
+ * Threading: a context is thread-compatible (one decode in flight per context,
+ * like the reference's decoder objects); different contexts are independent.
+ * The library needs an AMD GPU (gfx950); there is no CPU fallback: without a
+ * device slx_create fails with SLX_ERR_NO_DEVICE.
+ */
+#ifndef SLX_H
+#define SLX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SLX_VERSION_MAJOR 0
+#define SLX_VERSION_MINOR 1
+
+#define SLX_MAX_FREQ 4        /* frequencies of the temporal unwrap            */
+#define SLX_MAX_STEPS 16      /* phase-shift steps per frequency               */
+#define SLX_MAX_GRAY_BITS 16  /* R/CDecodeGray.cpp:39 accepts 1..16            */
+
+typedef struct slx_ctx slx_ctx;
+
+enum slx_status {
+    SLX_OK = 0,
+    SLX_ERR_INVALID_ARG = -1,     /* bad configuration / argument (reference: `return false`) */
+    SLX_ERR_NOT_CONFIGURED = -2,  /* frame index outside what the mode uses (reference: SetMat before SetNum*) */
+    SLX_ERR_MISSING_FRAME = -3,   /* decode before every input plane was set */
+    SLX_ERR_NO_DEVICE = -4,       /* no usable HIP device: there is no CPU fallback */
+    SLX_ERR_HIP = -5,             /* a HIP runtime call failed, see slx_last_error */
+    SLX_ERR_OUT_OF_MEMORY = -6,
+    SLX_ERR_NOT_DECODED = -7,     /* output requested before a decode */
+    SLX_ERR_UNAVAILABLE = -8      /* output not produced by this mode / not enabled in aux_outputs */
+};
+
+/* What one decode computes.  Stage names follow SURVEY.md section 8(a). */
+enum slx_mode {
+    SLX_MODE_PHASE_ONLY = 0,          /* CDecodePhase alone: pix (f64)                      */
+    SLX_MODE_GRAY_ONLY = 1,           /* CDecodeGray alone: gray (f64)                      */
+    SLX_MODE_GRAY_PHASE = 2,          /* the reference's CalculateFirst(): Gray + 1 freq    */
+    SLX_MODE_MULTIFREQ = 3,           /* F-frequency N-step temporal unwrap -> depth        */
+    SLX_MODE_MULTIFREQ_GRAYMASK = 4   /* same + Gray-code validity mask                     */
+};
+
+enum slx_mem_kind { SLX_MEM_HOST = 0, SLX_MEM_DEVICE = 1 };
+
+/* Image groups, numbered like CSensor::LoadDatas(groupNum), R/CSensorV.cpp:57-59. */
+enum slx_group { SLX_GROUP_GRAY = 0, SLX_GROUP_PHASE = 1 };
+
+enum slx_output {
+    SLX_OUT_Z = 0,     /* f64 [H][W]   depth, 0 where invalid (m_zMat)              */
+    SLX_OUT_X = 1,     /* f64 [H][W]   (m_xMat)                                     */
+    SLX_OUT_Y = 2,     /* f64 [H][W]   (m_yMat)                                     */
+    SLX_OUT_U = 3,     /* f64 [H][W]   projector column (m_ProjectorU)              */
+    SLX_OUT_PIX = 4,   /* f64 [F][H][W] wrapped phase in projector px per frequency */
+    SLX_OUT_GRAY = 5,  /* f64 [H][W]   Gray stripe left edge                        */
+    SLX_OUT_K = 6,     /* i32 [F-1][H][W] fringe orders of the temporal unwrap      */
+    SLX_OUT_MASK = 7,  /* u8  [H][W]   1 = valid                                    */
+    SLX_OUT_COUNT = 8
+};
+
+typedef struct slx_config {
+    int width, height;             /* camera tile, pixels                                       */
+    int row_offset;                /* image row v of the tile's first row (row-tile sharding)   */
+    int mode;                      /* enum slx_mode                                             */
+    int n_freq;                    /* F: 1 for PHASE_ONLY / GRAY_PHASE, 1..4 for MULTIFREQ*     */
+    int n_steps;                   /* N: 3..16; the reference's value is 4                      */
+    int period[SLX_MAX_FREQ];      /* T_f in projector px, coarse -> fine (m_pixPeroid)         */
+    int gray_bits;                 /* G (GRAY_V_NUMDIGIT)                                       */
+    int gray_stripe;               /* S = projector width / 2^G, integer division               */
+    const int16_t *gray_lut;       /* lut[gray] = bin, 2^G entries; copied by slx_create        */
+    double fov_min, fov_max;       /* FOV_MIN_DISTANCE / FOV_MAX_DISTANCE                       */
+    double cam[9], pro[9], rot[9], trans[3];  /* CamMat, ProMat, R, T of the calibration file   */
+    int device;                    /* HIP device ordinal, or -1 for the current device          */
+    unsigned aux_outputs;          /* bit (1u << slx_output) for every extra output to produce  */
+} slx_config;
+
+/* Validates the configuration (no device needed): SLX_OK or SLX_ERR_INVALID_ARG,
+ * with a message in msg (may be NULL). */
+int slx_validate_config(const slx_config *cfg, char *msg, size_t msg_bytes);
+
+int slx_create(const slx_config *cfg, slx_ctx **out);
+void slx_destroy(slx_ctx *ctx);
+
+/* Message of the last failure on this context (ctx == NULL: of the last failed slx_create
+ * on this thread).  Never NULL. */
+const char *slx_last_error(const slx_ctx *ctx);
+
+/* Replaces the Gray table (n = 2^gray_bits entries, lut[gray] = bin).  The reference re-reads
+ * its code file on every Decode (R/CDecodeGray.cpp:113-125); this is the hook for that. */
+int slx_set_gray_lut(slx_ctx *ctx, const int16_t *lut, size_t n);
+
+/* Hands over input plane `idx` of `group` (GRAY: 2b = pattern, 2b+1 = inverse of bit b,
+ * bit 0 = LSB; PHASE: f*N + k).  SLX_MEM_HOST: the bytes are copied to the device before
+ * the call returns to the caller's buffer being reusable (deep copy, like pic.copyTo).
+ * SLX_MEM_DEVICE: the pointer is borrowed until the next decode has completed. */
+int slx_set_frame(slx_ctx *ctx, int group, int idx, const uint8_t *data, size_t stride_bytes,
+                  int mem_kind);
+
+/* One frame-set: every stage of the mode, fused, on `stream` (a hipStream_t, or NULL for the
+ * context's own stream).  Asynchronous; outputs are read with slx_get_output. */
+int slx_decode(slx_ctx *ctx, void *stream);
+
+/* n_sets frame-sets resident in device memory, one launch.  Plane p of set s starts at
+ * base + s*set_stride + p*height*row_stride.  z_out: device, f64 [n_sets][height][width].
+ * gray_base may be NULL when the mode has no Gray planes (and phase_base for GRAY_ONLY). */
+int slx_decode_batch(slx_ctx *ctx, int n_sets,
+                     const uint8_t *phase_base, size_t phase_set_stride,
+                     const uint8_t *gray_base, size_t gray_set_stride,
+                     size_t row_stride, double *z_out, void *stream);
+
+int slx_synchronize(slx_ctx *ctx);
+
+/* Copies an output of the last slx_decode (waits for it).  dst_bytes must be at least the
+ * size listed at enum slx_output. */
+int slx_get_output(slx_ctx *ctx, int which, void *dst, size_t dst_bytes, int mem_kind);
+int slx_get_depth(slx_ctx *ctx, double *z, int mem_kind);
+
+/* Device pointer of an output buffer owned by the context (valid until slx_destroy). */
+int slx_output_device_ptr(slx_ctx *ctx, int which, void **ptr);
+
+/* Derived calibration constants, for inspection: P (3x4, row-major), cA, cB
+ * (R/CCalculation.cpp:145,151,152). */
+int slx_get_calibration(const slx_ctx *ctx, double P[12], double *cA, double *cB);
+
+/* Launch duration of the most recent decode in milliseconds, measured with HIP events recorded
+ * on the stream the kernel ran on (waits for it).  Off by default: slx_enable_timing(ctx, 1). */
+int slx_enable_timing(slx_ctx *ctx, int on);
+int slx_last_decode_ms(slx_ctx *ctx, float *ms);
+
+/* Selects the kernel variant (0 = default); tuning / A-B benchmarking only. */
+int slx_set_variant(slx_ctx *ctx, int variant);
+
+int slx_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

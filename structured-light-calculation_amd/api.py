@@ -1,0 +1,260 @@
+"""ctypes binding of libslx.so -- the C ABI declared in include/slx.h.
+
+This is the Python host side of the boundary: it adds nothing to the data path
+(PyTorch / numpy only carry buffers).  If libslx.so is missing the import of
+`lib()` raises: there is no fallback implementation.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libslx.so")
+
+MAX_FREQ, MAX_STEPS, MAX_GRAY_BITS = 4, 16, 16
+
+OK = 0
+ERR_INVALID_ARG, ERR_NOT_CONFIGURED, ERR_MISSING_FRAME, ERR_NO_DEVICE = -1, -2, -3, -4
+ERR_HIP, ERR_OUT_OF_MEMORY, ERR_NOT_DECODED, ERR_UNAVAILABLE = -5, -6, -7, -8
+
+MODE_PHASE_ONLY, MODE_GRAY_ONLY, MODE_GRAY_PHASE, MODE_MULTIFREQ, MODE_MULTIFREQ_GRAYMASK = range(5)
+MEM_HOST, MEM_DEVICE = 0, 1
+GROUP_GRAY, GROUP_PHASE = 0, 1
+OUT_Z, OUT_X, OUT_Y, OUT_U, OUT_PIX, OUT_GRAY, OUT_K, OUT_MASK = range(8)
+OUT_NAMES = {"z": OUT_Z, "x": OUT_X, "y": OUT_Y, "U": OUT_U, "pix": OUT_PIX, "gray": OUT_GRAY, "k": OUT_K, "mask": OUT_MASK}
+
+# every symbol include/slx.h declares
+SYMBOLS = [
+    "slx_validate_config", "slx_create", "slx_destroy", "slx_last_error", "slx_set_gray_lut",
+    "slx_set_frame", "slx_decode", "slx_decode_batch", "slx_synchronize", "slx_get_output",
+    "slx_get_depth", "slx_output_device_ptr", "slx_get_calibration", "slx_enable_timing",
+    "slx_last_decode_ms", "slx_set_variant", "slx_version",
+]
+
+
+class SlxConfig(C.Structure):
+    _fields_ = [
+        ("width", C.c_int), ("height", C.c_int), ("row_offset", C.c_int), ("mode", C.c_int),
+        ("n_freq", C.c_int), ("n_steps", C.c_int), ("period", C.c_int * MAX_FREQ),
+        ("gray_bits", C.c_int), ("gray_stripe", C.c_int),
+        ("gray_lut", C.POINTER(C.c_int16)),
+        ("fov_min", C.c_double), ("fov_max", C.c_double),
+        ("cam", C.c_double * 9), ("pro", C.c_double * 9), ("rot", C.c_double * 9), ("trans", C.c_double * 3),
+        ("device", C.c_int), ("aux_outputs", C.c_uint),
+    ]
+
+
+class SlxError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("slx error %d: %s" % (code, msg))
+        self.code = code
+
+
+_lib = None
+
+
+def lib():
+    """Loads libslx.so (built by __graft_entry__.build()).  Raises if it is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("libslx.so is not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "(there is no fallback implementation)")
+        L = C.CDLL(LIB_PATH)
+        vp, sz = C.c_void_p, C.c_size_t
+        L.slx_validate_config.argtypes = [C.POINTER(SlxConfig), C.c_char_p, sz]
+        L.slx_create.argtypes = [C.POINTER(SlxConfig), C.POINTER(vp)]
+        L.slx_destroy.argtypes = [vp]
+        L.slx_destroy.restype = None
+        L.slx_last_error.argtypes = [vp]
+        L.slx_last_error.restype = C.c_char_p
+        L.slx_set_gray_lut.argtypes = [vp, C.POINTER(C.c_int16), sz]
+        L.slx_set_frame.argtypes = [vp, C.c_int, C.c_int, vp, sz, C.c_int]
+        L.slx_decode.argtypes = [vp, vp]
+        L.slx_decode_batch.argtypes = [vp, C.c_int, vp, sz, vp, sz, sz, vp, vp]
+        L.slx_synchronize.argtypes = [vp]
+        L.slx_get_output.argtypes = [vp, C.c_int, vp, sz, C.c_int]
+        L.slx_get_depth.argtypes = [vp, vp, C.c_int]
+        L.slx_output_device_ptr.argtypes = [vp, C.c_int, C.POINTER(vp)]
+        L.slx_get_calibration.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        L.slx_enable_timing.argtypes = [vp, C.c_int]
+        L.slx_last_decode_ms.argtypes = [vp, C.POINTER(C.c_float)]
+        L.slx_set_variant.argtypes = [vp, C.c_int]
+        for name in SYMBOLS:
+            if name not in ("slx_destroy", "slx_last_error"):
+                getattr(L, name).restype = C.c_int
+        _lib = L
+    return _lib
+
+
+def make_config(spec, device=-1, aux=()):
+    """spec: dict as produced by synth.make_spec() (width, height, mode, periods, ...)."""
+    c = SlxConfig()
+    c.width, c.height = spec["width"], spec["height"]
+    c.row_offset = spec.get("row_offset", 0)
+    c.mode = spec["mode"]
+    c.n_freq = spec.get("n_freq", 1)
+    c.n_steps = spec.get("n_steps", 4)
+    for i, t in enumerate(spec.get("periods", [])[:MAX_FREQ]):
+        c.period[i] = int(t)
+    c.gray_bits = spec.get("gray_bits", 0)
+    c.gray_stripe = spec.get("gray_stripe", 0)
+    keep = None
+    if spec.get("gray_lut") is not None:
+        keep = np.ascontiguousarray(spec["gray_lut"], dtype=np.int16)
+        c.gray_lut = keep.ctypes.data_as(C.POINTER(C.c_int16))
+    c.fov_min = spec.get("fov_min", 0.0)
+    c.fov_max = spec.get("fov_max", 0.0)
+    cal = spec.get("calib")
+    if cal is not None:
+        for name, n in (("cam", 9), ("pro", 9), ("rot", 9), ("trans", 3)):
+            v = np.asarray(cal[name], dtype=np.float64).reshape(-1)
+            for i in range(n):
+                getattr(c, name)[i] = float(v[i])
+    c.device = device
+    bits = 0
+    for a in aux:
+        bits |= 1 << (OUT_NAMES[a] if isinstance(a, str) else int(a))
+    c.aux_outputs = bits
+    c._keep = keep
+    return c
+
+
+def validate_config(cfg):
+    buf = C.create_string_buffer(512)
+    rc = lib().slx_validate_config(C.byref(cfg), buf, 512)
+    return rc, buf.value.decode()
+
+
+_OUT_DTYPE = {OUT_K: np.int32, OUT_MASK: np.uint8}
+
+
+class Context:
+    """One decoder context (≙ the reference's decoder objects + result planes)."""
+
+    def __init__(self, spec, device=-1, aux=()):
+        self.spec = spec
+        self.cfg = make_config(spec, device=device, aux=aux)
+        self._h = C.c_void_p()
+        rc = lib().slx_create(C.byref(self.cfg), C.byref(self._h))
+        if rc != OK:
+            raise SlxError(rc, lib().slx_last_error(None).decode())
+        self._borrowed = []
+
+    def close(self):
+        if self._h:
+            lib().slx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != OK:
+            raise SlxError(rc, lib().slx_last_error(self._h).decode())
+
+    def last_error(self):
+        return lib().slx_last_error(self._h).decode()
+
+    def set_frame(self, group, idx, data, stride=None):
+        """data: numpy uint8 [H,W] (host, deep-copied) or a torch CUDA uint8 tensor (borrowed)."""
+        if isinstance(data, np.ndarray):
+            assert data.dtype == np.uint8 and data.ndim == 2
+            if data.strides[1] != 1:
+                data = np.ascontiguousarray(data)
+            self._check(lib().slx_set_frame(self._h, group, idx, data.ctypes.data, data.strides[0], MEM_HOST))
+        else:  # torch tensor on the device
+            assert data.is_cuda and data.dim() == 2 and data.stride(1) == 1
+            self._borrowed.append(data)
+            self._check(lib().slx_set_frame(self._h, group, idx, data.data_ptr(),
+                                            data.stride(0) if stride is None else stride, MEM_DEVICE))
+
+    def set_frames(self, phase=None, gray=None):
+        self._borrowed = []
+        if phase is not None:
+            for i in range(phase.shape[0]):
+                self.set_frame(GROUP_PHASE, i, phase[i])
+        if gray is not None:
+            for i in range(gray.shape[0]):
+                self.set_frame(GROUP_GRAY, i, gray[i])
+
+    def set_gray_lut(self, lut):
+        lut = np.ascontiguousarray(lut, dtype=np.int16)
+        self._check(lib().slx_set_gray_lut(self._h, lut.ctypes.data_as(C.POINTER(C.c_int16)), lut.size))
+
+    def decode(self, stream=None):
+        self._check(lib().slx_decode(self._h, stream))
+
+    def decode_batch(self, n_sets, phase=None, gray=None, z_out=None, stream=None, row_stride=None):
+        """phase: CUDA uint8 [n_sets, F*N, H, W]; gray: CUDA uint8 [n_sets, 2G, H, W]; z_out: CUDA f64 [n_sets,H,W]."""
+        def base(t):
+            if t is None:
+                return None, 0
+            assert t.is_cuda and t.stride(-1) == 1
+            return t.data_ptr(), t.stride(0) * t.element_size()
+        pb, ps = base(phase)
+        gb, gs = base(gray)
+        ref = phase if phase is not None else gray
+        rs = ref.stride(-2) if row_stride is None else row_stride
+        self._check(lib().slx_decode_batch(self._h, n_sets, pb, ps, gb, gs, rs, z_out.data_ptr(), stream))
+
+    def synchronize(self):
+        self._check(lib().slx_synchronize(self._h))
+
+    def output_shape(self, which):
+        H, W, F = self.spec["height"], self.spec["width"], self.spec.get("n_freq", 1)
+        if which == OUT_PIX:
+            return (F, H, W)
+        if which == OUT_K:
+            return (F - 1, H, W)
+        return (H, W)
+
+    def get_output(self, which):
+        if isinstance(which, str):
+            which = OUT_NAMES[which]
+        a = np.empty(self.output_shape(which), dtype=_OUT_DTYPE.get(which, np.float64))
+        self._check(lib().slx_get_output(self._h, which, a.ctypes.data, a.nbytes, MEM_HOST))
+        return a
+
+    def get_depth(self):
+        a = np.empty(self.output_shape(OUT_Z), dtype=np.float64)
+        self._check(lib().slx_get_depth(self._h, a.ctypes.data, MEM_HOST))
+        return a
+
+    def get_calibration(self):
+        P = (C.c_double * 12)()
+        cA, cB = C.c_double(), C.c_double()
+        self._check(lib().slx_get_calibration(self._h, P, C.byref(cA), C.byref(cB)))
+        return np.array(P[:]).reshape(3, 4), cA.value, cB.value
+
+    def enable_timing(self, on=True):
+        self._check(lib().slx_enable_timing(self._h, 1 if on else 0))
+
+    def last_decode_ms(self):
+        ms = C.c_float()
+        self._check(lib().slx_last_decode_ms(self._h, C.byref(ms)))
+        return ms.value
+
+    def set_variant(self, v):
+        self._check(lib().slx_set_variant(self._h, int(v)))
+
+
+def decode_frameset(spec, phase=None, gray=None, want=("z",), device=-1):
+    """Convenience: one frame-set from host arrays, outputs as numpy arrays."""
+    aux = [w for w in want if w != "z" or spec["mode"] < MODE_GRAY_PHASE]
+    primary = {MODE_PHASE_ONLY: "pix", MODE_GRAY_ONLY: "gray"}.get(spec["mode"])
+    aux = [w for w in aux if w != primary]
+    with Context(spec, device=device, aux=aux) as ctx:
+        ctx.set_frames(phase, gray)
+        ctx.decode()
+        return {w: ctx.get_output(w) for w in want}

@@ -1,0 +1,283 @@
+// dynaframe.cpp -- see dynaframe.hpp.  Thin C++ over the C ABI; no arithmetic lives here.
+#include "dynaframe.hpp"
+
+#include <cstring>
+#include <fstream>
+
+namespace slx {
+
+namespace {
+
+slx_config base_config(const StaticParameters &sp)
+{
+    slx_config c;
+    std::memset(&c, 0, sizeof c);
+    c.width = sp.CAMERA_RESLINE;
+    c.height = sp.CAMERA_RESROW;
+    c.device = -1;
+    return c;
+}
+
+bool push_frame(slx_ctx *ctx, int group, int num, const Image8 &pic, int rows, int cols, std::string &err)
+{
+    if (pic.empty() || pic.rows != rows || pic.cols != cols) {
+        err = "image is empty or has the wrong size";
+        return false;
+    }
+    int rc = slx_set_frame(ctx, group, num, pic.data, pic.step, pic.on_device ? SLX_MEM_DEVICE : SLX_MEM_HOST);
+    if (rc != SLX_OK) {
+        err = slx_last_error(ctx);
+        return false;
+    }
+    return true;
+}
+
+std::vector<double> fetch(slx_ctx *ctx, int which, size_t n, std::string &err)
+{
+    std::vector<double> r(n);
+    if (slx_get_output(ctx, which, r.data(), n * sizeof(double), SLX_MEM_HOST) != SLX_OK) {
+        err = slx_last_error(ctx);
+        r.clear();
+    }
+    return r;
+}
+
+}  // namespace
+
+bool ReadGrayCodeFile(const std::string &path, int grayCodeSize, std::vector<int16_t> &lut)
+{
+    std::ifstream codeFile(path.c_str(), std::ios::in);
+    if (!codeFile) return false;
+    lut.assign((size_t)grayCodeSize, 0);
+    for (int i = 0; i < grayCodeSize; i++) {
+        int binCode = 0, grayCode = 0;
+        codeFile >> binCode >> grayCode;
+        if (grayCode >= 0 && grayCode < grayCodeSize) lut[(size_t)grayCode] = (int16_t)binCode;
+    }
+    return true;
+}
+
+// ---------------------------------------------------------------- CDecodePhase
+CDecodePhase::CDecodePhase(const StaticParameters &sp) : m_sp(sp) {}
+CDecodePhase::~CDecodePhase() { DeleteSpace(); }
+
+bool CDecodePhase::DeleteSpace()
+{
+    if (m_ctx) slx_destroy(m_ctx);
+    m_ctx = nullptr;
+    m_decoded = false;
+    return true;
+}
+
+bool CDecodePhase::SetNumMat(int numMat, int pixperiod)
+{
+    if (numMat <= 0) return false;
+    m_numMat = numMat;
+    m_pixPeroid = pixperiod;
+    DeleteSpace();
+    slx_config c = base_config(m_sp);
+    c.mode = SLX_MODE_PHASE_ONLY;
+    c.n_freq = 1;
+    c.n_steps = numMat;
+    c.period[0] = pixperiod;
+    if (slx_create(&c, &m_ctx) != SLX_OK) {
+        m_err = slx_last_error(nullptr);
+        m_ctx = nullptr;
+        return false;
+    }
+    return true;
+}
+
+bool CDecodePhase::SetMat(int num, const Image8 &pic)
+{
+    if (!m_ctx) {
+        m_err = "CDecodePhase.SetMat->grePicture Space is not allocated.";
+        return false;
+    }
+    return push_frame(m_ctx, SLX_GROUP_PHASE, num, pic, m_sp.CAMERA_RESROW, m_sp.CAMERA_RESLINE, m_err);
+}
+
+bool CDecodePhase::Decode()
+{
+    if (!m_ctx || slx_decode(m_ctx, nullptr) != SLX_OK) {
+        m_err = m_ctx ? slx_last_error(m_ctx) : "CDecodePhase.Decode()->CountResult fault";
+        return false;
+    }
+    m_decoded = true;
+    return true;
+}
+
+std::vector<double> CDecodePhase::GetResult()
+{
+    if (!m_ctx || !m_decoded) return std::vector<double>();
+    return fetch(m_ctx, SLX_OUT_PIX, (size_t)m_sp.CAMERA_RESROW * m_sp.CAMERA_RESLINE, m_err);
+}
+
+bool CDecodePhase::GetResult(double *dst, size_t n_elems, bool to_device)
+{
+    if (!m_ctx || !m_decoded) return false;
+    if (slx_get_output(m_ctx, SLX_OUT_PIX, dst, n_elems * sizeof(double), to_device ? SLX_MEM_DEVICE : SLX_MEM_HOST) != SLX_OK) {
+        m_err = slx_last_error(m_ctx);
+        return false;
+    }
+    return true;
+}
+
+// ----------------------------------------------------------------- CDecodeGray
+CDecodeGray::CDecodeGray(const StaticParameters &sp) : m_sp(sp) {}
+CDecodeGray::~CDecodeGray() { ReleaseSpace(); }
+
+bool CDecodeGray::ReleaseSpace()
+{
+    if (m_ctx) slx_destroy(m_ctx);
+    m_ctx = nullptr;
+    m_decoded = false;
+    return true;
+}
+
+bool CDecodeGray::SetNumDigit(int numDigit, bool ver)
+{
+    if ((numDigit <= 0) || (numDigit > 16)) return false;
+    m_numDigit = numDigit;
+    m_grayCodeSize = 1 << numDigit;
+    m_vertical = ver;
+    ReleaseSpace();
+    slx_config c = base_config(m_sp);
+    c.mode = SLX_MODE_GRAY_ONLY;
+    c.gray_bits = numDigit;
+    // R/CDecodeGray.cpp:182-185, integer division
+    c.gray_stripe = (ver ? m_sp.PROJECTOR_RESLINE : m_sp.PROJECTOR_RESROW) / m_grayCodeSize;
+    std::vector<int16_t> zeros((size_t)m_grayCodeSize, 0);   // the table itself is read in Decode()
+    c.gray_lut = zeros.data();
+    if (slx_create(&c, &m_ctx) != SLX_OK) {
+        m_err = slx_last_error(nullptr);
+        m_ctx = nullptr;
+        return false;
+    }
+    return true;
+}
+
+bool CDecodeGray::SetMatFileName(std::string codeFilePath, std::string codeFileName)
+{
+    m_codeFilePath = codeFilePath;
+    m_codeFileName = codeFileName;
+    return true;
+}
+
+bool CDecodeGray::SetMat(int num, const Image8 &pic)
+{
+    if (!m_ctx) {
+        m_err = "CDecodeGray.SetMat->grePicture Space is not allocated.";
+        return false;
+    }
+    return push_frame(m_ctx, SLX_GROUP_GRAY, num, pic, m_sp.CAMERA_RESROW, m_sp.CAMERA_RESLINE, m_err);
+}
+
+bool CDecodeGray::Decode()
+{
+    if (!m_ctx) return false;
+    std::vector<int16_t> lut;
+    if (!ReadGrayCodeFile(m_codeFilePath + m_codeFileName, m_grayCodeSize, lut)) {
+        m_err = "Gray Decode->Open file error.";
+        return false;
+    }
+    if (slx_set_gray_lut(m_ctx, lut.data(), lut.size()) != SLX_OK || slx_decode(m_ctx, nullptr) != SLX_OK) {
+        m_err = slx_last_error(m_ctx);
+        return false;
+    }
+    m_decoded = true;
+    return true;
+}
+
+std::vector<double> CDecodeGray::GetResult()
+{
+    if (!m_ctx || !m_decoded) return std::vector<double>();
+    return fetch(m_ctx, SLX_OUT_GRAY, (size_t)m_sp.CAMERA_RESROW * m_sp.CAMERA_RESLINE, m_err);
+}
+
+bool CDecodeGray::GetResult(double *dst, size_t n_elems, bool to_device)
+{
+    if (!m_ctx || !m_decoded) return false;
+    if (slx_get_output(m_ctx, SLX_OUT_GRAY, dst, n_elems * sizeof(double), to_device ? SLX_MEM_DEVICE : SLX_MEM_HOST) != SLX_OK) {
+        m_err = slx_last_error(m_ctx);
+        return false;
+    }
+    return true;
+}
+
+// ---------------------------------------------------------------- CCalculation
+CCalculation::CCalculation() {}
+CCalculation::~CCalculation() { ReleaseSpace(); }
+
+bool CCalculation::ReleaseSpace()
+{
+    if (m_ctx) slx_destroy(m_ctx);
+    m_ctx = nullptr;
+    m_done = false;
+    return true;
+}
+
+bool CCalculation::Init(const StaticParameters &sp, const Calibration &calib,
+                        const std::string &codeFilePath, const std::string &codeFileName)
+{
+    if (m_ctx != nullptr) return false;             // R/CCalculation.cpp:80-83
+    m_sp = sp;
+    std::vector<int16_t> lut;
+    if (!ReadGrayCodeFile(codeFilePath + codeFileName, 1 << sp.GRAY_V_NUMDIGIT, lut)) {
+        m_err = "Gray Decode->Open file error.";
+        return false;
+    }
+    slx_config c = base_config(sp);
+    c.mode = SLX_MODE_GRAY_PHASE;
+    c.n_freq = 1;
+    c.n_steps = sp.PHASE_NUMDIGIT;
+    // R/CCalculation.cpp:550: `1 << GRAY_V_NUMDIGIT - 1` parses as 1 << (G-1)
+    c.period[0] = sp.PROJECTOR_RESLINE / (1 << (sp.GRAY_V_NUMDIGIT - 1));
+    c.gray_bits = sp.GRAY_V_NUMDIGIT;
+    c.gray_stripe = sp.PROJECTOR_RESLINE / (1 << sp.GRAY_V_NUMDIGIT);   // :562-563
+    c.gray_lut = lut.data();
+    c.fov_min = sp.FOV_MIN_DISTANCE;
+    c.fov_max = sp.FOV_MAX_DISTANCE;
+    std::memcpy(c.cam, calib.CamMat, sizeof c.cam);
+    std::memcpy(c.pro, calib.ProMat, sizeof c.pro);
+    std::memcpy(c.rot, calib.R, sizeof c.rot);
+    std::memcpy(c.trans, calib.T, sizeof c.trans);
+    c.aux_outputs = 1u << SLX_OUT_X | 1u << SLX_OUT_Y | 1u << SLX_OUT_U;
+    if (slx_create(&c, &m_ctx) != SLX_OK) {
+        m_err = slx_last_error(nullptr);
+        m_ctx = nullptr;
+        return false;
+    }
+    return true;
+}
+
+bool CCalculation::SetSensorFrame(int groupNum, int idx, const Image8 &pic)
+{
+    if (!m_ctx) return false;
+    if (groupNum != 0 && groupNum != 1) return false;   // R/CSensorV.cpp:94-97
+    return push_frame(m_ctx, groupNum == 0 ? SLX_GROUP_GRAY : SLX_GROUP_PHASE, idx, pic,
+                      m_sp.CAMERA_RESROW, m_sp.CAMERA_RESLINE, m_err);
+}
+
+bool CCalculation::CalculateFirst()
+{
+    if (!m_ctx) return false;                           // R/CCalculation.cpp:176-181
+    if (slx_decode(m_ctx, nullptr) != SLX_OK) {
+        m_err = slx_last_error(m_ctx);
+        return false;
+    }
+    m_done = true;
+    return true;
+}
+
+std::vector<double> CCalculation::Fetch(int which)
+{
+    if (!m_ctx || !m_done) return std::vector<double>();
+    return fetch(m_ctx, which, (size_t)m_sp.CAMERA_RESROW * m_sp.CAMERA_RESLINE, m_err);
+}
+std::vector<double> CCalculation::GetZ() { return Fetch(SLX_OUT_Z); }
+std::vector<double> CCalculation::GetX() { return Fetch(SLX_OUT_X); }
+std::vector<double> CCalculation::GetY() { return Fetch(SLX_OUT_Y); }
+std::vector<double> CCalculation::GetProjectorU() { return Fetch(SLX_OUT_U); }
+
+}  // namespace slx

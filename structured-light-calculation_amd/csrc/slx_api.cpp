@@ -1,0 +1,522 @@
+// slx_api.cpp -- C-ABI host side of the MI355X-native DynaFrame static depth path.
+//
+// Owns what the reference's decoder objects own (R/CDecodePhase.cpp:19-45,
+// R/CDecodeGray.cpp:65-105: the input-plane arrays; R/CCalculation.cpp:102-121:
+// the result planes) as device buffers, does the one-off calibration algebra of
+// CCalculation::Init (R/CCalculation.cpp:134-152) on the host, and launches the
+// fused HIP kernel.  No OpenCV, no torch, no CPU fallback.
+#include <hip/hip_runtime_api.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "slx.h"
+#include "slx_kernels.h"
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct Plane {
+    const uint8_t *dev = nullptr;   // what the kernel reads
+    uint8_t *owned = nullptr;       // staging buffer for host frames (deep copy)
+    size_t stride = 0;
+    bool set = false;
+};
+
+}  // namespace
+
+struct slx_ctx {
+    slx_config cfg;
+    SlxKParams kp;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timed = false;
+    std::vector<int16_t> lut;
+    int16_t *d_lut = nullptr;
+    std::vector<Plane> phase, gray;
+    void *out[SLX_OUT_COUNT] = {};
+    size_t out_bytes[SLX_OUT_COUNT] = {};
+    size_t staging_pitch = 0;
+    double P[12] = {}, cA = 0, cB = 0;
+    bool aux = false;
+    bool decoded = false;
+    int variant = 0;
+    std::string err;
+};
+
+namespace {
+
+int fail(slx_ctx *ctx, int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->err = buf;
+    else g_create_error = buf;
+    return code;
+}
+
+int hip_fail(slx_ctx *ctx, hipError_t e, const char *what)
+{
+    if (e == hipErrorOutOfMemory) return fail(ctx, SLX_ERR_OUT_OF_MEMORY, "%s: %s", what, hipGetErrorString(e));
+    return fail(ctx, SLX_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
+}
+
+#define SLX_HIP(ctx, call)                                   \
+    do {                                                     \
+        hipError_t e_ = (call);                              \
+        if (e_ != hipSuccess) return hip_fail(ctx, e_, #call); \
+    } while (0)
+
+bool mode_has_gray(int m) { return m == SLX_MODE_GRAY_ONLY || m == SLX_MODE_GRAY_PHASE || m == SLX_MODE_MULTIFREQ_GRAYMASK; }
+bool mode_has_phase(int m) { return m != SLX_MODE_GRAY_ONLY; }
+bool mode_has_depth(int m) { return m >= SLX_MODE_GRAY_PHASE; }
+
+int validate(const slx_config *c, std::string &msg)
+{
+    char b[256];
+    auto bad = [&](const char *fmt, auto... a) { snprintf(b, sizeof b, fmt, a...); msg = b; return (int)SLX_ERR_INVALID_ARG; };
+    if (!c) return bad("config is NULL");
+    if (c->width <= 0 || c->height <= 0) return bad("width/height must be positive (got %dx%d)", c->width, c->height);
+    if ((long long)c->width * c->height > (1ll << 31)) return bad("tile too large");
+    if (c->mode < SLX_MODE_PHASE_ONLY || c->mode > SLX_MODE_MULTIFREQ_GRAYMASK) return bad("unknown mode %d", c->mode);
+    if (mode_has_phase(c->mode)) {
+        // R/CDecodePhase.cpp:122 rejects numMat <= 0; three steps is the algebraic minimum
+        if (c->n_steps < 3 || c->n_steps > SLX_MAX_STEPS) return bad("n_steps must be in [3,%d] (got %d)", SLX_MAX_STEPS, c->n_steps);
+        if (c->n_freq < 1 || c->n_freq > SLX_MAX_FREQ) return bad("n_freq must be in [1,%d] (got %d)", SLX_MAX_FREQ, c->n_freq);
+        if ((c->mode == SLX_MODE_PHASE_ONLY || c->mode == SLX_MODE_GRAY_PHASE) && c->n_freq != 1)
+            return bad("mode %d decodes exactly one frequency (got n_freq=%d)", c->mode, c->n_freq);
+        for (int f = 0; f < c->n_freq; f++)
+            if (c->period[f] <= 0 || c->period[f] >= (1 << 24)) return bad("period[%d] must be in [1,2^24) (got %d)", f, c->period[f]);
+    }
+    if (mode_has_gray(c->mode)) {
+        // R/CDecodeGray.cpp:39
+        if (c->gray_bits <= 0 || c->gray_bits > SLX_MAX_GRAY_BITS) return bad("gray_bits must be in [1,%d] (got %d)", SLX_MAX_GRAY_BITS, c->gray_bits);
+        if (c->gray_stripe <= 0) return bad("gray_stripe must be positive (got %d)", c->gray_stripe);
+        if (!c->gray_lut) return bad("gray_lut is NULL (the reference fails when the code file is missing, R/CDecodeGray.cpp:115)");
+    }
+    if (mode_has_depth(c->mode)) {
+        if (!(c->fov_min <= c->fov_max)) return bad("fov_min must not exceed fov_max");
+        if (c->cam[0] == 0.0 || c->cam[4] == 0.0) return bad("camera focal lengths must be non-zero");
+    }
+    const unsigned allowed = [&] {
+        unsigned a = 0;
+        if (mode_has_depth(c->mode)) a |= 1u << SLX_OUT_Z | 1u << SLX_OUT_X | 1u << SLX_OUT_Y | 1u << SLX_OUT_U | 1u << SLX_OUT_MASK;
+        if (mode_has_phase(c->mode)) a |= 1u << SLX_OUT_PIX;
+        if (mode_has_gray(c->mode)) a |= 1u << SLX_OUT_GRAY;
+        if (mode_has_depth(c->mode) && c->mode != SLX_MODE_GRAY_PHASE && c->n_freq > 1) a |= 1u << SLX_OUT_K;
+        return a;
+    }();
+    if (c->aux_outputs & ~allowed) return bad("aux_outputs 0x%x names outputs this mode does not produce (allowed 0x%x)", c->aux_outputs, allowed);
+    return SLX_OK;
+}
+
+size_t out_elem_bytes(int which) { return which == SLX_OUT_K ? 4 : which == SLX_OUT_MASK ? 1 : 8; }
+
+size_t out_planes(const slx_config &c, int which)
+{
+    if (which == SLX_OUT_PIX) return (size_t)c.n_freq;
+    if (which == SLX_OUT_K) return (size_t)(c.n_freq - 1);
+    return 1;
+}
+
+// x1 weights; must stay the same formula as the documented spec (DESIGN.md "x1").
+void nstep_weights(int n, float *wy, float *wx, float *scale)
+{
+    const double pi = 3.1415926535897932384626433832795;
+    for (int k = 0; k < n; k++) {
+        const double a = 2.0 * pi * (double)k / (double)n;
+        double c = std::cos(a), s = std::sin(a);
+        if (std::fabs(c) < 1e-9) c = 0.0;
+        if (std::fabs(s) < 1e-9) s = 0.0;
+        wy[k] = (float)c;
+        wx[k] = (float)s;
+    }
+    *scale = 2.0f / (float)n;
+}
+
+// R/CCalculation.cpp:134-152: P = ProMat * [R T] (k ascending), cA, cB and the scalars the
+// kernel rebuilds cC/cD from.  Plain double arithmetic, no contraction (-ffp-contract=off).
+void calibrate(slx_ctx *ctx)
+{
+    const slx_config &c = ctx->cfg;
+    double RT[12];
+    for (int r = 0; r < 3; r++) {
+        for (int k = 0; k < 3; k++) RT[r * 4 + k] = c.rot[r * 3 + k];
+        RT[r * 4 + 3] = c.trans[r];
+    }
+    for (int r = 0; r < 3; r++)
+        for (int col = 0; col < 4; col++) {
+            double s = 0.0;
+            for (int k = 0; k < 3; k++) s = s + c.pro[r * 3 + k] * RT[k * 4 + col];
+            ctx->P[r * 4 + col] = s;
+        }
+    const double fu = c.cam[0], fv = c.cam[4];
+    ctx->cA = fu * fv * ctx->P[3];
+    ctx->cB = fu * fv * ctx->P[11];
+    SlxKParams &kp = ctx->kp;
+    kp.cx = c.cam[2];
+    kp.cy = c.cam[5];
+    kp.fu = fu;
+    kp.fv = fv;
+    kp.P00 = ctx->P[0];
+    kp.P01 = ctx->P[1];
+    kp.K1 = fu * fv * ctx->P[2];
+    kp.P20 = ctx->P[8];
+    kp.P21 = ctx->P[9];
+    kp.K2 = fu * fv * ctx->P[10];
+    kp.cA = ctx->cA;
+    kp.cB = ctx->cB;
+}
+
+// Host-side check that every operand the kernel will touch matches the grid it is launched on.
+int check_launch_shapes(slx_ctx *ctx, const SlxKParams &kp, int n_phase, int n_gray, int n_sets)
+{
+    const slx_config &c = ctx->cfg;
+    if (n_sets <= 0 || n_sets > 65535) return fail(ctx, SLX_ERR_INVALID_ARG, "n_sets must be in [1,65535] (got %d)", n_sets);
+    if (kp.row_stride < (size_t)c.width) return fail(ctx, SLX_ERR_INVALID_ARG, "row stride %zu is smaller than the width %d", kp.row_stride, c.width);
+    for (int i = 0; i < n_phase; i++)
+        if (!kp.phase[i]) return fail(ctx, SLX_ERR_MISSING_FRAME, "phase plane %d was never set", i);
+    for (int i = 0; i < n_gray; i++)
+        if (!kp.gray[i]) return fail(ctx, SLX_ERR_MISSING_FRAME, "gray plane %d was never set", i);
+    if (kp.quads_per_row != (unsigned)((c.width + SLX_QUAD - 1) / SLX_QUAD) || kp.n_quads != kp.quads_per_row * (unsigned)c.height)
+        return fail(ctx, SLX_ERR_INVALID_ARG, "internal: quad geometry does not match the tile");
+    return SLX_OK;
+}
+
+bool ptr_aligned(const void *p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
+
+}  // namespace
+
+extern "C" {
+
+int slx_version(void) { return SLX_VERSION_MAJOR * 100 + SLX_VERSION_MINOR; }
+
+int slx_validate_config(const slx_config *cfg, char *msg, size_t msg_bytes)
+{
+    std::string m;
+    int rc = validate(cfg, m);
+    if (msg && msg_bytes) {
+        snprintf(msg, msg_bytes, "%s", m.c_str());
+    }
+    return rc;
+}
+
+const char *slx_last_error(const slx_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+void slx_destroy(slx_ctx *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    for (auto *v : {&ctx->phase, &ctx->gray})
+        for (Plane &p : *v)
+            if (p.owned) (void)hipFree(p.owned);
+    for (void *o : ctx->out)
+        if (o) (void)hipFree(o);
+    if (ctx->d_lut) (void)hipFree(ctx->d_lut);
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+int slx_create(const slx_config *cfg, slx_ctx **out)
+{
+    if (!out) return fail(nullptr, SLX_ERR_INVALID_ARG, "out is NULL");
+    *out = nullptr;
+    std::string msg;
+    int rc = validate(cfg, msg);
+    if (rc != SLX_OK) return fail(nullptr, rc, "%s", msg.c_str());
+
+    int n_dev = 0;
+    hipError_t e = hipGetDeviceCount(&n_dev);
+    if (e != hipSuccess || n_dev <= 0)
+        return fail(nullptr, SLX_ERR_NO_DEVICE, "no HIP device available (%s); this library has no CPU fallback",
+                    e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+    int dev = cfg->device;
+    if (dev < 0) {
+        if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    }
+    if (dev >= n_dev) return fail(nullptr, SLX_ERR_INVALID_ARG, "device %d does not exist (%d devices)", dev, n_dev);
+
+    slx_ctx *ctx = new slx_ctx;
+    ctx->cfg = *cfg;
+    ctx->device = dev;
+    auto bail = [&](int code) {
+        g_create_error = ctx->err;
+        slx_destroy(ctx);
+        return code;
+    };
+#define SLX_TRY(call)                                                  \
+    do {                                                               \
+        hipError_t e2_ = (call);                                       \
+        if (e2_ != hipSuccess) return bail(hip_fail(ctx, e2_, #call)); \
+    } while (0)
+
+    SLX_TRY(hipSetDevice(dev));
+    SLX_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    SLX_TRY(hipEventCreate(&ctx->ev0));
+    SLX_TRY(hipEventCreate(&ctx->ev1));
+
+    const slx_config &c = ctx->cfg;
+    const int n_phase = mode_has_phase(c.mode) ? c.n_freq * c.n_steps : 0;
+    const int n_gray = mode_has_gray(c.mode) ? 2 * c.gray_bits : 0;
+    ctx->phase.resize((size_t)n_phase);
+    ctx->gray.resize((size_t)n_gray);
+    ctx->staging_pitch = ((size_t)c.width + 3) & ~(size_t)3;
+
+    SlxKParams &kp = ctx->kp;
+    std::memset(&kp, 0, sizeof kp);
+    kp.width = c.width;
+    kp.height = c.height;
+    kp.row_offset = c.row_offset;
+    kp.quads_per_row = (unsigned)((c.width + SLX_QUAD - 1) / SLX_QUAD);
+    kp.n_quads = kp.quads_per_row * (unsigned)c.height;
+    kp.n_freq = mode_has_phase(c.mode) ? c.n_freq : 0;
+    kp.n_steps = mode_has_phase(c.mode) ? c.n_steps : 4;
+    for (int f = 0; f < SLX_MAX_FREQ; f++) kp.period[f] = f < c.n_freq ? c.period[f] : 1;
+    kp.gray_bits = mode_has_gray(c.mode) ? c.gray_bits : 0;
+    kp.gray_stripe = c.gray_stripe;
+    kp.fov_min = c.fov_min;
+    kp.fov_max = c.fov_max;
+    kp.out_set_stride = (size_t)c.width * (size_t)c.height;
+    if (mode_has_phase(c.mode)) nstep_weights(c.n_steps, kp.wy, kp.wx, &kp.wscale);
+    if (mode_has_depth(c.mode)) calibrate(ctx);
+
+    if (mode_has_gray(c.mode)) {
+        const size_t n = (size_t)1 << c.gray_bits;
+        ctx->lut.assign(c.gray_lut, c.gray_lut + n);
+        ctx->cfg.gray_lut = ctx->lut.data();
+        SLX_TRY(hipMalloc((void **)&ctx->d_lut, n * sizeof(int16_t)));
+        SLX_TRY(hipMemcpy(ctx->d_lut, ctx->lut.data(), n * sizeof(int16_t), hipMemcpyHostToDevice));
+        kp.lut = ctx->d_lut;
+    }
+
+    // result planes (the reference allocates them in Init, R/CCalculation.cpp:110-121)
+    unsigned want = c.aux_outputs;
+    if (mode_has_depth(c.mode)) want |= 1u << SLX_OUT_Z;
+    if (c.mode == SLX_MODE_PHASE_ONLY) want |= 1u << SLX_OUT_PIX;
+    if (c.mode == SLX_MODE_GRAY_ONLY) want |= 1u << SLX_OUT_GRAY;
+    const size_t hw = (size_t)c.width * (size_t)c.height;
+    for (int w = 0; w < SLX_OUT_COUNT; w++) {
+        if (!(want & (1u << w))) continue;
+        const size_t bytes = hw * out_planes(c, w) * out_elem_bytes(w);
+        if (bytes == 0) continue;
+        SLX_TRY(hipMalloc(&ctx->out[w], bytes));
+        SLX_TRY(hipMemset(ctx->out[w], 0, bytes));
+        ctx->out_bytes[w] = bytes;
+    }
+    ctx->aux = mode_has_depth(c.mode) && (c.aux_outputs & ~(1u << SLX_OUT_Z)) != 0;
+    kp.z = (double *)ctx->out[SLX_OUT_Z];
+    kp.x = (double *)ctx->out[SLX_OUT_X];
+    kp.y = (double *)ctx->out[SLX_OUT_Y];
+    kp.U = (double *)ctx->out[SLX_OUT_U];
+    kp.pix = (double *)ctx->out[SLX_OUT_PIX];
+    kp.gray_out = (double *)ctx->out[SLX_OUT_GRAY];
+    kp.k = (int32_t *)ctx->out[SLX_OUT_K];
+    kp.mask = (uint8_t *)ctx->out[SLX_OUT_MASK];
+#undef SLX_TRY
+    *out = ctx;
+    return SLX_OK;
+}
+
+int slx_set_frame(slx_ctx *ctx, int group, int idx, const uint8_t *data, size_t stride_bytes, int mem_kind)
+{
+    if (!ctx) return SLX_ERR_INVALID_ARG;
+    if (group != SLX_GROUP_GRAY && group != SLX_GROUP_PHASE) return fail(ctx, SLX_ERR_INVALID_ARG, "unknown group %d", group);
+    std::vector<Plane> &v = group == SLX_GROUP_GRAY ? ctx->gray : ctx->phase;
+    if (v.empty())   // reference: "grePicture Space is not allocated", R/CDecodePhase.cpp:109-113
+        return fail(ctx, SLX_ERR_NOT_CONFIGURED, "this mode has no %s planes", group == SLX_GROUP_GRAY ? "gray" : "phase");
+    if (idx < 0 || (size_t)idx >= v.size()) return fail(ctx, SLX_ERR_NOT_CONFIGURED, "plane index %d outside [0,%zu)", idx, v.size());
+    if (!data) return fail(ctx, SLX_ERR_INVALID_ARG, "data is NULL");
+    if (stride_bytes < (size_t)ctx->cfg.width) return fail(ctx, SLX_ERR_INVALID_ARG, "stride %zu is smaller than the width %d", stride_bytes, ctx->cfg.width);
+    if (mem_kind != SLX_MEM_HOST && mem_kind != SLX_MEM_DEVICE) return fail(ctx, SLX_ERR_INVALID_ARG, "unknown mem_kind %d", mem_kind);
+    Plane &p = v[(size_t)idx];
+    SLX_HIP(ctx, hipSetDevice(ctx->device));
+    if (mem_kind == SLX_MEM_DEVICE) {
+        p.dev = data;
+        p.stride = stride_bytes;
+    } else {
+        if (!p.owned) SLX_HIP(ctx, hipMalloc((void **)&p.owned, ctx->staging_pitch * (size_t)ctx->cfg.height));
+        // deep copy, complete before return (pic.copyTo, R/CDecodePhase.cpp:114)
+        SLX_HIP(ctx, hipMemcpy2D(p.owned, ctx->staging_pitch, data, stride_bytes, (size_t)ctx->cfg.width,
+                                 (size_t)ctx->cfg.height, hipMemcpyHostToDevice));
+        p.dev = p.owned;
+        p.stride = ctx->staging_pitch;
+    }
+    p.set = true;
+    return SLX_OK;
+}
+
+int slx_set_gray_lut(slx_ctx *ctx, const int16_t *lut, size_t n)
+{
+    if (!ctx || !lut) return SLX_ERR_INVALID_ARG;
+    if (!ctx->d_lut) return fail(ctx, SLX_ERR_NOT_CONFIGURED, "this mode has no Gray table");
+    if (n != ctx->lut.size()) return fail(ctx, SLX_ERR_INVALID_ARG, "table has %zu entries, expected %zu", n, ctx->lut.size());
+    ctx->lut.assign(lut, lut + n);
+    SLX_HIP(ctx, hipSetDevice(ctx->device));
+    SLX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    SLX_HIP(ctx, hipMemcpy(ctx->d_lut, ctx->lut.data(), n * sizeof(int16_t), hipMemcpyHostToDevice));
+    return SLX_OK;
+}
+
+static int launch(slx_ctx *ctx, SlxKParams &kp, int n_sets, bool aux, void *stream)
+{
+    const slx_config &c = ctx->cfg;
+    const int n_phase = (int)ctx->phase.size(), n_gray = (int)ctx->gray.size();
+    int rc = check_launch_shapes(ctx, kp, n_phase, n_gray, n_sets);
+    if (rc != SLX_OK) return rc;
+    // dword input loads and 16-byte output stores need aligned bases, strides and width
+    bool al = (c.width % SLX_QUAD) == 0 && (kp.row_stride % 4) == 0 && (kp.phase_set_stride % 4) == 0 && (kp.gray_set_stride % 4) == 0;
+    for (int i = 0; i < n_phase; i++) al = al && ptr_aligned(kp.phase[i], 4);
+    for (int i = 0; i < n_gray; i++) al = al && ptr_aligned(kp.gray[i], 4);
+    for (const void *o : {(const void *)kp.z, (const void *)kp.x, (const void *)kp.y, (const void *)kp.U, (const void *)kp.pix,
+                          (const void *)kp.gray_out, (const void *)kp.k, (const void *)kp.mask})
+        al = al && ptr_aligned(o, 16);
+    kp.aligned = al ? 1 : 0;
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    SLX_HIP(ctx, hipSetDevice(ctx->device));
+    if (ctx->timed) SLX_HIP(ctx, hipEventRecord(ctx->ev0, s));
+    int e = slx_launch_fused(kp, c.mode, aux, n_sets, ctx->variant, s);
+    if (e != 0) return hip_fail(ctx, (hipError_t)e, "kernel launch");
+    if (ctx->timed) SLX_HIP(ctx, hipEventRecord(ctx->ev1, s));
+    return SLX_OK;
+}
+
+int slx_decode(slx_ctx *ctx, void *stream)
+{
+    if (!ctx) return SLX_ERR_INVALID_ARG;
+    SlxKParams kp = ctx->kp;
+    size_t stride = 0;
+    for (auto *v : {&ctx->phase, &ctx->gray}) {
+        for (size_t i = 0; i < v->size(); i++) {
+            const Plane &p = (*v)[i];
+            if (!p.set) return fail(ctx, SLX_ERR_MISSING_FRAME, "%s plane %zu was never set", v == &ctx->phase ? "phase" : "gray", i);
+            if (stride == 0) stride = p.stride;
+            if (p.stride != stride)
+                return fail(ctx, SLX_ERR_INVALID_ARG, "all input planes of one decode must share one row stride (%zu vs %zu); "
+                            "host frames are staged at pitch %zu", p.stride, stride, ctx->staging_pitch);
+            (v == &ctx->phase ? kp.phase : kp.gray)[i] = p.dev;
+        }
+    }
+    kp.row_stride = stride;
+    kp.phase_set_stride = kp.gray_set_stride = 0;
+    int rc = launch(ctx, kp, 1, ctx->aux, stream);
+    if (rc == SLX_OK) ctx->decoded = true;
+    return rc;
+}
+
+int slx_decode_batch(slx_ctx *ctx, int n_sets, const uint8_t *phase_base, size_t phase_set_stride,
+                     const uint8_t *gray_base, size_t gray_set_stride, size_t row_stride, double *z_out, void *stream)
+{
+    if (!ctx) return SLX_ERR_INVALID_ARG;
+    const slx_config &c = ctx->cfg;
+    const size_t n_phase = ctx->phase.size(), n_gray = ctx->gray.size();
+    if (n_phase && !phase_base) return fail(ctx, SLX_ERR_MISSING_FRAME, "phase_base is NULL");
+    if (n_gray && !gray_base) return fail(ctx, SLX_ERR_MISSING_FRAME, "gray_base is NULL");
+    if (row_stride < (size_t)c.width) return fail(ctx, SLX_ERR_INVALID_ARG, "row stride %zu is smaller than the width %d", row_stride, c.width);
+    const size_t plane_bytes = row_stride * (size_t)c.height;
+    if (n_sets > 1 && n_phase && phase_set_stride < n_phase * plane_bytes) return fail(ctx, SLX_ERR_INVALID_ARG, "phase_set_stride %zu overlaps frame-sets", phase_set_stride);
+    if (n_sets > 1 && n_gray && gray_set_stride < n_gray * plane_bytes) return fail(ctx, SLX_ERR_INVALID_ARG, "gray_set_stride %zu overlaps frame-sets", gray_set_stride);
+    SlxKParams kp = ctx->kp;
+    for (size_t i = 0; i < n_phase; i++) kp.phase[i] = phase_base + i * plane_bytes;
+    for (size_t i = 0; i < n_gray; i++) kp.gray[i] = gray_base + i * plane_bytes;
+    kp.phase_set_stride = n_phase ? phase_set_stride : 0;
+    kp.gray_set_stride = n_gray ? gray_set_stride : 0;
+    kp.row_stride = row_stride;
+    // the batch path produces the primary output only
+    double *primary = z_out;
+    if (!primary) return fail(ctx, SLX_ERR_INVALID_ARG, "z_out is NULL");
+    kp.x = kp.y = kp.U = nullptr;
+    kp.k = nullptr;
+    kp.mask = nullptr;
+    kp.z = kp.pix = kp.gray_out = nullptr;
+    if (c.mode == SLX_MODE_PHASE_ONLY) kp.pix = primary;
+    else if (c.mode == SLX_MODE_GRAY_ONLY) kp.gray_out = primary;
+    else kp.z = primary;
+    return launch(ctx, kp, n_sets, false, stream);
+}
+
+int slx_synchronize(slx_ctx *ctx)
+{
+    if (!ctx) return SLX_ERR_INVALID_ARG;
+    SLX_HIP(ctx, hipSetDevice(ctx->device));
+    SLX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return SLX_OK;
+}
+
+int slx_output_device_ptr(slx_ctx *ctx, int which, void **ptr)
+{
+    if (!ctx || !ptr) return SLX_ERR_INVALID_ARG;
+    if (which < 0 || which >= SLX_OUT_COUNT) return fail(ctx, SLX_ERR_INVALID_ARG, "unknown output %d", which);
+    if (!ctx->out[which]) return fail(ctx, SLX_ERR_UNAVAILABLE, "output %d is not produced by this context (mode %d, aux_outputs 0x%x)", which, ctx->cfg.mode, ctx->cfg.aux_outputs);
+    *ptr = ctx->out[which];
+    return SLX_OK;
+}
+
+int slx_get_output(slx_ctx *ctx, int which, void *dst, size_t dst_bytes, int mem_kind)
+{
+    if (!ctx || !dst) return SLX_ERR_INVALID_ARG;
+    if (which < 0 || which >= SLX_OUT_COUNT) return fail(ctx, SLX_ERR_INVALID_ARG, "unknown output %d", which);
+    if (!ctx->out[which]) return fail(ctx, SLX_ERR_UNAVAILABLE, "output %d is not produced by this context (mode %d, aux_outputs 0x%x)", which, ctx->cfg.mode, ctx->cfg.aux_outputs);
+    if (!ctx->decoded) return fail(ctx, SLX_ERR_NOT_DECODED, "no decode has run yet");
+    if (dst_bytes < ctx->out_bytes[which]) return fail(ctx, SLX_ERR_INVALID_ARG, "destination holds %zu bytes, output needs %zu", dst_bytes, ctx->out_bytes[which]);
+    if (mem_kind != SLX_MEM_HOST && mem_kind != SLX_MEM_DEVICE) return fail(ctx, SLX_ERR_INVALID_ARG, "unknown mem_kind %d", mem_kind);
+    SLX_HIP(ctx, hipSetDevice(ctx->device));
+    SLX_HIP(ctx, hipDeviceSynchronize());   // the decode may have run on a caller stream
+    SLX_HIP(ctx, hipMemcpy(dst, ctx->out[which], ctx->out_bytes[which],
+                           mem_kind == SLX_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice));
+    return SLX_OK;
+}
+
+int slx_get_depth(slx_ctx *ctx, double *z, int mem_kind)
+{
+    if (!ctx) return SLX_ERR_INVALID_ARG;
+    return slx_get_output(ctx, SLX_OUT_Z, z, ctx->out_bytes[SLX_OUT_Z], mem_kind);
+}
+
+int slx_get_calibration(const slx_ctx *ctx, double P[12], double *cA, double *cB)
+{
+    if (!ctx) return SLX_ERR_INVALID_ARG;
+    if (!mode_has_depth(ctx->cfg.mode)) return SLX_ERR_UNAVAILABLE;
+    if (P) std::memcpy(P, ctx->P, sizeof ctx->P);
+    if (cA) *cA = ctx->cA;
+    if (cB) *cB = ctx->cB;
+    return SLX_OK;
+}
+
+int slx_enable_timing(slx_ctx *ctx, int on)
+{
+    if (!ctx) return SLX_ERR_INVALID_ARG;
+    ctx->timed = on != 0;
+    return SLX_OK;
+}
+
+int slx_last_decode_ms(slx_ctx *ctx, float *ms)
+{
+    if (!ctx || !ms) return SLX_ERR_INVALID_ARG;
+    if (!ctx->timed) return fail(ctx, SLX_ERR_UNAVAILABLE, "timing is off (slx_enable_timing)");
+    SLX_HIP(ctx, hipSetDevice(ctx->device));
+    SLX_HIP(ctx, hipEventSynchronize(ctx->ev1));
+    SLX_HIP(ctx, hipEventElapsedTime(ms, ctx->ev0, ctx->ev1));
+    return SLX_OK;
+}
+
+int slx_set_variant(slx_ctx *ctx, int variant)
+{
+    if (!ctx) return SLX_ERR_INVALID_ARG;
+    if (variant < 0 || variant >= slx_num_variants()) return fail(ctx, SLX_ERR_INVALID_ARG, "variant %d outside [0,%d)", variant, slx_num_variants());
+    ctx->variant = variant;
+    return SLX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,48 @@
+// slx_kernels.h -- kernel parameter block shared by the HIP kernels and the C-ABI host code.
+#ifndef SLX_KERNELS_H
+#define SLX_KERNELS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "slx.h"
+
+#define SLX_MAX_PHASE_PLANES (SLX_MAX_FREQ * SLX_MAX_STEPS)
+#define SLX_MAX_GRAY_PLANES (2 * SLX_MAX_GRAY_BITS)
+
+// Pixels one lane owns per step: one dword of every 8-bit input plane.
+#define SLX_QUAD 4
+
+struct SlxKParams {
+    // inputs: plane p of frame-set s starts at plane[p] + s * set_stride
+    const uint8_t *phase[SLX_MAX_PHASE_PLANES];
+    const uint8_t *gray[SLX_MAX_GRAY_PLANES];
+    size_t phase_set_stride, gray_set_stride;   // bytes
+    size_t row_stride;                          // bytes between image rows of an input plane
+    // outputs, dense [set][plane][H][W]; null = not produced
+    double *z, *x, *y, *U, *pix, *gray_out;
+    int32_t *k;
+    uint8_t *mask;
+    size_t out_set_stride;                      // pixels (= H*W)
+    const int16_t *lut;                         // lut[gray] = bin
+    int width, height, row_offset;
+    unsigned quads_per_row;                     // ceil(W / 4)
+    unsigned n_quads;                           // quads_per_row * H
+    int aligned;                                // dword loads / 16-byte stores are legal
+    int n_freq, n_steps;
+    int period[SLX_MAX_FREQ];
+    int gray_bits, gray_stripe;
+    float wy[SLX_MAX_STEPS], wx[SLX_MAX_STEPS], wscale;   // x1 weights
+    double fov_min, fov_max;
+    // calibration scalars of R/CCalculation.cpp:151-164: cC = ((u-cx)*fv)*P00 + ((v-cy)*fu)*P01 + K1
+    double cx, cy, fu, fv, P00, P01, K1, P20, P21, K2, cA, cB;
+};
+
+// Launches the fused kernel for `n_sets` frame-sets on `stream` (hipStream_t).
+// Returns 0, or a hipError_t value.  `variant` selects a tuning variant.
+int slx_launch_fused(const SlxKParams &kp, int mode, bool aux, int n_sets, int variant, void *stream);
+
+// Number of distinct variants slx_launch_fused understands.
+int slx_num_variants(void);
+
+#endif

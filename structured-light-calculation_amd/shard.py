@@ -1,0 +1,69 @@
+"""Partition of a batch of frame-sets across ranks, and the final depth-map gather.
+
+The decode itself is pixel-independent, so ranks never
+exchange data while computing; the only collective is the gather of finished
+depth maps (RCCL over xGMI on GPUs -- torch.distributed backend "nccl" -- or
+gloo on CPU in the tests).  Two ways to cut the work, both exact:
+  * by frame-set: rank r decodes whole frame-sets [lo, hi);
+  * by row-tile:  rank r decodes rows [lo, hi) of every frame-set (the split
+    BASELINE.json's north_star words); the tile's row_offset keeps (v - cy) of
+    R/CCalculation.cpp:160 referring to the full-frame row.
+"""
+import torch
+import torch.distributed as dist
+
+
+def split_range(n, world, rank):
+    """Contiguous, balanced [lo, hi) of n units for `rank` of `world` (earlier ranks get the remainder)."""
+    if world <= 0 or not (0 <= rank < world):
+        raise ValueError("bad rank/world %r/%r" % (rank, world))
+    base, rem = divmod(n, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def row_tile_spec(spec, world, rank):
+    """The spec of this rank's row tile (height and row_offset adjusted)."""
+    lo, hi = split_range(spec["height"], world, rank)
+    tile = dict(spec)
+    tile["height"] = hi - lo
+    tile["row_offset"] = spec.get("row_offset", 0) + lo
+    return tile, lo, hi
+
+
+def gather_depth(local, dst=0, group=None, all_ranks=False):
+    """Gathers per-rank depth tensors along dim 0.
+
+    local: [n_local, ...] tensor (same trailing shape on every rank; n_local may
+    differ by one between ranks).  Returns the concatenation on `dst` (None on
+    other ranks), or on every rank when all_ranks=True.  One collective call.
+    """
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    if world == 1:
+        return local
+    counts = torch.zeros(world, dtype=torch.int64, device=local.device)
+    counts[rank] = local.shape[0]
+    dist.all_reduce(counts, group=group)
+    counts = [int(c) for c in counts.tolist()]
+    if len(set(counts)) == 1:
+        # equal shards: a single all_gather_into_tensor / gather of one flat buffer
+        if all_ranks:
+            out = torch.empty((world * counts[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+            dist.all_gather_into_tensor(out, local.contiguous(), group=group)
+            return out
+        bufs = None
+        if rank == dst:
+            out = torch.empty((world * counts[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+            bufs = list(out.split(counts[0], dim=0))
+        dist.gather(local.contiguous(), bufs, dst=dst, group=group)
+        return out if rank == dst else None
+    # ragged shards: pad to the largest, gather, trim
+    m = max(counts)
+    pad = torch.zeros((m,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    pad[: local.shape[0]] = local
+    gathered = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(gathered, pad, group=group)
+    if not all_ranks and rank != dst:
+        return None
+    return torch.cat([g[:c] for g, c in zip(gathered, counts)], dim=0)

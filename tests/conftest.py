@@ -1,0 +1,47 @@
+import importlib
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "oracle")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+PKG = "structured-light-calculation_amd"
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def pkg(name):
+    return importlib.import_module(PKG + "." + name)
+
+
+@pytest.fixture(scope="session")
+def synth():
+    return pkg("synth")
+
+
+@pytest.fixture(scope="session")
+def api():
+    return pkg("api")
+
+
+@pytest.fixture(scope="session")
+def shard():
+    return pkg("shard")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    import oracle as O   # oracle/oracle.py -- test infrastructure
+    O.build()
+    return O
+
+
+@pytest.fixture(scope="session")
+def golden_dir():
+    return os.path.join(ROOT, "tests", "golden")

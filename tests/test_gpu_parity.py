@@ -1,0 +1,348 @@
+"""GPU parity tests: the HIP path, called through the C ABI (libslx.so), against the CPU
+oracle on the same inputs.  Bar (BASELINE.json north_star): depth within 1e-4 mm RMS of the
+CPU path (1e-5 for the 4-frequency x 8-step case), phase indices bit-exact.  The kernel is
+written to round exactly like the oracle, so these tests demand bit-equality everywhere and
+state the contractual tolerance next to it.
+
+Oracle = oracle/ (CPU restatement, "parity unpinned": the reference has no tests and is
+unbuildable here).  Nothing in this file reads /root/reference.
+"""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+RMS_TOL_MM = 1e-4
+RMS_TOL_MM_C5 = 1e-5
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch
+
+
+def small_spec(synth, name, w=64, h=48):
+    spec = dict(synth.make_spec(name))
+    spec["width"], spec["height"] = w, h
+    spec["calib"] = synth.scaled_calibration(w, h, spec["proj_width"])
+    return spec
+
+
+def exhaustive_planes(width=511):
+    d = np.arange(-255, 256)
+    d02, d13 = np.meshgrid(d, d, indexing="ij")
+    p = np.zeros((4, 511, width), dtype=np.uint8)
+    p[0, :, :511] = np.maximum(d02, 0)
+    p[2, :, :511] = np.maximum(-d02, 0)
+    p[1, :, :511] = np.maximum(d13, 0)
+    p[3, :, :511] = np.maximum(-d13, 0)
+    return p
+
+
+def all_outputs(spec):
+    mode = spec["mode"]
+    want = ["z", "x", "y", "U", "pix"]
+    if spec.get("gray_bits"):
+        want.append("gray")
+    if mode in (3, 4):
+        want.append("mask")
+        if spec["n_freq"] > 1:
+            want.append("k")
+    return tuple(want)
+
+
+def assert_same(got, want, names, tol=RMS_TOL_MM):
+    for n in names:
+        g, w = got[n], want[n]
+        assert g.shape == w.shape, n
+        if n == "z":
+            both = np.isfinite(g) & np.isfinite(w)
+            rms = float(np.sqrt(np.mean((g[both] - w[both]) ** 2))) if both.any() else 0.0
+            assert rms <= tol, "depth RMS %.3e mm exceeds the contractual %.0e" % (rms, tol)
+        assert np.array_equal(g, w, equal_nan=True), "%s differs in %d of %d elements" % (
+            n, int(np.sum(~((g == w) | (np.isnan(g) & np.isnan(w))))), g.size)
+
+
+# ------------------------------------------------------------------ wrapped phase, exhaustive
+@pytest.mark.parametrize("width", [511, 512])
+def test_wrapped_phase_exhaustive(api, oracle, synth, golden_dir, width):
+    """All 511 x 511 possible (I0-I2, I1-I3) inputs of CDecodePhase::CountResult, every period the
+    configurations use.  width 511 takes the byte-granular path, 512 the dword path."""
+    tables = json.load(open(os.path.join(golden_dir, "wrapped_phase_tables.json")))["tables"]
+    planes = exhaustive_planes(width)
+    for T in (40, 20, 30, 160, 240, 1280, 1920, 4096, 8, 64, 512, 7, 1000003):
+        spec = {"width": width, "height": 511, "mode": synth.MODE_PHASE_ONLY, "n_freq": 1, "n_steps": 4, "periods": [T]}
+        got = api.decode_frameset(spec, planes, None, want=("pix",))["pix"][0]
+        ref = oracle.pipeline(spec, planes, None, want=("pix",))["pix"][0]
+        assert np.array_equal(got, ref), "T=%d: %d mismatches" % (T, int((got != ref).sum()))
+        if str(T) in tables:
+            sha = hashlib.sha256(np.ascontiguousarray(got[:, :511]).tobytes()).hexdigest()
+            assert sha == tables[str(T)]["sha256"]
+
+
+def test_wrapped_phase_random_bytes_nstep(api, oracle, synth):
+    """x1: N-step for N != 4 (literal float/double path) and N == 4 on unstructured bytes."""
+    for n_steps in (3, 4, 5, 8, 16):
+        for T in (40, 512):
+            spec = {"width": 333, "height": 65, "mode": synth.MODE_PHASE_ONLY, "n_freq": 1, "n_steps": n_steps, "periods": [T]}
+            ph, _ = synth.random_planes(spec, seed=n_steps * 10 + T)
+            got = api.decode_frameset(spec, ph, None, want=("pix",))["pix"]
+            ref = oracle.pipeline(spec, ph, None, want=("pix",))["pix"]
+            assert np.array_equal(got, ref), (n_steps, T)
+
+
+# ------------------------------------------------------------------ Gray decode alone
+@pytest.mark.parametrize("bits,width", [(6, 640), (1, 17), (10, 96), (16, 64)])
+def test_gray_only(api, oracle, synth, bits, width):
+    spec = {"width": width, "height": 37, "mode": synth.MODE_GRAY_ONLY, "gray_bits": bits,
+            "gray_stripe": max(1, 65536 // (1 << bits)) if bits == 16 else max(1, 1280 // (1 << bits)),
+            "gray_lut": synth.standard_gray_lut(bits) if bits < 16 else (np.arange(1 << 16) % 30000).astype(np.int16)}
+    _, gr = synth.random_planes(spec, seed=bits)
+    gr[:, :, : width // 3] = np.where(gr[:, :, : width // 3] > 127, 220, 20)     # also clean patterns and exact ties
+    gr[1::2, :, : width // 6] = gr[0::2, :, : width // 6]
+    got = api.decode_frameset(spec, None, gr, want=("gray",))["gray"]
+    ref = oracle.pipeline(spec, None, gr, want=("gray",))["gray"]
+    assert np.array_equal(got, ref)
+
+
+# ------------------------------------------------------------------ committed fixtures
+@pytest.mark.parametrize("name", ["C1x4", "C2", "C3", "C5"])
+def test_scene_fixtures(api, synth, golden_dir, name):
+    d = np.load(os.path.join(golden_dir, "scene_%s.npz" % name))
+    spec = small_spec(synth, name)
+    want = tuple(k[4:] for k in d.files if k.startswith("out_"))
+    got = api.decode_frameset(spec, d["phase"] if "phase" in d.files else None,
+                              d["gray_planes"] if "gray_planes" in d.files else None, want=want)
+    assert_same(got, {w: d["out_" + w] for w in want}, want, RMS_TOL_MM_C5 if name == "C5" else RMS_TOL_MM)
+
+
+# ------------------------------------------------------------------ BASELINE configurations, full size
+@pytest.mark.parametrize("name,scene", [("C1", "tilted"), ("C1x4", "sphere"), ("REF", "sphere"), ("C2", "sphere"),
+                                        ("C3", "sphere"), ("C4", "tilted")])
+def test_baseline_configs_full_size(api, oracle, synth, name, scene):
+    spec = synth.make_spec(name)
+    ph, gr, _ = synth.render(spec, scene, seed=0x5EED + len(name), noise_sigma=2.0)
+    want = all_outputs(spec)
+    got = api.decode_frameset(spec, ph, gr, want=want)
+    ref = oracle.pipeline(spec, ph, gr, want=want, threads=8)
+    assert_same(got, ref, want)
+    assert (got["z"] > 0).mean() > 0.9
+
+
+def test_baseline_config_c5(api, oracle, synth):
+    """4096 x 3000, 4-frequency x 8-step, tolerance 1e-5 mm RMS (bit-exact in fact)."""
+    spec = synth.make_spec("C5")
+    ph, _, _ = synth.render(spec, "tilted", seed=0x5EED + 5, noise_sigma=1.0)
+    got = api.decode_frameset(spec, ph, None, want=("z", "k", "U"))
+    ref = oracle.pipeline(spec, ph, None, want=("z", "k", "U"), threads=8)
+    assert_same(got, ref, ("z", "k", "U"), RMS_TOL_MM_C5)
+
+
+# ------------------------------------------------------------------ unstructured inputs, every branch
+@pytest.mark.parametrize("name", ["C1", "C1x4", "C2", "C3", "C5"])
+@pytest.mark.parametrize("shape", [(48, 64), (31, 250), (9, 511), (3, 1001), (1, 1), (2, 3), (5, 130)])
+def test_random_bytes_all_outputs(api, oracle, synth, name, shape):
+    h, w = shape
+    spec = small_spec(synth, name, w, h)
+    ph, gr = synth.random_planes(spec, seed=h * 7919 + w)
+    if gr is not None and w > 8:
+        gr[:, :, : w // 2] = np.where(gr[:, :, : w // 2] > 127, 220, 20)
+    want = all_outputs(spec)
+    got = api.decode_frameset(spec, ph, gr, want=want)
+    ref = oracle.pipeline(spec, ph, gr, want=want)
+    assert_same(got, ref, want)
+
+
+def test_mask_halo_crosses_wave_boundaries(api, oracle, synth):
+    """x3's 3-tap AND: invalid pixels planted on every quad / wave seam of a wide row."""
+    spec = small_spec(synth, "C3", 1920, 6)
+    ph, gr, _ = synth.render(spec, "tilted")
+    rng = np.random.default_rng(3)
+    cols = sorted(set([0, 1, 3, 4, 5, 247, 248, 249, 250, 251, 252, 255, 256, 1916, 1917, 1918, 1919]
+                      + [int(c) for c in rng.integers(0, 1920, 60)]))
+    for r in range(6):
+        for c in cols[r::3]:
+            for b in range(6):
+                gr[2 * b, r, c], gr[2 * b + 1, r, c] = gr[2 * b + 1, r, c], gr[2 * b, r, c]
+    got = api.decode_frameset(spec, ph, gr, want=("mask", "z"))
+    ref = oracle.pipeline(spec, ph, gr, want=("mask", "z"))
+    assert ref["mask"].min() == 0 and ref["mask"].max() == 1
+    assert_same(got, ref, ("mask", "z"))
+
+
+# ------------------------------------------------------------------ the boundary itself
+def test_device_frames_strides_and_batch(api, oracle, synth, torch_cuda):
+    torch = torch_cuda
+    spec = small_spec(synth, "C3", 200, 40)
+    n_sets = 5
+    sets = [synth.random_planes(spec, seed=50 + s) for s in range(n_sets)]
+    ref = [oracle.pipeline(spec, p, g, want=("z",))["z"] for p, g in sets]
+    H, W = spec["height"], spec["width"]
+    for pitch in (W, W + 8, W + 3):                      # dense, padded-aligned, padded-unaligned rows
+        ph = torch.zeros((n_sets, 12, H, pitch), dtype=torch.uint8, device="cuda")
+        gr = torch.zeros((n_sets, 12, H, pitch), dtype=torch.uint8, device="cuda")
+        for s, (p, g) in enumerate(sets):
+            ph[s, :, :, :W] = torch.from_numpy(p).cuda()
+            gr[s, :, :, :W] = torch.from_numpy(g).cuda()
+        with api.Context(spec) as ctx:
+            # borrowed device planes, one frame-set at a time
+            for s in range(n_sets):
+                ctx.set_frames(ph[s, :, :, :W], gr[s, :, :, :W])
+                ctx.decode()
+                assert np.array_equal(ctx.get_depth(), ref[s], equal_nan=True), (pitch, s)
+            # one launch for the whole batch
+            z = torch.full((n_sets, H, W), -1.0, dtype=torch.float64, device="cuda")
+            ctx.decode_batch(n_sets, ph, gr, z, row_stride=pitch)
+            ctx.synchronize()
+            torch.cuda.synchronize()
+            zb = z.cpu().numpy()
+            for s in range(n_sets):
+                assert np.array_equal(zb[s], ref[s], equal_nan=True), (pitch, s)
+
+
+def test_decode_on_caller_stream_and_timing(api, oracle, synth, torch_cuda):
+    torch = torch_cuda
+    spec = small_spec(synth, "C2", 256, 64)
+    ph, _ = synth.random_planes(spec, seed=9)
+    ref = oracle.pipeline(spec, ph, None, want=("z",))["z"]
+    dev = torch.from_numpy(ph).cuda()
+    z = torch.empty((1, 64, 256), dtype=torch.float64, device="cuda")
+    s = torch.cuda.Stream()
+    with api.Context(spec) as ctx:
+        ctx.enable_timing(True)
+        with torch.cuda.stream(s):
+            ctx.decode_batch(1, dev[None], None, z, stream=s.cuda_stream)
+        ms = ctx.last_decode_ms()
+        s.synchronize()
+        assert ms > 0.0
+        assert np.array_equal(z[0].cpu().numpy(), ref, equal_nan=True)
+        # idempotence: a second decode of the same inputs changes nothing
+        ctx.decode_batch(1, dev[None], None, z, stream=s.cuda_stream)
+        s.synchronize()
+        assert np.array_equal(z[0].cpu().numpy(), ref, equal_nan=True)
+
+
+def test_error_paths_on_device(api, synth):
+    spec = small_spec(synth, "C1x4", 32, 8)
+    ph, gr = synth.random_planes(spec, seed=1)
+    with api.Context(spec) as ctx:
+        with pytest.raises(api.SlxError) as e:
+            ctx.get_depth()
+        assert e.value.code == api.ERR_NOT_DECODED
+        with pytest.raises(api.SlxError) as e:
+            ctx.decode()                                   # nothing set yet
+        assert e.value.code == api.ERR_MISSING_FRAME
+        with pytest.raises(api.SlxError) as e:
+            ctx.set_frame(api.GROUP_PHASE, 4, ph[0])       # only 4 phase images exist (R/CDecodePhase.cpp:109)
+        assert e.value.code == api.ERR_NOT_CONFIGURED
+        with pytest.raises(api.SlxError) as e:
+            ctx.get_output("k")
+        assert e.value.code == api.ERR_UNAVAILABLE
+        ctx.set_frames(ph, gr)
+        ctx.decode()
+        assert ctx.get_depth().shape == (8, 32)
+    with api.Context(dict(spec, mode=synth.MODE_PHASE_ONLY)) as ctx:
+        with pytest.raises(api.SlxError) as e:
+            ctx.set_frame(api.GROUP_GRAY, 0, gr[0])        # this mode has no Gray planes
+        assert e.value.code == api.ERR_NOT_CONFIGURED
+
+
+def test_calibration_constants(api, oracle, synth):
+    spec = synth.make_spec("C4")
+    with api.Context(spec) as ctx:
+        P, cA, cB = ctx.get_calibration()
+    Po = oracle.projection_matrix(spec["calib"]["pro"], spec["calib"]["rot"], spec["calib"]["trans"])
+    assert np.array_equal(P, Po)
+    fu, fv = spec["calib"]["cam"][0], spec["calib"]["cam"][4]
+    assert cA == fu * fv * Po[0, 3] and cB == fu * fv * Po[2, 3]
+
+
+def test_gray_lut_replacement(api, oracle, synth):
+    spec = small_spec(synth, "C1x4", 64, 16)
+    ph, gr = synth.random_planes(spec, seed=4)
+    lut2 = (np.arange(64)[::-1] - 10).astype(np.int16)      # an arbitrary table, negative entries included
+    ref = oracle.pipeline(dict(spec, gray_lut=lut2), ph, gr, want=("z", "U", "gray"))
+    with api.Context(spec, aux=("U", "gray")) as ctx:
+        ctx.set_gray_lut(lut2)
+        ctx.set_frames(ph, gr)
+        ctx.decode()
+        for w in ("z", "U", "gray"):
+            assert np.array_equal(ctx.get_output(w), ref[w], equal_nan=True), w
+
+
+# ------------------------------------------------------------------ sharding on the device
+def test_row_tiles_and_frameset_shards_on_gpu(api, oracle, synth, shard):
+    spec = small_spec(synth, "C3", 128, 50)
+    ph, gr = synth.random_planes(spec, seed=21)
+    full = oracle.pipeline(spec, ph, gr, want=("z", "y"))
+    for world in (2, 8):
+        parts = []
+        for rank in range(world):
+            tile, lo, hi = shard.row_tile_spec(spec, world, rank)
+            parts.append(api.decode_frameset(tile, ph[:, lo:hi], gr[:, lo:hi], want=("z", "y")))
+        for w in ("z", "y"):
+            assert np.array_equal(np.concatenate([p[w] for p in parts]), full[w], equal_nan=True), (world, w)
+
+
+# ------------------------------------------------------------------ full batch size, size-independent properties
+def test_full_size_batch_properties(api, oracle, synth, torch_cuda):
+    """BASELINE configuration 4's per-GPU share: 32 frame-sets of 1920x1200, 3 x 4-step, in one launch.
+    Property: decoding is per-frame-set and per-pixel independent, so (a) a batch of copies of
+    one frame-set gives identical maps, each equal to the oracle's; (b) permuting the sets of a
+    batch permutes the outputs; (c) a second launch reproduces the first bit for bit."""
+    torch = torch_cuda
+    spec = synth.make_spec("C4")
+    H, W = spec["height"], spec["width"]
+    ph0, _, _ = synth.render(spec, "sphere", seed=77, noise_sigma=2.0)
+    ph1, _ = synth.random_planes(spec, seed=78)
+    ref0 = oracle.pipeline(spec, ph0, None, want=("z",), threads=8)["z"]
+    ref1 = oracle.pipeline(spec, ph1, None, want=("z",), threads=8)["z"]
+    n_sets = 32
+    batch = torch.empty((n_sets, 12, H, W), dtype=torch.uint8, device="cuda")
+    d0, d1 = torch.from_numpy(ph0).cuda(), torch.from_numpy(ph1).cuda()
+    odd = [s for s in range(n_sets) if s % 5 == 2]
+    for s in range(n_sets):
+        batch[s] = d1 if s in odd else d0
+    z = torch.empty((n_sets, H, W), dtype=torch.float64, device="cuda")
+    with api.Context(spec) as ctx:
+        ctx.decode_batch(n_sets, batch, None, z)
+        ctx.synchronize()
+        first = z.clone()
+        r0, r1 = torch.from_numpy(ref0).cuda(), torch.from_numpy(ref1).cuda()
+        for s in range(n_sets):
+            want = r1 if s in odd else r0
+            assert torch.equal(torch.nan_to_num(z[s], nan=-7.0), torch.nan_to_num(want, nan=-7.0)), s
+        z.fill_(-1.0)
+        ctx.decode_batch(n_sets, batch, None, z)
+        ctx.synchronize()
+        assert torch.equal(torch.nan_to_num(z, nan=-7.0), torch.nan_to_num(first, nan=-7.0))
+
+
+# ------------------------------------------------------------------ the C++ mirror of the reference classes
+def test_cpp_host_loop(tmp_path, oracle, synth, golden_dir):
+    """tests/cpp/dynaframe_host_loop.cpp drives slx::CDecodeGray / CDecodePhase / CCalculation the way
+    CCalculation::FillFirstProjectorU + CalculateFirst do (R/CCalculation.cpp:171-206, :525-592)."""
+    import subprocess
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "tests", "cpp", "dynaframe_host_loop")
+    assert os.path.exists(exe), "run __graft_entry__.build() first"
+    W, H, PW = 320, 200, 1280
+    spec = small_spec(synth, "C1x4", W, H)
+    ph, gr, _ = synth.render(spec, "sphere", seed=3, noise_sigma=2.0)
+    rows = json.load(open(os.path.join(golden_dir, "vGrayCode_rows.json")))["rows"]
+    code_dir = str(tmp_path) + "/"
+    with open(code_dir + "vGrayCode.txt", "w") as f:          # the reference's file format: "bin gray" per line
+        f.write("\n".join("%d %d" % (b, g) for b, g in rows) + "\n")
+    np.concatenate([gr.reshape(-1), ph.reshape(-1)]).tofile(code_dir + "in.bin")
+    subprocess.check_call([exe, code_dir + "in.bin", code_dir + "out.bin", str(W), str(H), str(PW), code_dir, "vGrayCode.txt"])
+    out = np.fromfile(code_dir + "out.bin", dtype=np.float64).reshape(6, H, W)
+    ref = oracle.pipeline(spec, ph, gr, want=("gray", "pix", "z", "x", "y", "U"))
+    for i, w in enumerate(("gray", "pix", "z", "x", "y", "U")):
+        r = ref[w][0] if w == "pix" else ref[w]
+        assert np.array_equal(out[i], r, equal_nan=True), w

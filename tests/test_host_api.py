@@ -1,0 +1,150 @@
+"""CPU tests of the boundary: libslx.so loads, exports every symbol include/slx.h declares,
+validates configurations like the reference's setters do, and fails loudly (no CPU fallback)
+when there is no GPU.  No compute calls here."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+def header_symbols():
+    text = open(os.path.join(ROOT, "include", "slx.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(slx_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol(api):
+    L = api.lib()
+    declared = header_symbols()
+    assert sorted(api.SYMBOLS) == declared
+    for name in declared:
+        assert hasattr(L, name), name
+    assert L.slx_version() == 1
+
+
+def test_cpp_mirror_classes_are_exported(api):
+    out = subprocess.check_output(["nm", "-DC", api.LIB_PATH]).decode()
+    for sym in ("slx::CDecodePhase::SetNumMat(int, int)", "slx::CDecodePhase::Decode()",
+                "slx::CDecodeGray::SetNumDigit(int, bool)", "slx::CDecodeGray::Decode()",
+                "slx::CCalculation::CalculateFirst()", "slx::ReadGrayCodeFile"):
+        assert sym in out, sym
+
+
+def test_no_oracle_in_product(api):
+    """The product never links or imports anything under oracle/."""
+    out = subprocess.check_output(["ldd", api.LIB_PATH]).decode()
+    assert "oracle" not in out
+    pkg_dir = os.path.dirname(api.LIB_PATH)
+    for dirpath, _, files in os.walk(pkg_dir):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h", ".hpp")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"import\s+oracle|from\s+oracle|slx_oracle|slxo_|oracle/|oracle\.py", text), f
+
+
+@pytest.mark.parametrize("name", ["C1", "C1x4", "REF", "C2", "C3", "C4", "C5"])
+def test_named_configs_validate(api, synth, name):
+    spec = synth.make_spec(name)
+    rc, msg = api.validate_config(api.make_config(spec, aux=("U",)))
+    assert rc == api.OK, msg
+    n_phase, n_gray = synth.n_planes(spec)
+    assert synth.algorithmic_bytes_per_pixel(spec) == n_phase + n_gray + 8
+
+
+def test_baseline_byte_model(synth):
+    # C2/C4 20 B/px, C3 32 B/px, C5 40 B/px, C1 12 / 24 B/px
+    got = {n: synth.algorithmic_bytes_per_pixel(synth.make_spec(n)) for n in ("C1", "C1x4", "C2", "C3", "C4", "C5")}
+    assert got == {"C1": 12, "C1x4": 24, "C2": 20, "C3": 32, "C4": 20, "C5": 40}
+    s = synth.make_spec("C4")
+    assert s["width"] * s["height"] * 20 == 46080000
+
+
+BAD = [
+    (dict(width=0), "width/height"),
+    (dict(height=-3), "width/height"),
+    (dict(mode=9), "unknown mode"),
+    (dict(n_steps=0), "n_steps"),            # R/CDecodePhase.cpp:122
+    (dict(n_steps=17), "n_steps"),
+    (dict(n_freq=0), "n_freq"),
+    (dict(n_freq=5), "n_freq"),
+    (dict(periods=[1920, 0, 30]), "period[1]"),
+    (dict(fov_min=5.0, fov_max=1.0), "fov_min"),
+]
+
+
+@pytest.mark.parametrize("patch,needle", BAD)
+def test_bad_configs_are_rejected(api, synth, patch, needle):
+    spec = dict(synth.make_spec("C4"), **patch)
+    rc, msg = api.validate_config(api.make_config(spec))
+    assert rc == api.ERR_INVALID_ARG
+    assert needle in msg, msg
+
+
+def test_bad_gray_configs_are_rejected(api, synth):
+    spec = synth.make_spec("C3")
+    for patch, needle in ((dict(gray_bits=0), "gray_bits"), (dict(gray_bits=17), "gray_bits"),   # R/CDecodeGray.cpp:39
+                          (dict(gray_stripe=0), "gray_stripe"), (dict(gray_lut=None), "gray_lut")):
+        rc, msg = api.validate_config(api.make_config(dict(spec, **patch)))
+        assert rc == api.ERR_INVALID_ARG and needle in msg, (patch, msg)
+    # an output the mode does not produce
+    rc, msg = api.validate_config(api.make_config(synth.make_spec("C4"), aux=("gray",)))
+    assert rc == api.ERR_INVALID_ARG and "aux_outputs" in msg
+    rc, msg = api.validate_config(api.make_config(synth.make_spec("C1x4"), aux=("k",)))
+    assert rc == api.ERR_INVALID_ARG
+    rc, msg = api.validate_config(api.make_config(dict(synth.make_spec("C1x4"), n_freq=2, periods=[40, 20])))
+    assert rc == api.ERR_INVALID_ARG and "exactly one frequency" in msg
+
+
+def test_null_arguments(api):
+    L = api.lib()
+    assert L.slx_validate_config(None, None, 0) == api.ERR_INVALID_ARG
+    assert L.slx_create(None, None) == api.ERR_INVALID_ARG
+    assert L.slx_decode(None, None) == api.ERR_INVALID_ARG
+    assert L.slx_set_frame(None, 0, 0, None, 0, 0) == api.ERR_INVALID_ARG
+    L.slx_destroy(None)                                  # no-op, must not crash
+    assert isinstance(L.slx_last_error(None), bytes)
+
+
+def test_create_fails_loudly_without_gpu(api, synth):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(api.SlxError) as e:
+        api.Context(synth.make_spec("C4"))
+    assert e.value.code == api.ERR_NO_DEVICE
+    assert "no CPU fallback" in str(e.value)
+
+
+def test_split_range(shard):
+    for n in (0, 1, 7, 32, 256, 1200):
+        for world in (1, 2, 3, 8):
+            spans = [shard.split_range(n, world, r) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            for a, b in zip(spans, spans[1:]):
+                assert a[1] == b[0]
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        shard.split_range(4, 2, 2)
+    assert shard.split_range(1200, 8, 3) == (450, 600)   # 150-row tiles of SURVEY.md section 8(e)
+
+
+def test_row_tile_spec(shard, synth):
+    spec = synth.make_spec("C4")
+    tile, lo, hi = shard.row_tile_spec(spec, 8, 7)
+    assert (lo, hi) == (1050, 1200) and tile["height"] == 150 and tile["row_offset"] == 1050
+    assert spec["height"] == 1200 and spec["row_offset"] == 0
+
+
+def test_synthetic_source_is_deterministic(synth):
+    spec = dict(synth.make_spec("C3"), width=64, height=48)
+    a = synth.render(spec, "sphere", seed=5, noise_sigma=2.0)
+    b = synth.render(spec, "sphere", seed=5, noise_sigma=2.0)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    assert a[0].shape == (12, 48, 64) and a[1].shape == (12, 48, 64)
+    assert a[0].dtype == np.uint8
