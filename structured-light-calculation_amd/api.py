@@ -249,12 +249,16 @@ class Context:
         self._check(lib().slx_set_variant(self._h, int(v)))
 
 
-def decode_frameset(spec, phase=None, gray=None, want=("z",), device=-1):
+VARIANT_AUTO, VARIANT_GENERIC, VARIANT_STRIP, VARIANT_STRIP_LUT = range(4)
+
+
+def decode_frameset(spec, phase=None, gray=None, want=("z",), device=-1, variant=0):
     """Convenience: one frame-set from host arrays, outputs as numpy arrays."""
     aux = [w for w in want if w != "z" or spec["mode"] < MODE_GRAY_PHASE]
     primary = {MODE_PHASE_ONLY: "pix", MODE_GRAY_ONLY: "gray"}.get(spec["mode"])
     aux = [w for w in aux if w != primary]
     with Context(spec, device=device, aux=aux) as ctx:
+        ctx.set_variant(variant)
         ctx.set_frames(phase, gray)
         ctx.decode()
         return {w: ctx.get_output(w) for w in want}

@@ -39,6 +39,7 @@ struct slx_ctx {
     bool timed = false;
     std::vector<int16_t> lut;
     int16_t *d_lut = nullptr;
+    float *d_atan_lut = nullptr;
     std::vector<Plane> phase, gray;
     void *out[SLX_OUT_COUNT] = {};
     size_t out_bytes[SLX_OUT_COUNT] = {};
@@ -192,6 +193,14 @@ int check_launch_shapes(slx_ctx *ctx, const SlxKParams &kp, int n_phase, int n_g
     return SLX_OK;
 }
 
+// lut[g] == inverse of g = b ^ (b >> 1) for every entry (the table of R/Patterns/vGrayCode.txt)
+bool is_reflected_gray(const std::vector<int16_t> &lut)
+{
+    for (size_t b = 0; b < lut.size(); b++)
+        if (lut[b ^ (b >> 1)] != (int16_t)b) return false;
+    return lut.size() <= 32768;
+}
+
 bool ptr_aligned(const void *p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
 
 }  // namespace
@@ -223,6 +232,7 @@ void slx_destroy(slx_ctx *ctx)
     for (void *o : ctx->out)
         if (o) (void)hipFree(o);
     if (ctx->d_lut) (void)hipFree(ctx->d_lut);
+    if (ctx->d_atan_lut) (void)hipFree(ctx->d_atan_lut);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -291,6 +301,19 @@ int slx_create(const slx_config *cfg, slx_ctx **out)
     kp.out_set_stride = (size_t)c.width * (size_t)c.height;
     if (mode_has_phase(c.mode)) nstep_weights(c.n_steps, kp.wy, kp.wx, &kp.wscale);
     if (mode_has_depth(c.mode)) calibrate(ctx);
+    for (int f = 0; f < SLX_MAX_FREQ; f++) {
+        // constants of the fast temporal unwrap (slx_kernels.hip: unwrap_stage<true>)
+        kp.inv_period[f] = 1.0 / (double)kp.period[f];
+        kp.half_biased[f] = 0.5 + 0x1p-30 / (double)kp.period[f];
+    }
+    if (mode_has_depth(c.mode) && mode_has_phase(c.mode) && c.n_steps == 4) {
+        // first-octant angle table of the fast path, computed on the device by the same code
+        SLX_TRY(hipMalloc((void **)&ctx->d_atan_lut, sizeof(float) * SLX_ATAN_LUT_ENTRIES));
+        int e3 = slx_launch_atan_lut_init(ctx->d_atan_lut, ctx->stream);
+        if (e3 != 0) return bail(hip_fail(ctx, (hipError_t)e3, "angle table init"));
+        SLX_TRY(hipStreamSynchronize(ctx->stream));
+        kp.atan_lut = ctx->d_atan_lut;
+    }
 
     if (mode_has_gray(c.mode)) {
         const size_t n = (size_t)1 << c.gray_bits;
@@ -299,6 +322,7 @@ int slx_create(const slx_config *cfg, slx_ctx **out)
         SLX_TRY(hipMalloc((void **)&ctx->d_lut, n * sizeof(int16_t)));
         SLX_TRY(hipMemcpy(ctx->d_lut, ctx->lut.data(), n * sizeof(int16_t), hipMemcpyHostToDevice));
         kp.lut = ctx->d_lut;
+        kp.std_gray = is_reflected_gray(ctx->lut) ? 1 : 0;
     }
 
     // result planes (the reference allocates them in Init, R/CCalculation.cpp:110-121)
@@ -366,6 +390,7 @@ int slx_set_gray_lut(slx_ctx *ctx, const int16_t *lut, size_t n)
     SLX_HIP(ctx, hipSetDevice(ctx->device));
     SLX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     SLX_HIP(ctx, hipMemcpy(ctx->d_lut, ctx->lut.data(), n * sizeof(int16_t), hipMemcpyHostToDevice));
+    ctx->kp.std_gray = is_reflected_gray(ctx->lut) ? 1 : 0;
     return SLX_OK;
 }
 
@@ -385,6 +410,8 @@ static int launch(slx_ctx *ctx, SlxKParams &kp, int n_sets, bool aux, void *stre
     kp.aligned = al ? 1 : 0;
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
     SLX_HIP(ctx, hipSetDevice(ctx->device));
+    if (ctx->variant >= SLX_VARIANT_STRIP && !slx_strip_eligible(kp, c.mode, aux))
+        return fail(ctx, SLX_ERR_UNAVAILABLE, "variant %d (strip kernel) cannot run this configuration or these operands", ctx->variant);
     if (ctx->timed) SLX_HIP(ctx, hipEventRecord(ctx->ev0, s));
     int e = slx_launch_fused(kp, c.mode, aux, n_sets, ctx->variant, s);
     if (e != 0) return hip_fail(ctx, (hipError_t)e, "kernel launch");

@@ -44,18 +44,34 @@ __device__ __forceinline__ int ibyte(uint32_t w, int j) { return (int)((w >> (8 
 //  * RN(x/360) by the same residual correction with r = RN(1/360);
 //  * (float)((double)q * (double)T) == q*T in f32 (the double product is exact), and
 //    (float)((double)pix + 0.5) == pix + 0.5f (the double sum is exact for pix = 0 or >= 2^-11).
-__device__ __forceinline__ float wrapped_pix_4step(float g0, float g1, float g2, float g3, float Tf)
+// First-octant angle for 0 <= mn <= mx (integers <= 255 held in floats), mx1 = max(mx, 1).
+__device__ __forceinline__ float octant_angle(float mn, float mx1)
+{
+    const float r = __builtin_amdgcn_rcpf(mx1);
+    const float q0 = mn * r;
+    const float c = __builtin_fmaf(__builtin_fmaf(-mx1, q0, mn), r, q0);
+    const float cc = c * c;
+    return (((kP7 * cc + kP5) * cc + kP3) * cc + kP1) * c;
+}
+
+// LUT: the first-octant angle comes from a table in LDS (filled by slx_atan_lut_init_kernel with
+// octant_angle itself) instead of being recomputed: 12 fewer VALU slots per evaluation.
+template <bool LUT>
+__device__ __forceinline__ float wrapped_pix_4step(float g0, float g1, float g2, float g3, float Tf,
+                                                   const float *lds_tab = nullptr)
 {
     const float s2 = g0 - g2;
     const float c2 = g1 - g3;
     const float as = __builtin_fabsf(s2), ac = __builtin_fabsf(c2);
-    const float mx = __builtin_fmaxf(__builtin_fmaxf(as, ac), 1.0f);
-    const float mn = __builtin_fminf(as, ac);
-    const float r = __builtin_amdgcn_rcpf(mx);
-    const float q0 = mn * r;
-    const float c = __builtin_fmaf(__builtin_fmaf(-mx, q0, mn), r, q0);
-    const float cc = c * c;
-    float a = (((kP7 * cc + kP5) * cc + kP3) * cc + kP1) * c;
+    float a;
+    if constexpr (LUT) {
+        const float mx = __builtin_fmaxf(as, ac), mn = __builtin_fminf(as, ac);
+        // entry mx(mx+1)/2 + mn, exact in f32 (< 2^24)
+        const unsigned idx = (unsigned)__builtin_fmaf(__builtin_fmaf(mx, mx, mx), 0.5f, mn);
+        a = lds_tab[idx];
+    } else {
+        a = octant_angle(__builtin_fminf(as, ac), __builtin_fmaxf(__builtin_fmaxf(as, ac), 1.0f));
+    }
     a = (as > ac) ? 90.f - a : a;
     a = (c2 < 0.f) ? 180.f - a : a;
     a = (s2 < 0.f) ? 360.f - a : a;
@@ -94,6 +110,57 @@ __device__ __forceinline__ float pix_tail_literal(float sinValue, float cosValue
     pix = (float)((double)pix + 0.5);
     if (pix > (float)T) pix = pix - (float)T;
     return pix;
+}
+
+// IEEE-754 correctly rounded num/den without the range scaling and special-case fix-up of the
+// general f64 division: the same v_rcp_f64 + two Newton steps + residual correction hipcc emits,
+// so the quotient is bit-identical whenever no scaling would have happened.  Callers guarantee
+// 2^-200 <= |den| <= 2^200 and |num| in {0} U [2^-200, 2^200] (see tri_depth).
+__device__ __forceinline__ double div_f64_inrange(double num, double den)
+{
+    double r = __builtin_amdgcn_rcp(den);
+    r = __builtin_fma(r, __builtin_fma(-den, r, 1.0), r);
+    r = __builtin_fma(r, __builtin_fma(-den, r, 1.0), r);
+    const double q = num * r;
+    return __builtin_fma(__builtin_fma(-den, q, num), r, q);
+}
+
+// a7 for one pixel: z = -(cA - cB U)/(cC - cD U), FOV clamp, U == 0 / mask -> 0.
+template <bool LEAN>
+__device__ __forceinline__ double tri_depth(double Uv, double cC, double cD, double cA, double cB,
+                                            double fov_min, double fov_max, bool valid)
+{
+    const double num = cA - cB * Uv;
+    const double den = cC - cD * Uv;
+    double zz;
+    if constexpr (LEAN) {
+        // |num|, |den| <= 2^200 is guaranteed by the host (calibration magnitudes are checked);
+        // tiny or zero operands take the general division
+        const bool safe = __builtin_fabs(den) >= 0x1p-200 && (num == 0.0 || __builtin_fabs(num) >= 0x1p-200);
+        if (__builtin_expect(safe, 1)) zz = -div_f64_inrange(num, den);
+        else zz = -num / den;
+    } else {
+        zz = -num / den;
+    }
+    if ((zz < fov_min) || (zz > fov_max)) zz = 0.0;
+    if (Uv == 0.0 || !valid) zz = 0.0;
+    return zz;
+}
+
+// x2 for one pixel and one stage: k = (int)floor((Uprev - pf)/T + 0.5), U = pf + k*T.
+// FASTK: d = Uprev - pf is exact and a multiple of 2^-24 (every pix is), so the real value
+// d/T + 0.5 is either an integer or at least 2^-24/T away from one, while both the oracle's
+// rounded division and fma(d, 1/T, 0.5 + 2^-30/T) stay within 2^-35/T of it (T <= 2^14): the
+// biased fma lands on the same side of every integer as the exact value, ties included.
+template <bool FASTK>
+__device__ __forceinline__ double unwrap_stage(double Uprev, double pf, int T, double invT, double half_biased, int &k_out)
+{
+    const double d = Uprev - pf;
+    double kd;
+    if constexpr (FASTK) kd = __builtin_floor(__builtin_fma(d, invT, half_biased));
+    else kd = __builtin_floor(d / (double)T + 0.5);
+    k_out = (int)kd;
+    return __builtin_fma(kd, (double)T, pf);        // exact: |k*T| and pf share a 2^-24 grid below 2^53
 }
 
 // One dword = four horizontally adjacent pixels of one 8-bit plane.
@@ -182,7 +249,7 @@ __global__ __launch_bounds__(256) void slx_fused_kernel(const SlxKParams p)
                 const float Tf = (float)p.period[f];
 #pragma unroll
                 for (int j = 0; j < SLX_QUAD; j++)
-                    pix[f][j] = wrapped_pix_4step(ubyte(w0, j), ubyte(w1, j), ubyte(w2, j), ubyte(w3, j), Tf);
+                    pix[f][j] = wrapped_pix_4step<false>(ubyte(w0, j), ubyte(w1, j), ubyte(w2, j), ubyte(w3, j), Tf);
             } else {
                 float sy[SLX_QUAD] = {0.f, 0.f, 0.f, 0.f}, sx[SLX_QUAD] = {0.f, 0.f, 0.f, 0.f};
                 const int N = p.n_steps;
@@ -361,6 +428,152 @@ __global__ __launch_bounds__(256) void slx_fused_kernel(const SlxKParams p)
     }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Fast path: persistent workgroups walking column strips.
+//
+// A thread owns one quad column (4 adjacent pixels) and walks down `rows_per_band` rows of a
+// work unit, so everything that depends only on the column -- ((u-cx)*fv)*P00 and ((u-cx)*fv)*P20
+// of R/CCalculation.cpp:159-164 -- lives in registers for the whole launch, the per-row
+// addressing is one 32-bit add against scalar plane bases, and a wave's loads are 256-byte
+// row segments of every plane.  A workgroup covers `bands_per_wg` row bands side by side
+// (threads = quads_per_row * bands_per_wg) and strides over (frame-set, band group) units.
+// LUT: the first-octant angle table (128.5 KiB) sits in LDS, one workgroup per CU.
+// Eligible operands only (slx_strip_eligible): N == 4, dword-aligned planes, W % 4 == 0,
+// periods <= 2^14, calibration magnitudes that keep the depth quotient in range.
+template <int MODE, int F, bool LUT>
+__global__ __launch_bounds__(1024) void slx_strip_kernel(const SlxKParams p)
+{
+    constexpr bool HAS_GRAY = MODE == SLX_MODE_GRAY_PHASE;
+    extern __shared__ __attribute__((aligned(16))) float lds_tab[];
+    const unsigned t = threadIdx.x;
+    if constexpr (LUT) {
+        typedef float vec4 __attribute__((ext_vector_type(4)));
+        const vec4 *src = reinterpret_cast<const vec4 *>(p.atan_lut);
+        vec4 *dst = reinterpret_cast<vec4 *>(lds_tab);
+        for (unsigned i = t; i < SLX_ATAN_LUT_ENTRIES / 4; i += blockDim.x) dst[i] = src[i];
+        __syncthreads();
+    }
+    const unsigned QR = p.quads_per_row;
+    const unsigned sub = t / QR;
+    const unsigned cq = t - sub * QR;
+    const bool lane_ok = sub < p.bands_per_wg;
+    const unsigned W = (unsigned)p.width, H = (unsigned)p.height;
+    const unsigned row_stride = (unsigned)p.row_stride;
+
+    // column constants (a6): a = (u - cx)*fv ; aC = a*P00 ; aD = a*P20
+    double aC[SLX_QUAD], aD[SLX_QUAD];
+#pragma unroll
+    for (int j = 0; j < SLX_QUAD; j++) {
+        const double uc = (double)(int)(cq * SLX_QUAD + j) - p.cx;
+        const double a = uc * p.fv;
+        aC[j] = a * p.P00;
+        aD[j] = a * p.P20;
+    }
+    float Tf[F];
+#pragma unroll
+    for (int f = 0; f < F; f++) Tf[f] = (float)p.period[f];
+
+    for (unsigned unit = blockIdx.x; unit < p.total_units; unit += gridDim.x) {
+        const unsigned set = unit / p.units_per_set;
+        const unsigned ub = unit - set * p.units_per_set;
+        const unsigned row0 = (ub * p.bands_per_wg + sub) * p.rows_per_band;
+        const size_t pset = (size_t)set * p.phase_set_stride;
+        const size_t gset = (size_t)set * p.gray_set_stride;
+        double *zset = p.z + (size_t)set * p.out_set_stride;
+        unsigned voff = row0 * row_stride + cq * SLX_QUAD;
+        unsigned zoff = row0 * W + cq * SLX_QUAD;
+
+        for (unsigned i = 0; i < p.rows_per_band; i++, voff += row_stride, zoff += W) {
+            const unsigned row = row0 + i;
+            if (!(lane_ok && row < H)) continue;
+
+            float pix[F][SLX_QUAD];
+#pragma unroll
+            for (int f = 0; f < F; f++) {
+                const uint32_t w0 = *reinterpret_cast<const uint32_t *>(p.phase[f * 4 + 0] + pset + voff);
+                const uint32_t w1 = *reinterpret_cast<const uint32_t *>(p.phase[f * 4 + 1] + pset + voff);
+                const uint32_t w2 = *reinterpret_cast<const uint32_t *>(p.phase[f * 4 + 2] + pset + voff);
+                const uint32_t w3 = *reinterpret_cast<const uint32_t *>(p.phase[f * 4 + 3] + pset + voff);
+#pragma unroll
+                for (int j = 0; j < SLX_QUAD; j++)
+                    pix[f][j] = wrapped_pix_4step<LUT>(ubyte(w0, j), ubyte(w1, j), ubyte(w2, j), ubyte(w3, j), Tf[f], lds_tab);
+            }
+
+            double U[SLX_QUAD];
+            if constexpr (HAS_GRAY) {
+                unsigned code[SLX_QUAD] = {0u, 0u, 0u, 0u};
+                for (int b = p.gray_bits - 1; b >= 0; b--) {       // MSB first: code = 2*code + bit
+                    const uint32_t wa = *reinterpret_cast<const uint32_t *>(p.gray[2 * b] + gset + voff);
+                    const uint32_t wb = *reinterpret_cast<const uint32_t *>(p.gray[2 * b + 1] + gset + voff);
+#pragma unroll
+                    for (int j = 0; j < SLX_QUAD; j++)
+                        code[j] = code[j] + code[j] + (ibyte(wa, j) > ibyte(wb, j) ? 1u : 0u);
+                }
+                const double Td = (double)p.period[0], Sd = (double)p.gray_stripe;
+#pragma unroll
+                for (int j = 0; j < SLX_QUAD; j++) {
+                    int bin;
+                    if (p.std_gray) {                               // inverse reflected Gray code: prefix xor
+                        unsigned g = code[j];
+                        g ^= g >> 1;
+                        g ^= g >> 2;
+                        g ^= g >> 4;
+                        g ^= g >> 8;
+                        bin = (int)g;
+                    } else {
+                        bin = (int)p.lut[code[j]];
+                    }
+                    const double grayv = (double)bin * Sd;
+                    const double phaseVal = (double)pix[0][j];
+                    double ph = phaseVal;
+                    if ((bin & 1) == 0) {
+                        if (phaseVal > Td * 0.75) ph = phaseVal - Td;
+                    } else {
+                        if (phaseVal < Td * 0.25) ph = phaseVal + Td;
+                        ph = ph - 0.5 * Td;
+                    }
+                    U[j] = grayv + ph;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < SLX_QUAD; j++) {
+                    double Uf = (double)pix[0][j];
+#pragma unroll
+                    for (int f = 1; f < F; f++) {
+                        int k;
+                        Uf = unwrap_stage<true>(Uf, (double)pix[f][j], p.period[f], p.inv_period[f], p.half_biased[f], k);
+                    }
+                    U[j] = Uf;
+                }
+            }
+
+            const double vc = (double)((int)row + p.row_offset) - p.cy;
+            const double vf = vc * p.fu;
+            const double tvC = vf * p.P01, tvD = vf * p.P21;
+            typedef double vec2 __attribute__((ext_vector_type(2)));
+            double z[SLX_QUAD];
+#pragma unroll
+            for (int j = 0; j < SLX_QUAD; j++) {
+                const double cC = (aC[j] + tvC) + p.K1;
+                const double cD = (aD[j] + tvD) + p.K2;
+                z[j] = tri_depth<true>(U[j], cC, cD, p.cA, p.cB, p.fov_min, p.fov_max, true);
+            }
+            vec2 *d = reinterpret_cast<vec2 *>(zset + zoff);
+            d[0] = vec2{z[0], z[1]};
+            d[1] = vec2{z[2], z[3]};
+        }
+    }
+}
+
+// One workgroup per |max| value, one thread per |min| <= |max|.
+__global__ __launch_bounds__(256) void slx_atan_lut_init_kernel(float *table)
+{
+    const unsigned mx = blockIdx.x, mn = threadIdx.x;
+    if (mn > mx) return;
+    table[mx * (mx + 1) / 2 + mn] = octant_angle((float)mn, __builtin_fmaxf((float)mx, 1.0f));
+}
+
 typedef void (*kernel_fn)(const SlxKParams);
 
 template <int MODE, int F>
@@ -394,13 +607,46 @@ kernel_fn pick(int mode, int F, bool n4, bool aux)
     return nullptr;
 }
 
+template <int MODE>
+kernel_fn pick_strip(int F, bool lut)
+{
+    switch (F) {
+    case 1: return lut ? slx_strip_kernel<MODE, 1, true> : slx_strip_kernel<MODE, 1, false>;
+    case 2: return lut ? slx_strip_kernel<MODE, 2, true> : slx_strip_kernel<MODE, 2, false>;
+    case 3: return lut ? slx_strip_kernel<MODE, 3, true> : slx_strip_kernel<MODE, 3, false>;
+    case 4: return lut ? slx_strip_kernel<MODE, 4, true> : slx_strip_kernel<MODE, 4, false>;
+    }
+    return nullptr;
+}
+
 }  // namespace
 
-int slx_num_variants(void) { return 1; }
+int slx_num_variants(void) { return 4; }
 
-int slx_launch_fused(const SlxKParams &kp, int mode, bool aux, int n_sets, int variant, void *stream)
+int slx_launch_atan_lut_init(float *table, void *stream)
 {
-    (void)variant;
+    hipLaunchKernelGGL(slx_atan_lut_init_kernel, dim3(256), dim3(256), 0, (hipStream_t)stream, table);
+    return (int)hipGetLastError();
+}
+
+bool slx_strip_eligible(const SlxKParams &kp, int mode, bool aux)
+{
+    if (aux || !kp.aligned || kp.n_steps != 4) return false;
+    if (mode != SLX_MODE_MULTIFREQ && mode != SLX_MODE_GRAY_PHASE) return false;
+    if (kp.quads_per_row == 0 || kp.quads_per_row > 1024) return false;
+    for (int f = 0; f < kp.n_freq; f++)
+        if (kp.period[f] > (1 << 14)) return false;
+    if ((unsigned long long)kp.row_stride * (unsigned)kp.height >= (1ull << 32)) return false;   // 32-bit plane offsets
+    if ((unsigned long long)kp.width * (unsigned)kp.height >= (1ull << 29)) return false;          // 32-bit output offsets
+    // the depth quotient's operands must stay far inside the double range (tri_depth<LEAN>)
+    const double big = 0x1p90;
+    for (double v : {kp.cA, kp.cB, kp.K1, kp.K2, kp.P00, kp.P01, kp.P20, kp.P21, kp.fu, kp.fv, kp.cx, kp.cy})
+        if (!(__builtin_fabs(v) < big)) return false;
+    return true;
+}
+
+static int launch_generic(const SlxKParams &kp, int mode, bool aux, int n_sets, void *stream)
+{
     kernel_fn fn = pick(mode, kp.n_freq, kp.n_steps == 4, aux);
     if (!fn) return (int)hipErrorInvalidValue;
     const unsigned block = 256;
@@ -415,5 +661,43 @@ int slx_launch_fused(const SlxKParams &kp, int mode, bool aux, int n_sets, int v
     if (grid_x == 0 || n_sets <= 0) return (int)hipErrorInvalidValue;
     // operand shapes were validated by the caller (slx_api.cpp: check_launch_shapes)
     hipLaunchKernelGGL(fn, dim3(grid_x, (unsigned)n_sets, 1), dim3(block, 1, 1), 0, (hipStream_t)stream, kp);
+    return (int)hipGetLastError();
+}
+
+int slx_launch_fused(const SlxKParams &kp_in, int mode, bool aux, int n_sets, int variant, void *stream)
+{
+    const bool can_strip = slx_strip_eligible(kp_in, mode, aux);
+    if (variant == SLX_VARIANT_GENERIC || !can_strip) {
+        if (variant == SLX_VARIANT_STRIP || variant == SLX_VARIANT_STRIP_LUT) return (int)hipErrorInvalidValue;
+        return launch_generic(kp_in, mode, aux, n_sets, stream);
+    }
+    const bool lut = variant == SLX_VARIANT_STRIP_LUT || (variant == SLX_VARIANT_AUTO && kp_in.atan_lut != nullptr && n_sets * kp_in.height >= 2048);
+    if (lut && !kp_in.atan_lut) return (int)hipErrorInvalidValue;
+    SlxKParams kp = kp_in;
+    // geometry: as many row bands side by side as fit in 1024 threads
+    const unsigned QR = kp.quads_per_row;
+    kp.bands_per_wg = 1024u / QR;
+    const unsigned threads = ((QR * kp.bands_per_wg + 63u) / 64u) * 64u;
+    const unsigned n_cu = 256, wg_per_cu = lut ? 1u : 2u;
+    const unsigned target_wgs = n_cu * wg_per_cu;
+    // rows per band: enough units to balance the persistent grid (>= 8 per workgroup when the
+    // launch is large), never more than 32 rows so that the tail stays short
+    const unsigned long long rows_total = (unsigned long long)kp.height * (unsigned)n_sets;
+    unsigned rb = (unsigned)(rows_total / ((unsigned long long)kp.bands_per_wg * target_wgs * 8ull));
+    if (rb < 1) rb = 1;
+    if (rb > 32) rb = 32;
+    kp.rows_per_band = rb;
+    kp.units_per_set = ((unsigned)kp.height + kp.bands_per_wg * rb - 1) / (kp.bands_per_wg * rb);
+    kp.total_units = kp.units_per_set * (unsigned)n_sets;
+    const unsigned grid = kp.total_units < target_wgs ? kp.total_units : target_wgs;
+    kernel_fn fn = mode == SLX_MODE_MULTIFREQ ? pick_strip<SLX_MODE_MULTIFREQ>(kp.n_freq, lut)
+                                              : pick_strip<SLX_MODE_GRAY_PHASE>(1, lut);
+    if (!fn || grid == 0) return (int)hipErrorInvalidValue;
+    const size_t lds = lut ? sizeof(float) * SLX_ATAN_LUT_ENTRIES : 0;
+    if (lut) {
+        hipError_t e = hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(fn, dim3(grid, 1, 1), dim3(threads, 1, 1), lds, (hipStream_t)stream, kp);
     return (int)hipGetLastError();
 }

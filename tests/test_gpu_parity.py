@@ -176,6 +176,130 @@ def test_mask_halo_crosses_wave_boundaries(api, oracle, synth):
     assert_same(got, ref, ("mask", "z"))
 
 
+# ------------------------------------------------------------------ kernel variants (fast paths)
+def quadrant_tie_planes(spec, reps=8):
+    """Every combination of quarter-turn phases across the frequencies, several amplitudes: these make
+    (U_{f-1} - pix_f)/T_f + 0.5 land exactly on integers (rounding ties of the temporal unwrap)."""
+    F, H, W = spec["n_freq"], spec["height"], spec["width"]
+    planes = np.zeros((F * 4, H, W), dtype=np.uint8)
+    combos = 4 ** F
+    idx = np.arange(H * W).reshape(H, W)
+    amp = 20 + 30 * ((idx // combos) % reps)
+    base = 128
+    for f in range(F):
+        quad = (idx // (4 ** f)) % 4                     # phase = quad * 90 degrees
+        s = np.array([0, 1, 0, -1])[quad] * amp          # I0 - I2 ~ 2 sin
+        c = np.array([1, 0, -1, 0])[quad] * amp          # I1 - I3 ~ 2 cos
+        planes[f * 4 + 0] = base + s // 2
+        planes[f * 4 + 2] = base - s // 2
+        planes[f * 4 + 1] = base + c // 2
+        planes[f * 4 + 3] = base - c // 2
+    return planes
+
+
+@pytest.mark.parametrize("name", ["C2", "C4", "C5x4"])
+def test_unwrap_rounding_ties(api, oracle, synth, name):
+    if name == "C5x4":
+        spec = dict(small_spec(synth, "C5", 256, 16), n_steps=4)
+    else:
+        spec = small_spec(synth, name, 256, 16)
+    spec["fov_min"], spec["fov_max"] = -1e300, 1e300
+    ph = quadrant_tie_planes(spec)
+    ref = oracle.pipeline(spec, ph, None, want=("z", "k", "U", "pix"))
+    # the construction does hit ties: (U_prev - pix)/T + 0.5 is an exact integer somewhere
+    T = spec["periods"]
+    r = (ref["pix"][0] - ref["pix"][1]) / T[1] + 0.5
+    assert np.any(r == np.floor(r))
+    got = api.decode_frameset(spec, ph, None, want=("z", "k", "U"), variant=api.VARIANT_GENERIC)
+    assert_same(got, ref, ("z", "k", "U"))
+    for variant in (api.VARIANT_AUTO, api.VARIANT_STRIP, api.VARIANT_STRIP_LUT):
+        got = api.decode_frameset(spec, ph, None, want=("z",), variant=variant)
+        assert_same(got, ref, ("z",))
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2, 3])
+def test_variants_exhaustive_wrapped_phase_through_depth(api, oracle, synth, variant):
+    """The fast kernels only emit depth; with an unbounded FOV depth is a strictly monotonic function
+    of pix, so depth parity over all 511 x 511 inputs checks their wrapped phase exhaustively
+    (the LDS angle table included)."""
+    planes = exhaustive_planes(512)
+    for T in (40, 30, 240, 1920, 4096, 16384):
+        spec = dict(synth.make_spec("C1"), width=512, height=511, periods=[T])
+        spec["calib"] = synth.scaled_calibration(512, 511, 1280)
+        spec["fov_min"], spec["fov_max"] = -1e300, 1e300
+        ref = oracle.pipeline(spec, planes, None, want=("z", "pix"))
+        got = api.decode_frameset(spec, planes, None, want=("z",), variant=variant)
+        assert np.array_equal(got["z"], ref["z"], equal_nan=True), (variant, T, int((got["z"] != ref["z"]).sum()))
+        z, pix = ref["z"].ravel(), ref["pix"][0].ravel()     # distinct pix -> distinct z within a row
+        row = 200 * 512
+        pr, zr = pix[row:row + 511], z[row:row + 511]
+        assert len(np.unique(np.round(zr, 12))) >= len(np.unique(pr)) * 0.99
+
+
+@pytest.mark.parametrize("name,scene", [("C1", "sphere"), ("C1x4", "tilted"), ("REF", "tilted"), ("C2", "tilted"), ("C4", "sphere")])
+@pytest.mark.parametrize("variant", [1, 2, 3])
+def test_variants_full_size(api, oracle, synth, name, scene, variant):
+    spec = synth.make_spec(name)
+    ph, gr, _ = synth.render(spec, scene, seed=11, noise_sigma=3.0)
+    ref = oracle.pipeline(spec, ph, gr, want=("z",), threads=8)
+    got = api.decode_frameset(spec, ph, gr, want=("z",), variant=variant)
+    assert_same(got, ref, ("z",))
+
+
+@pytest.mark.parametrize("variant", [2, 3])
+@pytest.mark.parametrize("shape", [(7, 64), (33, 1024), (130, 4096), (1, 4), (1200, 8)])
+def test_strip_kernel_geometries(api, oracle, synth, variant, shape):
+    """Row bands, partial last bands, one-quad-wide and 1024-quad-wide strips, Gray + phase and 4-frequency."""
+    h, w = shape
+    for name in ("C1x4", "C5x4"):
+        spec = small_spec(synth, "C5" if name == "C5x4" else name, w, h)
+        spec["n_steps"] = 4
+        ph, gr = synth.random_planes(spec, seed=h + w)
+        ref = oracle.pipeline(spec, ph, gr, want=("z",))
+        got = api.decode_frameset(spec, ph, gr, want=("z",), variant=variant)
+        assert_same(got, ref, ("z",))
+
+
+def test_strip_variant_refuses_ineligible_operands(api, synth):
+    spec = small_spec(synth, "C2", 63, 8)                   # width not a multiple of 4
+    ph, _ = synth.random_planes(spec, seed=1)
+    with api.Context(spec) as ctx:
+        ctx.set_variant(api.VARIANT_STRIP)
+        ctx.set_frames(ph, None)
+        with pytest.raises(api.SlxError) as e:
+            ctx.decode()
+        assert e.value.code == api.ERR_UNAVAILABLE
+        ctx.set_variant(api.VARIANT_AUTO)                   # automatic selection falls back to the generic kernel
+        ctx.decode()
+    big = dict(small_spec(synth, "C2", 64, 8), periods=[40000, 160, 20])   # period > 2^14: exact-division kernel
+    ph, _ = synth.random_planes(big, seed=2)
+    with api.Context(big) as ctx:
+        ctx.set_variant(api.VARIANT_STRIP_LUT)
+        ctx.set_frames(ph, None)
+        with pytest.raises(api.SlxError):
+            ctx.decode()
+
+
+def test_degenerate_depth_quotients(api, oracle, synth):
+    """den == 0, num == 0 and 0/0 in z = -(cA - cB U)/(cC - cD U): the in-range fast division must hand
+    these to the IEEE division (inf -> FOV clamp -> 0, NaN stays NaN as in the reference's compare chain)."""
+    spec = small_spec(synth, "C1", 64, 8)
+    cal = {"cam": [1.0, 0, 0.0, 0, 1.0, 0.0, 0, 0, 1], "pro": [1.0, 0, 0, 0, 1.0, 0, 0, 0, 1.0],
+           "rot": [1.0, 0, 0, 0, 1.0, 0, 0, 0, 0.0], "trans": [0.0, 0.0, 0.0]}      # P row 2 == 0, cA == cB == 0
+    spec["calib"] = cal
+    ph, _ = synth.random_planes(spec, seed=5)
+    ref = oracle.pipeline(spec, ph, None, want=("z",))
+    for variant in (0, 1, 2, 3):
+        got = api.decode_frameset(spec, ph, None, want=("z",), variant=variant)
+        assert np.array_equal(got["z"], ref["z"], equal_nan=True), variant
+    cal2 = dict(cal, rot=[1.0, 0, 0, 0, 1.0, 0, 0, 0, 1.0], trans=[0.0, 0.0, 0.0])  # num == 0 everywhere, den varies
+    spec["calib"] = cal2
+    ref = oracle.pipeline(spec, ph, None, want=("z",))
+    for variant in (0, 1, 2, 3):
+        got = api.decode_frameset(spec, ph, None, want=("z",), variant=variant)
+        assert np.array_equal(got["z"], ref["z"], equal_nan=True), variant
+
+
 # ------------------------------------------------------------------ the boundary itself
 def test_device_frames_strides_and_batch(api, oracle, synth, torch_cuda):
     torch = torch_cuda
