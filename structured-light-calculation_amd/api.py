@@ -29,7 +29,7 @@ SYMBOLS = [
     "slx_validate_config", "slx_create", "slx_destroy", "slx_last_error", "slx_set_gray_lut",
     "slx_set_frame", "slx_decode", "slx_decode_batch", "slx_synchronize", "slx_get_output",
     "slx_get_depth", "slx_output_device_ptr", "slx_get_calibration", "slx_enable_timing",
-    "slx_last_decode_ms", "slx_set_variant", "slx_version",
+    "slx_last_decode_ms", "slx_debug_stamps", "slx_set_variant", "slx_version",
 ]
 
 
@@ -81,6 +81,7 @@ def lib():
         L.slx_enable_timing.argtypes = [vp, C.c_int]
         L.slx_last_decode_ms.argtypes = [vp, C.POINTER(C.c_float)]
         L.slx_set_variant.argtypes = [vp, C.c_int]
+        L.slx_debug_stamps.argtypes = [vp, vp, sz]
         for name in SYMBOLS:
             if name not in ("slx_destroy", "slx_last_error"):
                 getattr(L, name).restype = C.c_int
@@ -244,6 +245,14 @@ class Context:
         ms = C.c_float()
         self._check(lib().slx_last_decode_ms(self._h, C.byref(ms)))
         return ms.value
+
+    def debug_stamps(self, tensor):
+        """tensor: CUDA int64 tensor of >= 32768 elements (or None to stop)."""
+        if tensor is None:
+            self._check(lib().slx_debug_stamps(self._h, None, 0))
+        else:
+            self._stamps = tensor
+            self._check(lib().slx_debug_stamps(self._h, tensor.data_ptr(), tensor.numel()))
 
     def set_variant(self, v):
         self._check(lib().slx_set_variant(self._h, int(v)))

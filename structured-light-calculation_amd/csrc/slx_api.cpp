@@ -538,6 +538,14 @@ int slx_last_decode_ms(slx_ctx *ctx, float *ms)
     return SLX_OK;
 }
 
+int slx_debug_stamps(slx_ctx *ctx, unsigned long long *device_words, size_t n_words)
+{
+    if (!ctx) return SLX_ERR_INVALID_ARG;
+    if (device_words && n_words < 4 * 8192) return fail(ctx, SLX_ERR_INVALID_ARG, "stamp buffer needs at least 32768 words");
+    ctx->kp.stamps = device_words;
+    return SLX_OK;
+}
+
 int slx_set_variant(slx_ctx *ctx, int variant)
 {
     if (!ctx) return SLX_ERR_INVALID_ARG;

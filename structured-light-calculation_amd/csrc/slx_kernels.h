@@ -41,10 +41,13 @@ struct SlxKParams {
     double half_biased[SLX_MAX_FREQ];           // 0.5 + 2^-30/T_f
     const float *atan_lut;                      // first-octant angle table, SLX_ATAN_LUT_ENTRIES floats (device)
     int std_gray;                               // lut is the reflected Gray code: bin = prefix-xor(gray)
-    unsigned bands_per_wg;                      // row bands a workgroup walks side by side (threads = quads_per_row * bands_per_wg)
-    unsigned rows_per_band;                     // rows one thread walks per work unit
-    unsigned units_per_set;                     // ceil(H / (bands_per_wg * rows_per_band))
-    unsigned total_units;                       // units_per_set * n_sets
+    unsigned interleave;                        // rows laid end to end so that their quads fill whole waves: 64 / gcd(quads_per_row, 64)
+    unsigned chunks_per_group;                  // interleave * quads_per_row / 64 (64-quad chunks of a row group)
+    unsigned rows_per_lane;                     // rows one lane walks per work item (even)
+    unsigned items_per_set;                     // ceil(H / (interleave * rows_per_lane)) * chunks_per_group
+    unsigned long long total_items;             // items_per_set * n_sets
+    int dbg;                                    // experiments only (SLX_DBG): 1 = skip stores, 2 = skip compute
+    unsigned long long *stamps;                 // diagnostics: 4 words per workgroup (s_memtime / s_memrealtime at start, end) or null
 };
 
 // First-octant table of cv::fastAtan2: entry mx*(mx+1)/2 + mn holds the angle (degrees, before

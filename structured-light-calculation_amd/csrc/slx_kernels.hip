@@ -16,6 +16,8 @@
 // R/ = DynaFrame/DynaFrame/ of the reference repository.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "slx_kernels.h"
 
 #pragma clang fp contract(off)
@@ -56,12 +58,31 @@ __device__ __forceinline__ float octant_angle(float mn, float mx1)
 
 // LUT: the first-octant angle comes from a table in LDS (filled by slx_atan_lut_init_kernel with
 // octant_angle itself) instead of being recomputed: 12 fewer VALU slots per evaluation.
+// (byte J of a) - (byte J of b) in one VALU slot (SDWA operand selects); hipcc finds this form
+// for only some of the 24 differences of a row step.
+template <int J>
+__device__ __forceinline__ int byte_diff(uint32_t a, uint32_t b)
+{
+    int d;
+    if constexpr (J == 0)
+        asm("v_sub_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:BYTE_0" : "=v"(d) : "v"(a), "v"(b));
+    else if constexpr (J == 1)
+        asm("v_sub_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:BYTE_1" : "=v"(d) : "v"(a), "v"(b));
+    else if constexpr (J == 2)
+        asm("v_sub_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:BYTE_2" : "=v"(d) : "v"(a), "v"(b));
+    else
+        asm("v_sub_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:BYTE_3" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+
 template <bool LUT>
 __device__ __forceinline__ float wrapped_pix_4step(float g0, float g1, float g2, float g3, float Tf,
-                                                   const float *lds_tab = nullptr)
+                                                   const float *lds_tab = nullptr);
+
+// s2 = I0 - I2, c2 = I1 - I3 (twice the reference's sinValue / cosValue, see below)
+template <bool LUT>
+__device__ __forceinline__ float wrapped_pix_from_diffs(float s2, float c2, float Tf, const float *lds_tab = nullptr)
 {
-    const float s2 = g0 - g2;
-    const float c2 = g1 - g3;
     const float as = __builtin_fabsf(s2), ac = __builtin_fabsf(c2);
     float a;
     if constexpr (LUT) {
@@ -81,6 +102,12 @@ __device__ __forceinline__ float wrapped_pix_4step(float g0, float g1, float g2,
     pix = pix + 0.5f;
     pix = (pix > Tf) ? pix - Tf : pix;
     return pix;
+}
+
+template <bool LUT>
+__device__ __forceinline__ float wrapped_pix_4step(float g0, float g1, float g2, float g3, float Tf, const float *lds_tab)
+{
+    return wrapped_pix_from_diffs<LUT>(g0 - g2, g1 - g3, Tf, lds_tab);
 }
 
 // a2 literally (any float inputs): used by the x1 path, N != 4.
@@ -134,11 +161,11 @@ __device__ __forceinline__ double tri_depth(double Uv, double cC, double cD, dou
     const double den = cC - cD * Uv;
     double zz;
     if constexpr (LEAN) {
-        // |num|, |den| <= 2^200 is guaranteed by the host (calibration magnitudes are checked);
-        // tiny or zero operands take the general division
-        const bool safe = __builtin_fabs(den) >= 0x1p-200 && (num == 0.0 || __builtin_fabs(num) >= 0x1p-200);
-        if (__builtin_expect(safe, 1)) zz = -div_f64_inrange(num, den);
-        else zz = -num / den;
+        // The host guarantees |num|, |den| < 2^111 (slx_strip_eligible) and num is 0 or >= one ulp of
+        // cA (no tiny non-zero numerators), so the unscaled sequence can only go wrong when den is
+        // zero or denormal -- and then it yields NaN, never a wrong finite value.  NaN -> general division.
+        zz = -div_f64_inrange(num, den);
+        if (__builtin_expect(zz != zz, 0)) zz = -num / den;
     } else {
         zz = -num / den;
     }
@@ -430,23 +457,80 @@ __global__ __launch_bounds__(256) void slx_fused_kernel(const SlxKParams p)
 
 
 // ------------------------------------------------------------------------------------------
-// Fast path: persistent workgroups walking column strips.
+// Fast path: waves walking column strips.
 //
-// A thread owns one quad column (4 adjacent pixels) and walks down `rows_per_band` rows of a
-// work unit, so everything that depends only on the column -- ((u-cx)*fv)*P00 and ((u-cx)*fv)*P20
-// of R/CCalculation.cpp:159-164 -- lives in registers for the whole launch, the per-row
-// addressing is one 32-bit add against scalar plane bases, and a wave's loads are 256-byte
-// row segments of every plane.  A workgroup covers `bands_per_wg` row bands side by side
-// (threads = quads_per_row * bands_per_wg) and strides over (frame-set, band group) units.
-// LUT: the first-octant angle table (128.5 KiB) sits in LDS, one workgroup per CU.
+// A work item is 64 quad columns x `rows_per_lane` rows of one frame-set.  Every lane owns one
+// quad column (4 adjacent pixels) for the whole item and walks down its rows, so what depends
+// only on the column -- ((u-cx)*fv)*P00 and ((u-cx)*fv)*P20 of R/CCalculation.cpp:159-164 --
+// stays in registers, the per-row addressing is one 32-bit add against scalar plane bases, and a
+// wave reads 256-byte row segments of every plane.  When the quads of a row are not a multiple
+// of 64, `interleave` consecutive rows are laid end to end (interleave * quads_per_row is) and a
+// lane walks rows with that stride, so no lane idles.  Two schedules:
+//  * PERSIST = false: one item per wave, workgroups of 4 waves, far more workgroups than the chip
+//    holds -- the hardware dispatcher back-fills SIMDs as waves retire;
+//  * PERSIST = true (needed by LUT: the table is loaded once per workgroup): wave w takes items
+//    w, w + NW, w + 2 NW ...  The SIMD arbitrates oldest-first, which would let each SIMD's oldest
+//    wave race ahead and retire early, leaving the SIMD under-occupied for the rest of the launch
+//    (measured: wave lifetimes 154..329 us for equal work); every wave therefore rotates its
+//    s_setprio level each row so that the four waves of a SIMD advance together.
+// The next row's dwords (or the next item's first row) are in flight while a row is decoded, and a
+// row's stores are issued one row late so that the wait for the loads never waits for a store.
+// LUT: the first-octant angle table (128.5 KiB) sits in LDS, one 16-wave workgroup per CU.
 // Eligible operands only (slx_strip_eligible): N == 4, dword-aligned planes, W % 4 == 0,
 // periods <= 2^14, calibration magnitudes that keep the depth quotient in range.
-template <int MODE, int F, bool LUT>
-__global__ __launch_bounds__(1024) void slx_strip_kernel(const SlxKParams p)
+struct StripPos {
+    unsigned set, row, cq, row_step;   // first row of the item for this lane; rows advance by row_step
+    unsigned out_row[2];               // store slot k of this lane: first row ...
+    unsigned out_off[2];               // ... and offset in doubles within the frame-set's depth map
+};
+
+// Output transposition.  After a row step lane l holds depths of pixels 4l..4l+3 of the wave's 256
+// pixel run; a store instruction is fastest when lane l writes the 16 bytes next to lane l-1's
+// (tools/membench: 6.56 vs 5.86 TB/s for this traffic mix, with nontemporal stores), i.e. when it
+// holds pixels 2s, 2s+1 for slot s = k*64 + l of store k.  The wave writes its 2 KiB to LDS as it
+// has them and reads them back in slot order; slot s belongs to source lane s/2.
+__device__ __forceinline__ StripPos strip_locate(const SlxKParams &p, unsigned item)
+{
+    StripPos s;
+    const unsigned lane = threadIdx.x & 63u;
+    s.set = item / p.items_per_set;
+    const unsigned rem = item - s.set * p.items_per_set;
+    const unsigned g = rem / p.chunks_per_group;
+    const unsigned c = rem - g * p.chunks_per_group;
+    const unsigned row_base = g * p.rows_per_lane * p.interleave;
+    const unsigned idx = c * 64u + lane;
+    const unsigned sub = idx / p.quads_per_row;
+    s.cq = idx - sub * p.quads_per_row;
+    s.row = row_base + sub;
+    s.row_step = p.interleave;
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        const unsigned slot = (unsigned)k * 64u + lane;
+        const unsigned vidx = c * 64u + (slot >> 1);              // the lane whose pixels this slot stores
+        const unsigned vsub = vidx / p.quads_per_row;
+        const unsigned vcq = vidx - vsub * p.quads_per_row;
+        s.out_row[k] = row_base + vsub;
+        s.out_off[k] = (row_base + vsub) * (unsigned)p.width + vcq * SLX_QUAD + (slot & 1u) * 2u;
+    }
+    return s;
+}
+
+template <int MODE, int F, bool LUT, bool PERSIST>
+__global__ __launch_bounds__(PERSIST ? 1024 : 256) void slx_strip_kernel(const SlxKParams p)
 {
     constexpr bool HAS_GRAY = MODE == SLX_MODE_GRAY_PHASE;
-    extern __shared__ __attribute__((aligned(16))) float lds_tab[];
+    constexpr int NP = F * 4;                     // phase planes
+    constexpr unsigned ROW_DW = NP * 64;          // one row of the fringe stack in LDS, dwords per wave
+    typedef double vec2 __attribute__((ext_vector_type(2)));
+    typedef __attribute__((address_space(3))) void lds_void;
+    typedef const __attribute__((address_space(1))) void glb_void;
+    // LDS: [angle table (LUT only)] then per wave [fringe-stack ring: 2 rows x NP planes x 256 B] [2 KiB depth staging]
+    extern __shared__ __attribute__((aligned(16))) float lds_raw[];
+    float *lds_tab = lds_raw;
     const unsigned t = threadIdx.x;
+    const unsigned lane = t & 63u;
+    uint32_t *ring = reinterpret_cast<uint32_t *>(lds_raw + (LUT ? SLX_ATAN_LUT_ENTRIES : 0)) + (t >> 6) * (2u * ROW_DW + 512u);
+    vec2 *stage = reinterpret_cast<vec2 *>(ring + 2u * ROW_DW);
     if constexpr (LUT) {
         typedef float vec4 __attribute__((ext_vector_type(4)));
         const vec4 *src = reinterpret_cast<const vec4 *>(p.atan_lut);
@@ -454,115 +538,217 @@ __global__ __launch_bounds__(1024) void slx_strip_kernel(const SlxKParams p)
         for (unsigned i = t; i < SLX_ATAN_LUT_ENTRIES / 4; i += blockDim.x) dst[i] = src[i];
         __syncthreads();
     }
-    const unsigned QR = p.quads_per_row;
-    const unsigned sub = t / QR;
-    const unsigned cq = t - sub * QR;
-    const bool lane_ok = sub < p.bands_per_wg;
+    const unsigned wave_id = blockIdx.x * (blockDim.x >> 6) + (t >> 6);
+    if (p.stamps && lane == 0 && wave_id < 8192) {   // diagnostics only (slx_debug_stamps)
+        p.stamps[4 * wave_id + 0] = __builtin_amdgcn_s_memtime();
+        p.stamps[4 * wave_id + 2] = __builtin_amdgcn_s_memrealtime();
+    }
     const unsigned W = (unsigned)p.width, H = (unsigned)p.height;
     const unsigned row_stride = (unsigned)p.row_stride;
-
-    // column constants (a6): a = (u - cx)*fv ; aC = a*P00 ; aD = a*P20
-    double aC[SLX_QUAD], aD[SLX_QUAD];
-#pragma unroll
-    for (int j = 0; j < SLX_QUAD; j++) {
-        const double uc = (double)(int)(cq * SLX_QUAD + j) - p.cx;
-        const double a = uc * p.fv;
-        aC[j] = a * p.P00;
-        aD[j] = a * p.P20;
-    }
+    const unsigned RB = p.rows_per_lane;
+    const unsigned last_row = H - 1u;
     float Tf[F];
 #pragma unroll
     for (int f = 0; f < F; f++) Tf[f] = (float)p.period[f];
 
-    for (unsigned unit = blockIdx.x; unit < p.total_units; unit += gridDim.x) {
-        const unsigned set = unit / p.units_per_set;
-        const unsigned ub = unit - set * p.units_per_set;
-        const unsigned row0 = (ub * p.bands_per_wg + sub) * p.rows_per_band;
-        const size_t pset = (size_t)set * p.phase_set_stride;
-        const size_t gset = (size_t)set * p.gray_set_stride;
-        double *zset = p.z + (size_t)set * p.out_set_stride;
-        unsigned voff = row0 * row_stride + cq * SLX_QUAD;
-        unsigned zoff = row0 * W + cq * SLX_QUAD;
+    const unsigned n_waves = gridDim.x * (blockDim.x >> 6);
+    unsigned long long ticket = wave_id;
+    const unsigned prio_rank = (t >> 6) >> 2;        // waves w, w+4, w+8, w+12 of a workgroup share a SIMD
+    // one row of depth waits in LDS until the next step has issued its loads
+    bool pending = false;
+    unsigned pend_off[2] = {0u, 0u};
+    bool pend_ok[2] = {false, false};
+    double *pend_set = p.z;
+    unsigned slot = 0;                               // ring slot holding the current row
+    // hipcc does not track LDS-DMA: the waits are ours.  vmcnt retires in issue order, so "all but the NP
+    // youngest" = everything up to and including the previous row's DMA (and any store issued before it).
+    auto wait_dma = [&](bool one_row_younger) {
+        if (one_row_younger) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
 
-        for (unsigned i = 0; i < p.rows_per_band; i++, voff += row_stride, zoff += W) {
-            const unsigned row = row0 + i;
-            if (!(lane_ok && row < H)) continue;
-
-            float pix[F][SLX_QUAD];
+    // The fringe stack of one row -- NP dwords per lane -- goes HBM -> LDS by DMA (no VGPRs): plane k of
+    // the wave lands at ring[slot][k][lane].
+    auto issue_loads = [&](unsigned dst_slot, unsigned set, unsigned row, unsigned cq) {
+        const unsigned r = row < last_row ? row : last_row;            // rows past the tile: harmless re-read
+        const size_t off = (size_t)set * p.phase_set_stride + (size_t)(r * row_stride + cq * SLX_QUAD);
+        uint32_t *dst = ring + dst_slot * ROW_DW;
 #pragma unroll
-            for (int f = 0; f < F; f++) {
-                const uint32_t w0 = *reinterpret_cast<const uint32_t *>(p.phase[f * 4 + 0] + pset + voff);
-                const uint32_t w1 = *reinterpret_cast<const uint32_t *>(p.phase[f * 4 + 1] + pset + voff);
-                const uint32_t w2 = *reinterpret_cast<const uint32_t *>(p.phase[f * 4 + 2] + pset + voff);
-                const uint32_t w3 = *reinterpret_cast<const uint32_t *>(p.phase[f * 4 + 3] + pset + voff);
+        for (int k = 0; k < NP; k++)
+            __builtin_amdgcn_global_load_lds((glb_void *)(p.phase[k] + off), (lds_void *)(dst + k * 64), 4, 0, 0);
+    };
+    auto flush = [&]() {                                               // last row's depth, in slot order
+        if (!pending) return;
 #pragma unroll
-                for (int j = 0; j < SLX_QUAD; j++)
-                    pix[f][j] = wrapped_pix_4step<LUT>(ubyte(w0, j), ubyte(w1, j), ubyte(w2, j), ubyte(w3, j), Tf[f], lds_tab);
-            }
-
-            double U[SLX_QUAD];
-            if constexpr (HAS_GRAY) {
-                unsigned code[SLX_QUAD] = {0u, 0u, 0u, 0u};
-                for (int b = p.gray_bits - 1; b >= 0; b--) {       // MSB first: code = 2*code + bit
-                    const uint32_t wa = *reinterpret_cast<const uint32_t *>(p.gray[2 * b] + gset + voff);
-                    const uint32_t wb = *reinterpret_cast<const uint32_t *>(p.gray[2 * b + 1] + gset + voff);
-#pragma unroll
-                    for (int j = 0; j < SLX_QUAD; j++)
-                        code[j] = code[j] + code[j] + (ibyte(wa, j) > ibyte(wb, j) ? 1u : 0u);
-                }
-                const double Td = (double)p.period[0], Sd = (double)p.gray_stripe;
-#pragma unroll
-                for (int j = 0; j < SLX_QUAD; j++) {
-                    int bin;
-                    if (p.std_gray) {                               // inverse reflected Gray code: prefix xor
-                        unsigned g = code[j];
-                        g ^= g >> 1;
-                        g ^= g >> 2;
-                        g ^= g >> 4;
-                        g ^= g >> 8;
-                        bin = (int)g;
-                    } else {
-                        bin = (int)p.lut[code[j]];
-                    }
-                    const double grayv = (double)bin * Sd;
-                    const double phaseVal = (double)pix[0][j];
-                    double ph = phaseVal;
-                    if ((bin & 1) == 0) {
-                        if (phaseVal > Td * 0.75) ph = phaseVal - Td;
-                    } else {
-                        if (phaseVal < Td * 0.25) ph = phaseVal + Td;
-                        ph = ph - 0.5 * Td;
-                    }
-                    U[j] = grayv + ph;
-                }
-            } else {
-#pragma unroll
-                for (int j = 0; j < SLX_QUAD; j++) {
-                    double Uf = (double)pix[0][j];
-#pragma unroll
-                    for (int f = 1; f < F; f++) {
-                        int k;
-                        Uf = unwrap_stage<true>(Uf, (double)pix[f][j], p.period[f], p.inv_period[f], p.half_biased[f], k);
-                    }
-                    U[j] = Uf;
-                }
-            }
-
-            const double vc = (double)((int)row + p.row_offset) - p.cy;
-            const double vf = vc * p.fu;
-            const double tvC = vf * p.P01, tvD = vf * p.P21;
-            typedef double vec2 __attribute__((ext_vector_type(2)));
-            double z[SLX_QUAD];
-#pragma unroll
-            for (int j = 0; j < SLX_QUAD; j++) {
-                const double cC = (aC[j] + tvC) + p.K1;
-                const double cD = (aD[j] + tvD) + p.K2;
-                z[j] = tri_depth<true>(U[j], cC, cD, p.cA, p.cB, p.fov_min, p.fov_max, true);
-            }
-            vec2 *d = reinterpret_cast<vec2 *>(zset + zoff);
-            d[0] = vec2{z[0], z[1]};
-            d[1] = vec2{z[2], z[3]};
+        for (int k = 0; k < 2; k++) {
+            const vec2 v = stage[k * 64 + lane];
+            if (pend_ok[k]) __builtin_nontemporal_store(v, reinterpret_cast<vec2 *>(pend_set + pend_off[k]));
         }
+        pending = false;
+    };
+
+    // rows are issued two ahead: while row i is decoded the DMA of rows i+1 and i+2 is in flight
+    // (2 * NP * 256 B per wave), with only two ring slots: row i+2 reuses row i's slot once it is read
+    StripPos pos;
+    unsigned ahead = 0;                              // 1 when the DMA of the row after the current one is in flight
+    auto row_of = [&](const StripPos &q, unsigned i) { return q.row + i * q.row_step; };
+    if (ticket < p.total_items) {
+        pos = strip_locate(p, (unsigned)ticket);
+        issue_loads(0, pos.set, row_of(pos, 0), pos.cq);
+        if (RB > 1) {
+            issue_loads(1, pos.set, row_of(pos, 1), pos.cq);
+            ahead = 1;
+        }
+    }
+
+    while (ticket < p.total_items) {
+        const unsigned long long ticket_next = PERSIST ? ticket + n_waves : ~0ull;
+        const bool more = ticket_next < p.total_items;
+        StripPos pos_next = pos;
+        if (more) pos_next = strip_locate(p, (unsigned)ticket_next);
+
+        // column constants (a6): a = (u - cx)*fv ; aC = a*P00 ; aD = a*P20
+        double aC[SLX_QUAD], aD[SLX_QUAD];
+#pragma unroll
+        for (int j = 0; j < SLX_QUAD; j++) {
+            const double uc = (double)(int)(pos.cq * SLX_QUAD + j) - p.cx;
+            const double a = uc * p.fv;
+            aC[j] = a * p.P00;
+            aD[j] = a * p.P20;
+        }
+        const size_t gset = (size_t)pos.set * p.gray_set_stride;
+        double *zset = p.z + (size_t)pos.set * p.out_set_stride;
+
+        for (unsigned i = 0; i < RB; i++) {
+            const unsigned row = pos.row + i * pos.row_step;
+            const bool live = row < H;
+            if constexpr (PERSIST) {                                    // rotate the issue priority, see the header
+                switch ((prio_rank + i) & 3u) {
+                case 0: __builtin_amdgcn_s_setprio(0); break;
+                case 1: __builtin_amdgcn_s_setprio(1); break;
+                case 2: __builtin_amdgcn_s_setprio(2); break;
+                default: __builtin_amdgcn_s_setprio(3); break;
+                }
+            }
+            // this row's dwords out of the ring (the wait for its DMA lands here), then last row's
+            // stores, then the DMA of the next row: nothing younger than the awaited loads is in flight
+            uint32_t cur[NP];
+            wait_dma(ahead != 0);
+            {
+                const uint32_t *src = ring + slot * ROW_DW + lane;
+#pragma unroll
+                for (int k = 0; k < NP; k++) cur[k] = src[k * 64];
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the slot is free once it has been read
+            flush();
+            // row i+2 (or the matching row of the next item) into the slot just read
+            if (i + 2 < RB) {
+                issue_loads(slot, pos.set, row_of(pos, i + 2), pos.cq);
+                ahead = 1;
+            } else if (more) {                                          // RB >= 2: i + 2 - RB is row 0 or 1 of the next item
+                issue_loads(slot, pos_next.set, row_of(pos_next, i + 2 - RB), pos_next.cq);
+                ahead = 1;
+            } else {
+                ahead = 0;                                              // nothing younger than the next row's DMA
+            }
+            slot ^= 1u;
+
+            double z[SLX_QUAD] = {0.0, 0.0, 0.0, 0.0};
+            if (live && p.dbg == 2) {                                   // experiment: memory traffic only
+                uint32_t acc = 0;
+#pragma unroll
+                for (int k = 0; k < NP; k++) acc += cur[k];
+#pragma unroll
+                for (int j = 0; j < SLX_QUAD; j++) z[j] = (double)(acc >> j);
+            } else if (live) {
+                float pix[F][SLX_QUAD];
+#pragma unroll
+                for (int f = 0; f < F; f++) {
+                    const uint32_t w0 = cur[f * 4 + 0], w1 = cur[f * 4 + 1], w2 = cur[f * 4 + 2], w3 = cur[f * 4 + 3];
+                    pix[f][0] = wrapped_pix_from_diffs<LUT>((float)byte_diff<0>(w0, w2), (float)byte_diff<0>(w1, w3), Tf[f], lds_tab);
+                    pix[f][1] = wrapped_pix_from_diffs<LUT>((float)byte_diff<1>(w0, w2), (float)byte_diff<1>(w1, w3), Tf[f], lds_tab);
+                    pix[f][2] = wrapped_pix_from_diffs<LUT>((float)byte_diff<2>(w0, w2), (float)byte_diff<2>(w1, w3), Tf[f], lds_tab);
+                    pix[f][3] = wrapped_pix_from_diffs<LUT>((float)byte_diff<3>(w0, w2), (float)byte_diff<3>(w1, w3), Tf[f], lds_tab);
+                }
+
+                double U[SLX_QUAD];
+                if constexpr (HAS_GRAY) {
+                    const unsigned voff = row * row_stride + pos.cq * SLX_QUAD;
+                    unsigned code[SLX_QUAD] = {0u, 0u, 0u, 0u};
+                    for (int b = p.gray_bits - 1; b >= 0; b--) {       // MSB first: code = 2*code + bit
+                        const uint32_t wa = *reinterpret_cast<const uint32_t *>(p.gray[2 * b] + gset + voff);
+                        const uint32_t wb = *reinterpret_cast<const uint32_t *>(p.gray[2 * b + 1] + gset + voff);
+#pragma unroll
+                        for (int j = 0; j < SLX_QUAD; j++)
+                            code[j] = code[j] + code[j] + (ibyte(wa, j) > ibyte(wb, j) ? 1u : 0u);
+                    }
+                    const double Td = (double)p.period[0], Sd = (double)p.gray_stripe;
+#pragma unroll
+                    for (int j = 0; j < SLX_QUAD; j++) {
+                        int bin;
+                        if (p.std_gray) {                               // inverse reflected Gray code: prefix xor
+                            unsigned g = code[j];
+                            g ^= g >> 1;
+                            g ^= g >> 2;
+                            g ^= g >> 4;
+                            g ^= g >> 8;
+                            bin = (int)g;
+                        } else {
+                            bin = (int)p.lut[code[j]];
+                        }
+                        const double grayv = (double)bin * Sd;
+                        const double phaseVal = (double)pix[0][j];
+                        double ph = phaseVal;
+                        if ((bin & 1) == 0) {
+                            if (phaseVal > Td * 0.75) ph = phaseVal - Td;
+                        } else {
+                            if (phaseVal < Td * 0.25) ph = phaseVal + Td;
+                            ph = ph - 0.5 * Td;
+                        }
+                        U[j] = grayv + ph;
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < SLX_QUAD; j++) {
+                        double Uf = (double)pix[0][j];
+#pragma unroll
+                        for (int f = 1; f < F; f++) {
+                            int k;
+                            Uf = unwrap_stage<true>(Uf, (double)pix[f][j], p.period[f], p.inv_period[f], p.half_biased[f], k);
+                        }
+                        U[j] = Uf;
+                    }
+                }
+
+                const double vc = (double)((int)row + p.row_offset) - p.cy;
+                const double vf = vc * p.fu;
+                const double tvC = vf * p.P01, tvD = vf * p.P21;
+#pragma unroll
+                for (int j = 0; j < SLX_QUAD; j++) {
+                    const double cC = (aC[j] + tvC) + p.K1;
+                    const double cD = (aD[j] + tvD) + p.K2;
+                    z[j] = tri_depth<true>(U[j], cC, cD, p.cA, p.cB, p.fov_min, p.fov_max, true);
+                }
+            }
+            // stage this row's depth; it is stored (slot order) at the top of the next step
+            stage[2 * lane + 0] = vec2{z[0], z[1]};
+            stage[2 * lane + 1] = vec2{z[2], z[3]};
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                pend_ok[k] = (pos.out_row[k] + i * pos.row_step) < H && p.dbg != 1;
+                pend_off[k] = pos.out_off[k] + i * pos.row_step * W;
+            }
+            pend_set = zset;
+            pending = true;
+        }
+        ticket = ticket_next;
+        pos = pos_next;
+    }
+    flush();
+    if (p.stamps && lane == 0 && wave_id < 8192) {
+        p.stamps[4 * wave_id + 1] = __builtin_amdgcn_s_memtime();
+        p.stamps[4 * wave_id + 3] = __builtin_amdgcn_s_memrealtime();
     }
 }
 
@@ -611,10 +797,10 @@ template <int MODE>
 kernel_fn pick_strip(int F, bool lut)
 {
     switch (F) {
-    case 1: return lut ? slx_strip_kernel<MODE, 1, true> : slx_strip_kernel<MODE, 1, false>;
-    case 2: return lut ? slx_strip_kernel<MODE, 2, true> : slx_strip_kernel<MODE, 2, false>;
-    case 3: return lut ? slx_strip_kernel<MODE, 3, true> : slx_strip_kernel<MODE, 3, false>;
-    case 4: return lut ? slx_strip_kernel<MODE, 4, true> : slx_strip_kernel<MODE, 4, false>;
+    case 1: return lut ? slx_strip_kernel<MODE, 1, true, true> : slx_strip_kernel<MODE, 1, false, false>;
+    case 2: return lut ? slx_strip_kernel<MODE, 2, true, true> : slx_strip_kernel<MODE, 2, false, false>;
+    case 3: return lut ? slx_strip_kernel<MODE, 3, true, true> : slx_strip_kernel<MODE, 3, false, false>;
+    case 4: return lut ? slx_strip_kernel<MODE, 4, true, true> : slx_strip_kernel<MODE, 4, false, false>;
     }
     return nullptr;
 }
@@ -671,30 +857,48 @@ int slx_launch_fused(const SlxKParams &kp_in, int mode, bool aux, int n_sets, in
         if (variant == SLX_VARIANT_STRIP || variant == SLX_VARIANT_STRIP_LUT) return (int)hipErrorInvalidValue;
         return launch_generic(kp_in, mode, aux, n_sets, stream);
     }
-    const bool lut = variant == SLX_VARIANT_STRIP_LUT || (variant == SLX_VARIANT_AUTO && kp_in.atan_lut != nullptr && n_sets * kp_in.height >= 2048);
+    const bool lut = variant == SLX_VARIANT_STRIP_LUT || (variant == SLX_VARIANT_AUTO && kp_in.atan_lut != nullptr && (long long)n_sets * kp_in.height >= 2048);
     if (lut && !kp_in.atan_lut) return (int)hipErrorInvalidValue;
     SlxKParams kp = kp_in;
-    // geometry: as many row bands side by side as fit in 1024 threads
+    // geometry: `interleave` rows end to end fill whole waves; an item is 64 quads x rows_per_lane rows
     const unsigned QR = kp.quads_per_row;
-    kp.bands_per_wg = 1024u / QR;
-    const unsigned threads = ((QR * kp.bands_per_wg + 63u) / 64u) * 64u;
-    const unsigned n_cu = 256, wg_per_cu = lut ? 1u : 2u;
-    const unsigned target_wgs = n_cu * wg_per_cu;
-    // rows per band: enough units to balance the persistent grid (>= 8 per workgroup when the
-    // launch is large), never more than 32 rows so that the tail stays short
-    const unsigned long long rows_total = (unsigned long long)kp.height * (unsigned)n_sets;
-    unsigned rb = (unsigned)(rows_total / ((unsigned long long)kp.bands_per_wg * target_wgs * 8ull));
-    if (rb < 1) rb = 1;
-    if (rb > 32) rb = 32;
-    kp.rows_per_band = rb;
-    kp.units_per_set = ((unsigned)kp.height + kp.bands_per_wg * rb - 1) / (kp.bands_per_wg * rb);
-    kp.total_units = kp.units_per_set * (unsigned)n_sets;
-    const unsigned grid = kp.total_units < target_wgs ? kp.total_units : target_wgs;
+    unsigned g = QR, h = 64;
+    while (h) { const unsigned r = g % h; g = h; h = r; }          // gcd(QR, 64)
+    kp.interleave = 64u / g;
+    kp.chunks_per_group = kp.interleave * QR / 64u;
+    unsigned rb = 16;                                                // even; ~1 % item-switch overhead
+    if (const char *e = getenv("SLX_DBG")) kp.dbg = atoi(e);
+    if (const char *e = getenv("SLX_STRIP_ROWS")) {                  // tuning hook
+        const int v = atoi(e);
+        if (v >= 2 && v <= 64 && v % 2 == 0) rb = (unsigned)v;
+    }
+    while (rb > 2 && (unsigned long long)kp.interleave * (rb / 2) * 4ull >= (unsigned)kp.height) rb -= 2;   // small tiles: smaller items
+    kp.rows_per_lane = rb;
+    const unsigned rows_group = kp.interleave * rb;
+    const unsigned groups = ((unsigned)kp.height + rows_group - 1) / rows_group;
+    kp.items_per_set = groups * kp.chunks_per_group;
+    kp.total_items = (unsigned long long)kp.items_per_set * (unsigned)n_sets;
+    if (kp.total_items >= (1ull << 32)) return (int)hipErrorInvalidValue;
+    // LDS per wave: 2 rows of the fringe stack (n_freq * 4 planes * 256 B each) + 2 KiB of depth staging
+    const unsigned lds_wave = 2u * (unsigned)kp.n_freq * 4u * 256u + 2048u;
+    const unsigned lut_bytes = (unsigned)sizeof(float) * SLX_ATAN_LUT_ENTRIES;
+    unsigned threads = 256u;
+    if (lut) {                                        // as many waves as fit next to the 128.5 KiB table (<= 16)
+        unsigned w = (160u * 1024u - lut_bytes) / lds_wave;
+        if (w > 16u) w = 16u;
+        if (w == 0u) return (int)hipErrorInvalidValue;
+        threads = w * 64u;
+    }
+    const unsigned waves_per_wg = threads / 64u;
+    const unsigned long long need_wgs = (kp.total_items + waves_per_wg - 1) / waves_per_wg;
+    // persistent (LUT) schedule: one 16-wave workgroup per CU; otherwise one item per wave
+    const unsigned n_cu = 256;
+    const unsigned grid = (unsigned)(lut && need_wgs > n_cu ? n_cu : need_wgs);
     kernel_fn fn = mode == SLX_MODE_MULTIFREQ ? pick_strip<SLX_MODE_MULTIFREQ>(kp.n_freq, lut)
                                               : pick_strip<SLX_MODE_GRAY_PHASE>(1, lut);
     if (!fn || grid == 0) return (int)hipErrorInvalidValue;
-    const size_t lds = lut ? sizeof(float) * SLX_ATAN_LUT_ENTRIES : 0;
-    if (lut) {
+    const size_t lds = (lut ? lut_bytes : 0u) + (size_t)waves_per_wg * lds_wave;
+    if (lds > 48u * 1024u) {
         hipError_t e = hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
     }

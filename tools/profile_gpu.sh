@@ -17,7 +17,7 @@ timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_wri
 # keep only the rows of our kernel from the (large) per-dispatch counter files
 for d in pmc_sq pmc_sq2 pmc_fetch pmc_write; do
   f=$(ls $OUT/$d/*/*counter_collection.csv 2>/dev/null | head -1)
-  if [ -n "$f" ]; then head -1 $f > $OUT/$d.csv; grep slx_fused $f >> $OUT/$d.csv || true; fi
+  if [ -n "$f" ]; then head -1 $f > $OUT/$d.csv; grep "slx_" $f >> $OUT/$d.csv || true; fi
 done
 rm -rf $OUT/pmc_sq $OUT/pmc_sq2 $OUT/pmc_fetch $OUT/pmc_write
 echo profiled $TAG

@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Diagnostic (GPU box): in-kernel clock and per-workgroup duration of the strip kernel on the bench workload."""
+import importlib, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+sys.argv = [sys.argv[0]] + sys.argv[1:]
+variant = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+n_sets = int(sys.argv[2]) if len(sys.argv) > 2 else 32
+synth = importlib.import_module("structured-light-calculation_amd.synth")
+api = importlib.import_module("structured-light-calculation_amd.api")
+spec = synth.make_spec("C4")
+H, W = spec["height"], spec["width"]
+mode = sys.argv[3] if len(sys.argv) > 3 else "random"
+if mode == "random":
+    phase = torch.randint(0, 256, (n_sets, 12, H, W), dtype=torch.uint8, device="cuda")
+elif mode == "zeros":
+    phase = torch.zeros((n_sets, 12, H, W), dtype=torch.uint8, device="cuda")
+else:
+    sys.path.insert(0, ROOT)
+    import bench
+    phase = bench.make_batch(torch, synth, spec, n_sets, torch.device("cuda"), seed=1)
+    if mode == "bench_nomask":
+        pass
+print("data mode", mode)
+z = torch.empty((n_sets, H, W), dtype=torch.float64, device="cuda")
+ctx = api.Context(spec)
+ctx.set_variant(variant)
+st = torch.zeros(32768, dtype=torch.int64, device="cuda")
+s = torch.cuda.Stream(); torch.cuda.set_stream(s)
+for _ in range(300):       # ~2 s of back-to-back launches so the clock settles
+    ctx.decode_batch(n_sets, phase, None, z, stream=s.cuda_stream)
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record(s)
+for _ in range(100):
+    ctx.decode_batch(n_sets, phase, None, z, stream=s.cuda_stream)
+e1.record(s)
+torch.cuda.synchronize()
+print("event-timed launch: %.1f us" % (e0.elapsed_time(e1) * 10.0))
+print("fraction of z > 0: %.3f" % float((z > 0).double().mean()))
+ctx.debug_stamps(st)
+ctx.decode_batch(n_sets, phase, None, z, stream=s.cuda_stream)
+torch.cuda.synchronize()
+w = st.cpu().numpy().reshape(-1, 4)
+w = w[w[:, 1] > 0]
+cyc = (w[:, 1] - w[:, 0]).astype(float)
+real = (w[:, 3] - w[:, 2]).astype(float) / 100e6       # s_memrealtime ticks at 100 MHz
+t0, t1 = w[:, 2].min(), w[:, 3].max()
+print("waves", len(w), "kernel span %.1f us" % ((t1 - t0) / 100.0))
+print("per-wave duration us: min %.1f median %.1f max %.1f" % (real.min() * 1e6, sorted(real)[len(real) // 2] * 1e6, real.max() * 1e6))
+print("in-kernel clock GHz: median %.3f" % (sorted(cyc / real)[len(cyc) // 2] / 1e9))
+print("start skew us: %.1f" % ((w[:, 2].max() - t0) / 100.0))
