@@ -217,7 +217,7 @@ def main():
                        "periods": spec["periods"], "sharding": "by frame-set, no data-path collective", "kernel_variant": args.variant},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "kernel": {0: "slx_strip_kernel<MULTIFREQ,F=3,LUT> (auto)", 1: "slx_fused_kernel<MULTIFREQ,F=3,N4>", 2: "slx_strip_kernel<MULTIFREQ,F=3>", 3: "slx_strip_kernel<MULTIFREQ,F=3,LUT>"}[args.variant], "launch_ms": kernel_ms_max,
+                         "kernel": {0: "slx_strip_kernel<MULTIFREQ,F=3> (auto)", 1: "slx_fused_kernel<MULTIFREQ,F=3,N4>", 2: "slx_strip_kernel<MULTIFREQ,F=3>"}[args.variant], "launch_ms": kernel_ms_max,
                          "algorithmic_bytes_per_launch": bytes_per_launch},
             "achieved_hbm_gbps_per_gpu": achieved,
             "cpu_baseline": cpu_single, "cpu_baseline_all_cores": cpu_multi,

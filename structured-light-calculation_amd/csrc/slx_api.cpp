@@ -39,7 +39,6 @@ struct slx_ctx {
     bool timed = false;
     std::vector<int16_t> lut;
     int16_t *d_lut = nullptr;
-    float *d_atan_lut = nullptr;
     std::vector<Plane> phase, gray;
     void *out[SLX_OUT_COUNT] = {};
     size_t out_bytes[SLX_OUT_COUNT] = {};
@@ -232,7 +231,6 @@ void slx_destroy(slx_ctx *ctx)
     for (void *o : ctx->out)
         if (o) (void)hipFree(o);
     if (ctx->d_lut) (void)hipFree(ctx->d_lut);
-    if (ctx->d_atan_lut) (void)hipFree(ctx->d_atan_lut);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -305,14 +303,6 @@ int slx_create(const slx_config *cfg, slx_ctx **out)
         // constants of the fast temporal unwrap (slx_kernels.hip: unwrap_stage<true>)
         kp.inv_period[f] = 1.0 / (double)kp.period[f];
         kp.half_biased[f] = 0.5 + 0x1p-30 / (double)kp.period[f];
-    }
-    if (mode_has_depth(c.mode) && mode_has_phase(c.mode) && c.n_steps == 4) {
-        // first-octant angle table of the fast path, computed on the device by the same code
-        SLX_TRY(hipMalloc((void **)&ctx->d_atan_lut, sizeof(float) * SLX_ATAN_LUT_ENTRIES));
-        int e3 = slx_launch_atan_lut_init(ctx->d_atan_lut, ctx->stream);
-        if (e3 != 0) return bail(hip_fail(ctx, (hipError_t)e3, "angle table init"));
-        SLX_TRY(hipStreamSynchronize(ctx->stream));
-        kp.atan_lut = ctx->d_atan_lut;
     }
 
     if (mode_has_gray(c.mode)) {

@@ -37,9 +37,10 @@ struct SlxKParams {
     // calibration scalars of R/CCalculation.cpp:151-164: cC = ((u-cx)*fv)*P00 + ((v-cy)*fu)*P01 + K1
     double cx, cy, fu, fv, P00, P01, K1, P20, P21, K2, cA, cB;
     // ---- fast path (slx_strip_kernel) ----
+    const uint8_t *phase_base;                  // lowest phase-plane address: the buffer descriptor's base
+    unsigned phase_rel[SLX_MAX_PHASE_PLANES];   // phase[k] - phase_base (fits 32 bits, checked by slx_strip_eligible)
     double inv_period[SLX_MAX_FREQ];            // RN(1/T_f)
     double half_biased[SLX_MAX_FREQ];           // 0.5 + 2^-30/T_f
-    const float *atan_lut;                      // first-octant angle table, SLX_ATAN_LUT_ENTRIES floats (device)
     int std_gray;                               // lut is the reflected Gray code: bin = prefix-xor(gray)
     unsigned interleave;                        // rows laid end to end so that their quads fill whole waves: 64 / gcd(quads_per_row, 64)
     unsigned chunks_per_group;                  // interleave * quads_per_row / 64 (64-quad chunks of a row group)
@@ -50,19 +51,10 @@ struct SlxKParams {
     unsigned long long *stamps;                 // diagnostics: 4 words per workgroup (s_memtime / s_memrealtime at start, end) or null
 };
 
-// First-octant table of cv::fastAtan2: entry mx*(mx+1)/2 + mn holds the angle (degrees, before
-// the octant fix-ups) for |min| = mn <= |max| = mx, both in 0..255.
-#define SLX_ATAN_LUT_ENTRIES (256 * 257 / 2)
-
-// Kernel variants (slx_set_variant): 0 = automatic, 1 = generic kernel only,
-// 2 = strip kernel computing the angle, 3 = strip kernel with the LDS angle table.
+// Kernel variants (slx_set_variant): 0 = automatic, 1 = generic kernel only, 2 = strip kernel only.
 #define SLX_VARIANT_AUTO 0
 #define SLX_VARIANT_GENERIC 1
 #define SLX_VARIANT_STRIP 2
-#define SLX_VARIANT_STRIP_LUT 3
-
-// Fills the angle table on the device (same arithmetic as the in-kernel evaluation).
-int slx_launch_atan_lut_init(float *table, void *stream);
 
 // True when the strip kernel can run this configuration / these operands.
 bool slx_strip_eligible(const SlxKParams &kp, int mode, bool aux);

@@ -36,28 +36,6 @@ constexpr float kInv360 = 1.0f / 360.0f;
 __device__ __forceinline__ float ubyte(uint32_t w, int j) { return (float)((w >> (8 * j)) & 0xffu); }
 __device__ __forceinline__ int ibyte(uint32_t w, int j) { return (int)((w >> (8 * j)) & 0xffu); }
 
-// a1 + a2 for N == 4, all in f32.
-// Identities used (each argued in DESIGN.md, each covered by the exhaustive 511x511 test):
-//  * sinValue/cosValue = (g0-g2)/2, (g1-g3)/2 enter cvFastArctan only through their signs
-//    and the ratio min/max, and (a/2)/(b/2) == a/b exactly, so the halving is dropped;
-//  * for integer 0 <= a <= b <= 255, b >= 1, RN(a/b) == fma(fma(-b,q0,a), r, q0) with
-//    r = v_rcp_f32(b), q0 = a*r (the quotient is never within 1/510 ulp of a rounding tie);
-//    ax + (float)DBL_EPSILON == ax for ax >= 0.5, and 0/(0+eps) == 0/1;
-//  * RN(x/360) by the same residual correction with r = RN(1/360);
-//  * (float)((double)q * (double)T) == q*T in f32 (the double product is exact), and
-//    (float)((double)pix + 0.5) == pix + 0.5f (the double sum is exact for pix = 0 or >= 2^-11).
-// First-octant angle for 0 <= mn <= mx (integers <= 255 held in floats), mx1 = max(mx, 1).
-__device__ __forceinline__ float octant_angle(float mn, float mx1)
-{
-    const float r = __builtin_amdgcn_rcpf(mx1);
-    const float q0 = mn * r;
-    const float c = __builtin_fmaf(__builtin_fmaf(-mx1, q0, mn), r, q0);
-    const float cc = c * c;
-    return (((kP7 * cc + kP5) * cc + kP3) * cc + kP1) * c;
-}
-
-// LUT: the first-octant angle comes from a table in LDS (filled by slx_atan_lut_init_kernel with
-// octant_angle itself) instead of being recomputed: 12 fewer VALU slots per evaluation.
 // (byte J of a) - (byte J of b) in one VALU slot (SDWA operand selects); hipcc finds this form
 // for only some of the 24 differences of a row step.
 template <int J>
@@ -75,24 +53,27 @@ __device__ __forceinline__ int byte_diff(uint32_t a, uint32_t b)
     return d;
 }
 
-template <bool LUT>
-__device__ __forceinline__ float wrapped_pix_4step(float g0, float g1, float g2, float g3, float Tf,
-                                                   const float *lds_tab = nullptr);
-
-// s2 = I0 - I2, c2 = I1 - I3 (twice the reference's sinValue / cosValue, see below)
-template <bool LUT>
-__device__ __forceinline__ float wrapped_pix_from_diffs(float s2, float c2, float Tf, const float *lds_tab = nullptr)
+// a1 + a2 for N == 4, all in f32, from s2 = I0 - I2 and c2 = I1 - I3 (twice the reference's
+// sinValue / cosValue; integers in [-255, 255] held in floats).
+// Identities used (each argued in DESIGN.md, each covered by the exhaustive 511x511 tests):
+//  * sinValue/cosValue enter cvFastArctan only through their signs and the ratio min/max, and
+//    (a/2)/(b/2) == a/b exactly, so the halving is dropped;
+//  * for integer 0 <= a <= b <= 255, b >= 1, RN(a/b) == fma(fma(-b,q0,a), r, q0) with
+//    r = v_rcp_f32(b), q0 = a*r (the quotient is never within 1/510 ulp of a rounding tie);
+//    ax + (float)DBL_EPSILON == ax for ax >= 0.5, and 0/(0+eps) == 0/1;
+//  * RN(x/360) by the same residual correction with r = RN(1/360);
+//  * (float)((double)q * (double)T) == q*T in f32 (the double product is exact), and
+//    (float)((double)pix + 0.5) == pix + 0.5f (the double sum is exact for pix = 0 or >= 2^-11).
+__device__ __forceinline__ float wrapped_pix_from_diffs(float s2, float c2, float Tf)
 {
     const float as = __builtin_fabsf(s2), ac = __builtin_fabsf(c2);
-    float a;
-    if constexpr (LUT) {
-        const float mx = __builtin_fmaxf(as, ac), mn = __builtin_fminf(as, ac);
-        // entry mx(mx+1)/2 + mn, exact in f32 (< 2^24)
-        const unsigned idx = (unsigned)__builtin_fmaf(__builtin_fmaf(mx, mx, mx), 0.5f, mn);
-        a = lds_tab[idx];
-    } else {
-        a = octant_angle(__builtin_fminf(as, ac), __builtin_fmaxf(__builtin_fmaxf(as, ac), 1.0f));
-    }
+    const float mx = __builtin_fmaxf(__builtin_fmaxf(as, ac), 1.0f);
+    const float mn = __builtin_fminf(as, ac);
+    const float r = __builtin_amdgcn_rcpf(mx);
+    const float q0 = mn * r;
+    const float c = __builtin_fmaf(__builtin_fmaf(-mx, q0, mn), r, q0);
+    const float cc = c * c;
+    float a = (((kP7 * cc + kP5) * cc + kP3) * cc + kP1) * c;
     a = (as > ac) ? 90.f - a : a;
     a = (c2 < 0.f) ? 180.f - a : a;
     a = (s2 < 0.f) ? 360.f - a : a;
@@ -104,10 +85,9 @@ __device__ __forceinline__ float wrapped_pix_from_diffs(float s2, float c2, floa
     return pix;
 }
 
-template <bool LUT>
-__device__ __forceinline__ float wrapped_pix_4step(float g0, float g1, float g2, float g3, float Tf, const float *lds_tab)
+__device__ __forceinline__ float wrapped_pix_4step(float g0, float g1, float g2, float g3, float Tf)
 {
-    return wrapped_pix_from_diffs<LUT>(g0 - g2, g1 - g3, Tf, lds_tab);
+    return wrapped_pix_from_diffs(g0 - g2, g1 - g3, Tf);
 }
 
 // a2 literally (any float inputs): used by the x1 path, N != 4.
@@ -276,7 +256,7 @@ __global__ __launch_bounds__(256) void slx_fused_kernel(const SlxKParams p)
                 const float Tf = (float)p.period[f];
 #pragma unroll
                 for (int j = 0; j < SLX_QUAD; j++)
-                    pix[f][j] = wrapped_pix_4step<false>(ubyte(w0, j), ubyte(w1, j), ubyte(w2, j), ubyte(w3, j), Tf);
+                    pix[f][j] = wrapped_pix_4step(ubyte(w0, j), ubyte(w1, j), ubyte(w2, j), ubyte(w3, j), Tf);
             } else {
                 float sy[SLX_QUAD] = {0.f, 0.f, 0.f, 0.f}, sx[SLX_QUAD] = {0.f, 0.f, 0.f, 0.f};
                 const int N = p.n_steps;
@@ -457,38 +437,32 @@ __global__ __launch_bounds__(256) void slx_fused_kernel(const SlxKParams p)
 
 
 // ------------------------------------------------------------------------------------------
-// Fast path: waves walking column strips.
+// Fast path: waves walking column strips, fringe stack staged through LDS.
 //
-// A work item is 64 quad columns x `rows_per_lane` rows of one frame-set.  Every lane owns one
-// quad column (4 adjacent pixels) for the whole item and walks down its rows, so what depends
-// only on the column -- ((u-cx)*fv)*P00 and ((u-cx)*fv)*P20 of R/CCalculation.cpp:159-164 --
-// stays in registers, the per-row addressing is one 32-bit add against scalar plane bases, and a
-// wave reads 256-byte row segments of every plane.  When the quads of a row are not a multiple
-// of 64, `interleave` consecutive rows are laid end to end (interleave * quads_per_row is) and a
-// lane walks rows with that stride, so no lane idles.  Two schedules:
-//  * PERSIST = false: one item per wave, workgroups of 4 waves, far more workgroups than the chip
-//    holds -- the hardware dispatcher back-fills SIMDs as waves retire;
-//  * PERSIST = true (needed by LUT: the table is loaded once per workgroup): wave w takes items
-//    w, w + NW, w + 2 NW ...  The SIMD arbitrates oldest-first, which would let each SIMD's oldest
-//    wave race ahead and retire early, leaving the SIMD under-occupied for the rest of the launch
-//    (measured: wave lifetimes 154..329 us for equal work); every wave therefore rotates its
-//    s_setprio level each row so that the four waves of a SIMD advance together.
-// The next row's dwords (or the next item's first row) are in flight while a row is decoded, and a
-// row's stores are issued one row late so that the wait for the loads never waits for a store.
-// LUT: the first-octant angle table (128.5 KiB) sits in LDS, one 16-wave workgroup per CU.
+// A work item is 64 quad columns x `rows_per_lane` rows of one frame-set, one item per wave, far
+// more waves than the chip holds (the dispatcher back-fills SIMDs as waves retire).  Every lane owns
+// one quad column (4 adjacent pixels) and walks down its rows, so what depends only on the column
+// -- (u-cx)*fv of R/CCalculation.cpp:159-164 -- stays in registers and the per-row addressing is a
+// handful of adds.  When the quads of a row are not a multiple of 64, `interleave` consecutive rows
+// are laid end to end (interleave * quads_per_row is) and a lane walks rows with that stride, so no
+// lane idles.
+//   in : one row of the fringe stack = NP dwords per lane goes HBM -> LDS by DMA (global_load_lds,
+//        no VGPRs), two rows ahead of the row being decoded, through a two-slot ring per wave;
+//   out: a row's depth is written to LDS as the lanes have it (pixels 4l..4l+3) and read back in
+//        store order (lane l next to lane l-1), then stored nontemporally one step late, so that
+//        the wait for a row's DMA never waits for a store (tools/membench.hip: lane-contiguous
+//        nontemporal stores move this traffic mix at 6.56 TB/s, 32-byte-stride pairs at 5.86).
+// hipcc does not track LDS-DMA in its s_waitcnt insertion: the vmcnt waits here are explicit.
 // Eligible operands only (slx_strip_eligible): N == 4, dword-aligned planes, W % 4 == 0,
 // periods <= 2^14, calibration magnitudes that keep the depth quotient in range.
 struct StripPos {
-    unsigned set, row, cq, row_step;   // first row of the item for this lane; rows advance by row_step
+    unsigned set, row, cq;             // frame-set, first row and quad column of this lane
     unsigned out_row[2];               // store slot k of this lane: first row ...
     unsigned out_off[2];               // ... and offset in doubles within the frame-set's depth map
 };
 
-// Output transposition.  After a row step lane l holds depths of pixels 4l..4l+3 of the wave's 256
-// pixel run; a store instruction is fastest when lane l writes the 16 bytes next to lane l-1's
-// (tools/membench: 6.56 vs 5.86 TB/s for this traffic mix, with nontemporal stores), i.e. when it
-// holds pixels 2s, 2s+1 for slot s = k*64 + l of store k.  The wave writes its 2 KiB to LDS as it
-// has them and reads them back in slot order; slot s belongs to source lane s/2.
+// Store slot s = k*64 + lane of store instruction k holds pixels 2s, 2s+1 of the wave's 256-pixel
+// run, i.e. half of source lane s/2's quad.
 __device__ __forceinline__ StripPos strip_locate(const SlxKParams &p, unsigned item)
 {
     StripPos s;
@@ -502,11 +476,10 @@ __device__ __forceinline__ StripPos strip_locate(const SlxKParams &p, unsigned i
     const unsigned sub = idx / p.quads_per_row;
     s.cq = idx - sub * p.quads_per_row;
     s.row = row_base + sub;
-    s.row_step = p.interleave;
 #pragma unroll
     for (int k = 0; k < 2; k++) {
         const unsigned slot = (unsigned)k * 64u + lane;
-        const unsigned vidx = c * 64u + (slot >> 1);              // the lane whose pixels this slot stores
+        const unsigned vidx = c * 64u + (slot >> 1);
         const unsigned vsub = vidx / p.quads_per_row;
         const unsigned vcq = vidx - vsub * p.quads_per_row;
         s.out_row[k] = row_base + vsub;
@@ -515,249 +488,173 @@ __device__ __forceinline__ StripPos strip_locate(const SlxKParams &p, unsigned i
     return s;
 }
 
-template <int MODE, int F, bool LUT, bool PERSIST>
-__global__ __launch_bounds__(PERSIST ? 1024 : 256) void slx_strip_kernel(const SlxKParams p)
+template <int MODE, int F>
+__global__ __launch_bounds__(256) void slx_strip_kernel(const SlxKParams p)
 {
     constexpr bool HAS_GRAY = MODE == SLX_MODE_GRAY_PHASE;
     constexpr int NP = F * 4;                     // phase planes
     constexpr unsigned ROW_DW = NP * 64;          // one row of the fringe stack in LDS, dwords per wave
     typedef double vec2 __attribute__((ext_vector_type(2)));
     typedef __attribute__((address_space(3))) void lds_void;
-    typedef const __attribute__((address_space(1))) void glb_void;
-    // LDS: [angle table (LUT only)] then per wave [fringe-stack ring: 2 rows x NP planes x 256 B] [2 KiB depth staging]
-    extern __shared__ __attribute__((aligned(16))) float lds_raw[];
-    float *lds_tab = lds_raw;
+    // LDS per wave: [fringe-stack ring: 2 rows x NP planes x 256 B] [2 KiB depth staging]
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds_raw[];
     const unsigned t = threadIdx.x;
     const unsigned lane = t & 63u;
-    uint32_t *ring = reinterpret_cast<uint32_t *>(lds_raw + (LUT ? SLX_ATAN_LUT_ENTRIES : 0)) + (t >> 6) * (2u * ROW_DW + 512u);
+    // wave-uniform by construction; readfirstlane tells hipcc so (scalar addressing, M0 straight from
+    // an SGPR, no waterfall loops around the buffer descriptor)
+    const unsigned wave_in_wg = __builtin_amdgcn_readfirstlane(t >> 6);
+    uint32_t *ring = lds_raw + wave_in_wg * (2u * ROW_DW + 512u);
     vec2 *stage = reinterpret_cast<vec2 *>(ring + 2u * ROW_DW);
-    if constexpr (LUT) {
-        typedef float vec4 __attribute__((ext_vector_type(4)));
-        const vec4 *src = reinterpret_cast<const vec4 *>(p.atan_lut);
-        vec4 *dst = reinterpret_cast<vec4 *>(lds_tab);
-        for (unsigned i = t; i < SLX_ATAN_LUT_ENTRIES / 4; i += blockDim.x) dst[i] = src[i];
-        __syncthreads();
-    }
-    const unsigned wave_id = blockIdx.x * (blockDim.x >> 6) + (t >> 6);
-    if (p.stamps && lane == 0 && wave_id < 8192) {   // diagnostics only (slx_debug_stamps)
-        p.stamps[4 * wave_id + 0] = __builtin_amdgcn_s_memtime();
-        p.stamps[4 * wave_id + 2] = __builtin_amdgcn_s_memrealtime();
+    const unsigned item = blockIdx.x * (blockDim.x >> 6) + wave_in_wg;
+    if (item >= p.total_items) return;
+    if (p.stamps && lane == 0 && item < 8192) {   // diagnostics only (slx_debug_stamps)
+        p.stamps[4 * item + 0] = __builtin_amdgcn_s_memtime();
+        p.stamps[4 * item + 2] = __builtin_amdgcn_s_memrealtime();
     }
     const unsigned W = (unsigned)p.width, H = (unsigned)p.height;
     const unsigned row_stride = (unsigned)p.row_stride;
-    const unsigned RB = p.rows_per_lane;
+    const unsigned RB = p.rows_per_lane, step_rows = p.interleave;
     const unsigned last_row = H - 1u;
     float Tf[F];
 #pragma unroll
     for (int f = 0; f < F; f++) Tf[f] = (float)p.period[f];
 
-    const unsigned n_waves = gridDim.x * (blockDim.x >> 6);
-    unsigned long long ticket = wave_id;
-    const unsigned prio_rank = (t >> 6) >> 2;        // waves w, w+4, w+8, w+12 of a workgroup share a SIMD
-    // one row of depth waits in LDS until the next step has issued its loads
-    bool pending = false;
-    unsigned pend_off[2] = {0u, 0u};
-    bool pend_ok[2] = {false, false};
-    double *pend_set = p.z;
-    unsigned slot = 0;                               // ring slot holding the current row
-    // hipcc does not track LDS-DMA: the waits are ours.  vmcnt retires in issue order, so "all but the NP
-    // youngest" = everything up to and including the previous row's DMA (and any store issued before it).
-    auto wait_dma = [&](bool one_row_younger) {
-        if (one_row_younger) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    };
+    const StripPos pos = strip_locate(p, item);
+    const size_t pset = (size_t)pos.set * p.phase_set_stride;
+    const size_t gset = (size_t)pos.set * p.gray_set_stride;
+    double *zset = p.z + (size_t)pos.set * p.out_set_stride;
 
-    // The fringe stack of one row -- NP dwords per lane -- goes HBM -> LDS by DMA (no VGPRs): plane k of
-    // the wave lands at ring[slot][k][lane].
-    auto issue_loads = [&](unsigned dst_slot, unsigned set, unsigned row, unsigned cq) {
-        const unsigned r = row < last_row ? row : last_row;            // rows past the tile: harmless re-read
-        const size_t off = (size_t)set * p.phase_set_stride + (size_t)(r * row_stride + cq * SLX_QUAD);
-        uint32_t *dst = ring + dst_slot * ROW_DW;
+    // buffer_load ... lds: one 32-bit lane offset for every plane, the plane's offset in an SGPR, no VALU
+    const __amdgpu_buffer_rsrc_t rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(p.phase_base + pset), 0, 0xFFFFFFFFu, 0x00020000);
+    auto issue_row = [&](unsigned slot, unsigned i) {                  // DMA of row i of the item into ring[slot]
+        unsigned r = pos.row + i * step_rows;
+        r = r < last_row ? r : last_row;                               // rows past the tile: harmless re-read
+        const unsigned voff = r * row_stride + pos.cq * SLX_QUAD;
+        uint32_t *dst = ring + slot * ROW_DW;
 #pragma unroll
         for (int k = 0; k < NP; k++)
-            __builtin_amdgcn_global_load_lds((glb_void *)(p.phase[k] + off), (lds_void *)(dst + k * 64), 4, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void *)(dst + k * 64), 4, voff, p.phase_rel[k], 0, 0);
     };
-    auto flush = [&]() {                                               // last row's depth, in slot order
-        if (!pending) return;
+    auto flush_row = [&](unsigned i) {                                 // depth of row i of the item, in store order
 #pragma unroll
         for (int k = 0; k < 2; k++) {
             const vec2 v = stage[k * 64 + lane];
-            if (pend_ok[k]) __builtin_nontemporal_store(v, reinterpret_cast<vec2 *>(pend_set + pend_off[k]));
+            if (pos.out_row[k] + i * step_rows < H && p.dbg != 1)
+                __builtin_nontemporal_store(v, reinterpret_cast<vec2 *>(zset + (pos.out_off[k] + i * step_rows * W)));
         }
-        pending = false;
     };
 
-    // rows are issued two ahead: while row i is decoded the DMA of rows i+1 and i+2 is in flight
-    // (2 * NP * 256 B per wave), with only two ring slots: row i+2 reuses row i's slot once it is read
-    StripPos pos;
-    unsigned ahead = 0;                              // 1 when the DMA of the row after the current one is in flight
-    auto row_of = [&](const StripPos &q, unsigned i) { return q.row + i * q.row_step; };
-    if (ticket < p.total_items) {
-        pos = strip_locate(p, (unsigned)ticket);
-        issue_loads(0, pos.set, row_of(pos, 0), pos.cq);
-        if (RB > 1) {
-            issue_loads(1, pos.set, row_of(pos, 1), pos.cq);
-            ahead = 1;
-        }
-    }
-
-    while (ticket < p.total_items) {
-        const unsigned long long ticket_next = PERSIST ? ticket + n_waves : ~0ull;
-        const bool more = ticket_next < p.total_items;
-        StripPos pos_next = pos;
-        if (more) pos_next = strip_locate(p, (unsigned)ticket_next);
-
-        // column constants (a6): a = (u - cx)*fv ; aC = a*P00 ; aD = a*P20
-        double aC[SLX_QUAD], aD[SLX_QUAD];
+    // a6, column part: a = (u - cx)*fv
+    double acol[SLX_QUAD];
 #pragma unroll
-        for (int j = 0; j < SLX_QUAD; j++) {
-            const double uc = (double)(int)(pos.cq * SLX_QUAD + j) - p.cx;
-            const double a = uc * p.fv;
-            aC[j] = a * p.P00;
-            aD[j] = a * p.P20;
-        }
-        const size_t gset = (size_t)pos.set * p.gray_set_stride;
-        double *zset = p.z + (size_t)pos.set * p.out_set_stride;
+    for (int j = 0; j < SLX_QUAD; j++) acol[j] = ((double)(int)(pos.cq * SLX_QUAD + j) - p.cx) * p.fv;
 
-        for (unsigned i = 0; i < RB; i++) {
-            const unsigned row = pos.row + i * pos.row_step;
-            const bool live = row < H;
-            if constexpr (PERSIST) {                                    // rotate the issue priority, see the header
-                switch ((prio_rank + i) & 3u) {
-                case 0: __builtin_amdgcn_s_setprio(0); break;
-                case 1: __builtin_amdgcn_s_setprio(1); break;
-                case 2: __builtin_amdgcn_s_setprio(2); break;
-                default: __builtin_amdgcn_s_setprio(3); break;
+    issue_row(0, 0);
+    if (RB > 1) issue_row(1, 1);
+
+    for (unsigned i = 0; i < RB; i++) {
+        const unsigned row = pos.row + i * step_rows;
+        const unsigned slot = i & 1u;
+        // vmcnt retires in issue order: "all but the NP youngest" = everything up to this row's DMA
+        if (i + 1 < RB) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (i > 0) flush_row(i - 1);                                    // last row's stores, one step late
+
+        double z[SLX_QUAD] = {0.0, 0.0, 0.0, 0.0};
+        if (row < H) {
+            const uint32_t *src = ring + slot * ROW_DW + lane;
+            float pix[F][SLX_QUAD];
+#pragma unroll
+            for (int f = 0; f < F; f++) {
+                const uint32_t w0 = src[(f * 4 + 0) * 64], w1 = src[(f * 4 + 1) * 64];
+                const uint32_t w2 = src[(f * 4 + 2) * 64], w3 = src[(f * 4 + 3) * 64];
+                pix[f][0] = wrapped_pix_from_diffs((float)byte_diff<0>(w0, w2), (float)byte_diff<0>(w1, w3), Tf[f]);
+                pix[f][1] = wrapped_pix_from_diffs((float)byte_diff<1>(w0, w2), (float)byte_diff<1>(w1, w3), Tf[f]);
+                pix[f][2] = wrapped_pix_from_diffs((float)byte_diff<2>(w0, w2), (float)byte_diff<2>(w1, w3), Tf[f]);
+                pix[f][3] = wrapped_pix_from_diffs((float)byte_diff<3>(w0, w2), (float)byte_diff<3>(w1, w3), Tf[f]);
+            }
+            // the slot is free once it has been read: row i+2 goes into it
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (i + 2 < RB) issue_row(slot, i + 2);
+
+            double U[SLX_QUAD];
+            if constexpr (HAS_GRAY) {
+                const unsigned voff = row * row_stride + pos.cq * SLX_QUAD;
+                unsigned code[SLX_QUAD] = {0u, 0u, 0u, 0u};
+                for (int b = p.gray_bits - 1; b >= 0; b--) {           // MSB first: code = 2*code + bit
+                    const uint32_t wa = *reinterpret_cast<const uint32_t *>(p.gray[2 * b] + gset + voff);
+                    const uint32_t wb = *reinterpret_cast<const uint32_t *>(p.gray[2 * b + 1] + gset + voff);
+#pragma unroll
+                    for (int j = 0; j < SLX_QUAD; j++)
+                        code[j] = code[j] + code[j] + (ibyte(wa, j) > ibyte(wb, j) ? 1u : 0u);
                 }
-            }
-            // this row's dwords out of the ring (the wait for its DMA lands here), then last row's
-            // stores, then the DMA of the next row: nothing younger than the awaited loads is in flight
-            uint32_t cur[NP];
-            wait_dma(ahead != 0);
-            {
-                const uint32_t *src = ring + slot * ROW_DW + lane;
+                const double Td = (double)p.period[0], Sd = (double)p.gray_stripe;
 #pragma unroll
-                for (int k = 0; k < NP; k++) cur[k] = src[k * 64];
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the slot is free once it has been read
-            flush();
-            // row i+2 (or the matching row of the next item) into the slot just read
-            if (i + 2 < RB) {
-                issue_loads(slot, pos.set, row_of(pos, i + 2), pos.cq);
-                ahead = 1;
-            } else if (more) {                                          // RB >= 2: i + 2 - RB is row 0 or 1 of the next item
-                issue_loads(slot, pos_next.set, row_of(pos_next, i + 2 - RB), pos_next.cq);
-                ahead = 1;
+                for (int j = 0; j < SLX_QUAD; j++) {
+                    int bin;
+                    if (p.std_gray) {                                   // inverse reflected Gray code: prefix xor
+                        unsigned g = code[j];
+                        g ^= g >> 1;
+                        g ^= g >> 2;
+                        g ^= g >> 4;
+                        g ^= g >> 8;
+                        bin = (int)g;
+                    } else {
+                        bin = (int)p.lut[code[j]];
+                    }
+                    const double grayv = (double)bin * Sd;
+                    const double phaseVal = (double)pix[0][j];
+                    double ph = phaseVal;
+                    if ((bin & 1) == 0) {
+                        if (phaseVal > Td * 0.75) ph = phaseVal - Td;
+                    } else {
+                        if (phaseVal < Td * 0.25) ph = phaseVal + Td;
+                        ph = ph - 0.5 * Td;
+                    }
+                    U[j] = grayv + ph;
+                }
             } else {
-                ahead = 0;                                              // nothing younger than the next row's DMA
+#pragma unroll
+                for (int j = 0; j < SLX_QUAD; j++) {
+                    double Uf = (double)pix[0][j];
+#pragma unroll
+                    for (int f = 1; f < F; f++) {
+                        int k;
+                        Uf = unwrap_stage<true>(Uf, (double)pix[f][j], p.period[f], p.inv_period[f], p.half_biased[f], k);
+                    }
+                    U[j] = Uf;
+                }
             }
-            slot ^= 1u;
 
-            double z[SLX_QUAD] = {0.0, 0.0, 0.0, 0.0};
-            if (live && p.dbg == 2) {                                   // experiment: memory traffic only
-                uint32_t acc = 0;
+            if (p.dbg == 2) {                                           // experiment: memory traffic only
 #pragma unroll
-                for (int k = 0; k < NP; k++) acc += cur[k];
-#pragma unroll
-                for (int j = 0; j < SLX_QUAD; j++) z[j] = (double)(acc >> j);
-            } else if (live) {
-                float pix[F][SLX_QUAD];
-#pragma unroll
-                for (int f = 0; f < F; f++) {
-                    const uint32_t w0 = cur[f * 4 + 0], w1 = cur[f * 4 + 1], w2 = cur[f * 4 + 2], w3 = cur[f * 4 + 3];
-                    pix[f][0] = wrapped_pix_from_diffs<LUT>((float)byte_diff<0>(w0, w2), (float)byte_diff<0>(w1, w3), Tf[f], lds_tab);
-                    pix[f][1] = wrapped_pix_from_diffs<LUT>((float)byte_diff<1>(w0, w2), (float)byte_diff<1>(w1, w3), Tf[f], lds_tab);
-                    pix[f][2] = wrapped_pix_from_diffs<LUT>((float)byte_diff<2>(w0, w2), (float)byte_diff<2>(w1, w3), Tf[f], lds_tab);
-                    pix[f][3] = wrapped_pix_from_diffs<LUT>((float)byte_diff<3>(w0, w2), (float)byte_diff<3>(w1, w3), Tf[f], lds_tab);
-                }
-
-                double U[SLX_QUAD];
-                if constexpr (HAS_GRAY) {
-                    const unsigned voff = row * row_stride + pos.cq * SLX_QUAD;
-                    unsigned code[SLX_QUAD] = {0u, 0u, 0u, 0u};
-                    for (int b = p.gray_bits - 1; b >= 0; b--) {       // MSB first: code = 2*code + bit
-                        const uint32_t wa = *reinterpret_cast<const uint32_t *>(p.gray[2 * b] + gset + voff);
-                        const uint32_t wb = *reinterpret_cast<const uint32_t *>(p.gray[2 * b + 1] + gset + voff);
-#pragma unroll
-                        for (int j = 0; j < SLX_QUAD; j++)
-                            code[j] = code[j] + code[j] + (ibyte(wa, j) > ibyte(wb, j) ? 1u : 0u);
-                    }
-                    const double Td = (double)p.period[0], Sd = (double)p.gray_stripe;
-#pragma unroll
-                    for (int j = 0; j < SLX_QUAD; j++) {
-                        int bin;
-                        if (p.std_gray) {                               // inverse reflected Gray code: prefix xor
-                            unsigned g = code[j];
-                            g ^= g >> 1;
-                            g ^= g >> 2;
-                            g ^= g >> 4;
-                            g ^= g >> 8;
-                            bin = (int)g;
-                        } else {
-                            bin = (int)p.lut[code[j]];
-                        }
-                        const double grayv = (double)bin * Sd;
-                        const double phaseVal = (double)pix[0][j];
-                        double ph = phaseVal;
-                        if ((bin & 1) == 0) {
-                            if (phaseVal > Td * 0.75) ph = phaseVal - Td;
-                        } else {
-                            if (phaseVal < Td * 0.25) ph = phaseVal + Td;
-                            ph = ph - 0.5 * Td;
-                        }
-                        U[j] = grayv + ph;
-                    }
-                } else {
-#pragma unroll
-                    for (int j = 0; j < SLX_QUAD; j++) {
-                        double Uf = (double)pix[0][j];
-#pragma unroll
-                        for (int f = 1; f < F; f++) {
-                            int k;
-                            Uf = unwrap_stage<true>(Uf, (double)pix[f][j], p.period[f], p.inv_period[f], p.half_biased[f], k);
-                        }
-                        U[j] = Uf;
-                    }
-                }
-
+                for (int j = 0; j < SLX_QUAD; j++) z[j] = (double)pix[0][j];
+            } else {
                 const double vc = (double)((int)row + p.row_offset) - p.cy;
                 const double vf = vc * p.fu;
                 const double tvC = vf * p.P01, tvD = vf * p.P21;
 #pragma unroll
                 for (int j = 0; j < SLX_QUAD; j++) {
-                    const double cC = (aC[j] + tvC) + p.K1;
-                    const double cD = (aD[j] + tvD) + p.K2;
+                    const double cC = (acol[j] * p.P00 + tvC) + p.K1;
+                    const double cD = (acol[j] * p.P20 + tvD) + p.K2;
                     z[j] = tri_depth<true>(U[j], cC, cD, p.cA, p.cB, p.fov_min, p.fov_max, true);
                 }
             }
-            // stage this row's depth; it is stored (slot order) at the top of the next step
-            stage[2 * lane + 0] = vec2{z[0], z[1]};
-            stage[2 * lane + 1] = vec2{z[2], z[3]};
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int k = 0; k < 2; k++) {
-                pend_ok[k] = (pos.out_row[k] + i * pos.row_step) < H && p.dbg != 1;
-                pend_off[k] = pos.out_off[k] + i * pos.row_step * W;
-            }
-            pend_set = zset;
-            pending = true;
+        } else if (i + 2 < RB) {
+            issue_row(slot, i + 2);                                     // keeps the DMA count per step fixed
         }
-        ticket = ticket_next;
-        pos = pos_next;
+        // stage this row's depth; it is stored (slot order) at the top of the next step
+        stage[2 * lane + 0] = vec2{z[0], z[1]};
+        stage[2 * lane + 1] = vec2{z[2], z[3]};
+        __builtin_amdgcn_wave_barrier();
     }
-    flush();
-    if (p.stamps && lane == 0 && wave_id < 8192) {
-        p.stamps[4 * wave_id + 1] = __builtin_amdgcn_s_memtime();
-        p.stamps[4 * wave_id + 3] = __builtin_amdgcn_s_memrealtime();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    flush_row(RB - 1);
+    if (p.stamps && lane == 0 && item < 8192) {
+        p.stamps[4 * item + 1] = __builtin_amdgcn_s_memtime();
+        p.stamps[4 * item + 3] = __builtin_amdgcn_s_memrealtime();
     }
-}
-
-// One workgroup per |max| value, one thread per |min| <= |max|.
-__global__ __launch_bounds__(256) void slx_atan_lut_init_kernel(float *table)
-{
-    const unsigned mx = blockIdx.x, mn = threadIdx.x;
-    if (mn > mx) return;
-    table[mx * (mx + 1) / 2 + mn] = octant_angle((float)mn, __builtin_fmaxf((float)mx, 1.0f));
 }
 
 typedef void (*kernel_fn)(const SlxKParams);
@@ -794,26 +691,20 @@ kernel_fn pick(int mode, int F, bool n4, bool aux)
 }
 
 template <int MODE>
-kernel_fn pick_strip(int F, bool lut)
+kernel_fn pick_strip(int F)
 {
     switch (F) {
-    case 1: return lut ? slx_strip_kernel<MODE, 1, true, true> : slx_strip_kernel<MODE, 1, false, false>;
-    case 2: return lut ? slx_strip_kernel<MODE, 2, true, true> : slx_strip_kernel<MODE, 2, false, false>;
-    case 3: return lut ? slx_strip_kernel<MODE, 3, true, true> : slx_strip_kernel<MODE, 3, false, false>;
-    case 4: return lut ? slx_strip_kernel<MODE, 4, true, true> : slx_strip_kernel<MODE, 4, false, false>;
+    case 1: return slx_strip_kernel<MODE, 1>;
+    case 2: return slx_strip_kernel<MODE, 2>;
+    case 3: return slx_strip_kernel<MODE, 3>;
+    case 4: return slx_strip_kernel<MODE, 4>;
     }
     return nullptr;
 }
 
 }  // namespace
 
-int slx_num_variants(void) { return 4; }
-
-int slx_launch_atan_lut_init(float *table, void *stream)
-{
-    hipLaunchKernelGGL(slx_atan_lut_init_kernel, dim3(256), dim3(256), 0, (hipStream_t)stream, table);
-    return (int)hipGetLastError();
-}
+int slx_num_variants(void) { return 3; }
 
 bool slx_strip_eligible(const SlxKParams &kp, int mode, bool aux)
 {
@@ -822,7 +713,18 @@ bool slx_strip_eligible(const SlxKParams &kp, int mode, bool aux)
     if (kp.quads_per_row == 0 || kp.quads_per_row > 1024) return false;
     for (int f = 0; f < kp.n_freq; f++)
         if (kp.period[f] > (1 << 14)) return false;
-    if ((unsigned long long)kp.row_stride * (unsigned)kp.height >= (1ull << 32)) return false;   // 32-bit plane offsets
+    if ((unsigned long long)kp.row_stride * (unsigned)kp.height >= (1ull << 31)) return false;   // 32-bit plane offsets
+    {
+        // every phase plane must sit within 2 GiB of the lowest one (32-bit buffer offsets)
+        const int np = kp.n_freq * 4;
+        uintptr_t lo = ~(uintptr_t)0, hi = 0;
+        for (int k = 0; k < np; k++) {
+            const uintptr_t a = reinterpret_cast<uintptr_t>(kp.phase[k]);
+            lo = a < lo ? a : lo;
+            hi = a > hi ? a : hi;
+        }
+        if (hi - lo >= (1ull << 31)) return false;
+    }
     if ((unsigned long long)kp.width * (unsigned)kp.height >= (1ull << 29)) return false;          // 32-bit output offsets
     // the depth quotient's operands must stay far inside the double range (tri_depth<LEAN>)
     const double big = 0x1p90;
@@ -854,54 +756,44 @@ int slx_launch_fused(const SlxKParams &kp_in, int mode, bool aux, int n_sets, in
 {
     const bool can_strip = slx_strip_eligible(kp_in, mode, aux);
     if (variant == SLX_VARIANT_GENERIC || !can_strip) {
-        if (variant == SLX_VARIANT_STRIP || variant == SLX_VARIANT_STRIP_LUT) return (int)hipErrorInvalidValue;
+        if (variant == SLX_VARIANT_STRIP) return (int)hipErrorInvalidValue;
         return launch_generic(kp_in, mode, aux, n_sets, stream);
     }
-    const bool lut = variant == SLX_VARIANT_STRIP_LUT || (variant == SLX_VARIANT_AUTO && kp_in.atan_lut != nullptr && (long long)n_sets * kp_in.height >= 2048);
-    if (lut && !kp_in.atan_lut) return (int)hipErrorInvalidValue;
     SlxKParams kp = kp_in;
+    {
+        const int np = kp.n_freq * 4;
+        const uint8_t *lo = kp.phase[0];
+        for (int k = 1; k < np; k++) lo = kp.phase[k] < lo ? kp.phase[k] : lo;
+        kp.phase_base = lo;
+        for (int k = 0; k < np; k++) kp.phase_rel[k] = (unsigned)(kp.phase[k] - lo);
+    }
     // geometry: `interleave` rows end to end fill whole waves; an item is 64 quads x rows_per_lane rows
     const unsigned QR = kp.quads_per_row;
     unsigned g = QR, h = 64;
     while (h) { const unsigned r = g % h; g = h; h = r; }          // gcd(QR, 64)
     kp.interleave = 64u / g;
     kp.chunks_per_group = kp.interleave * QR / 64u;
-    unsigned rb = 16;                                                // even; ~1 % item-switch overhead
+    unsigned rb = 16;                                                // ~2 % item start-up cost (locate, column constants, ring fill)
+    while (rb > 1 && (unsigned long long)kp.interleave * rb * 2ull > (unsigned)kp.height) rb /= 2;   // small tiles: smaller items
     if (const char *e = getenv("SLX_DBG")) kp.dbg = atoi(e);
     if (const char *e = getenv("SLX_STRIP_ROWS")) {                  // tuning hook
         const int v = atoi(e);
-        if (v >= 2 && v <= 64 && v % 2 == 0) rb = (unsigned)v;
+        if (v >= 1 && v <= 256) rb = (unsigned)v;
     }
-    while (rb > 2 && (unsigned long long)kp.interleave * (rb / 2) * 4ull >= (unsigned)kp.height) rb -= 2;   // small tiles: smaller items
     kp.rows_per_lane = rb;
     const unsigned rows_group = kp.interleave * rb;
     const unsigned groups = ((unsigned)kp.height + rows_group - 1) / rows_group;
     kp.items_per_set = groups * kp.chunks_per_group;
     kp.total_items = (unsigned long long)kp.items_per_set * (unsigned)n_sets;
-    if (kp.total_items >= (1ull << 32)) return (int)hipErrorInvalidValue;
     // LDS per wave: 2 rows of the fringe stack (n_freq * 4 planes * 256 B each) + 2 KiB of depth staging
     const unsigned lds_wave = 2u * (unsigned)kp.n_freq * 4u * 256u + 2048u;
-    const unsigned lut_bytes = (unsigned)sizeof(float) * SLX_ATAN_LUT_ENTRIES;
-    unsigned threads = 256u;
-    if (lut) {                                        // as many waves as fit next to the 128.5 KiB table (<= 16)
-        unsigned w = (160u * 1024u - lut_bytes) / lds_wave;
-        if (w > 16u) w = 16u;
-        if (w == 0u) return (int)hipErrorInvalidValue;
-        threads = w * 64u;
-    }
-    const unsigned waves_per_wg = threads / 64u;
+    const unsigned threads = 256u, waves_per_wg = threads / 64u;
     const unsigned long long need_wgs = (kp.total_items + waves_per_wg - 1) / waves_per_wg;
-    // persistent (LUT) schedule: one 16-wave workgroup per CU; otherwise one item per wave
-    const unsigned n_cu = 256;
-    const unsigned grid = (unsigned)(lut && need_wgs > n_cu ? n_cu : need_wgs);
-    kernel_fn fn = mode == SLX_MODE_MULTIFREQ ? pick_strip<SLX_MODE_MULTIFREQ>(kp.n_freq, lut)
-                                              : pick_strip<SLX_MODE_GRAY_PHASE>(1, lut);
-    if (!fn || grid == 0) return (int)hipErrorInvalidValue;
-    const size_t lds = (lut ? lut_bytes : 0u) + (size_t)waves_per_wg * lds_wave;
-    if (lds > 48u * 1024u) {
-        hipError_t e = hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-    }
-    hipLaunchKernelGGL(fn, dim3(grid, 1, 1), dim3(threads, 1, 1), lds, (hipStream_t)stream, kp);
+    if (need_wgs == 0 || need_wgs >= (1ull << 31)) return (int)hipErrorInvalidValue;
+    kernel_fn fn = mode == SLX_MODE_MULTIFREQ ? pick_strip<SLX_MODE_MULTIFREQ>(kp.n_freq) : pick_strip<SLX_MODE_GRAY_PHASE>(1);
+    if (!fn) return (int)hipErrorInvalidValue;
+    const size_t lds = (size_t)waves_per_wg * lds_wave;
+    // operand shapes were validated by the caller (slx_api.cpp: check_launch_shapes) and slx_strip_eligible
+    hipLaunchKernelGGL(fn, dim3((unsigned)need_wgs, 1, 1), dim3(threads, 1, 1), lds, (hipStream_t)stream, kp);
     return (int)hipGetLastError();
 }

@@ -212,16 +212,16 @@ def test_unwrap_rounding_ties(api, oracle, synth, name):
     assert np.any(r == np.floor(r))
     got = api.decode_frameset(spec, ph, None, want=("z", "k", "U"), variant=api.VARIANT_GENERIC)
     assert_same(got, ref, ("z", "k", "U"))
-    for variant in (api.VARIANT_AUTO, api.VARIANT_STRIP, api.VARIANT_STRIP_LUT):
+    for variant in (api.VARIANT_AUTO, api.VARIANT_STRIP):
         got = api.decode_frameset(spec, ph, None, want=("z",), variant=variant)
         assert_same(got, ref, ("z",))
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3])
+@pytest.mark.parametrize("variant", [0, 1, 2])
 def test_variants_exhaustive_wrapped_phase_through_depth(api, oracle, synth, variant):
     """The fast kernels only emit depth; with an unbounded FOV depth is a strictly monotonic function
     of pix, so depth parity over all 511 x 511 inputs checks their wrapped phase exhaustively
-    (the LDS angle table included)."""
+    (in-register SDWA byte differences, fast unwrap and in-range division included)."""
     planes = exhaustive_planes(512)
     for T in (40, 30, 240, 1920, 4096, 16384):
         spec = dict(synth.make_spec("C1"), width=512, height=511, periods=[T])
@@ -237,7 +237,7 @@ def test_variants_exhaustive_wrapped_phase_through_depth(api, oracle, synth, var
 
 
 @pytest.mark.parametrize("name,scene", [("C1", "sphere"), ("C1x4", "tilted"), ("REF", "tilted"), ("C2", "tilted"), ("C4", "sphere")])
-@pytest.mark.parametrize("variant", [1, 2, 3])
+@pytest.mark.parametrize("variant", [1, 2])
 def test_variants_full_size(api, oracle, synth, name, scene, variant):
     spec = synth.make_spec(name)
     ph, gr, _ = synth.render(spec, scene, seed=11, noise_sigma=3.0)
@@ -246,8 +246,8 @@ def test_variants_full_size(api, oracle, synth, name, scene, variant):
     assert_same(got, ref, ("z",))
 
 
-@pytest.mark.parametrize("variant", [2, 3])
-@pytest.mark.parametrize("shape", [(7, 64), (33, 1024), (130, 4096), (1, 4), (1200, 8)])
+@pytest.mark.parametrize("variant", [0, 2])
+@pytest.mark.parametrize("shape", [(7, 64), (33, 1024), (130, 4096), (1, 4), (1200, 8), (37, 1920), (5, 500), (64, 20)])
 def test_strip_kernel_geometries(api, oracle, synth, variant, shape):
     """Row bands, partial last bands, one-quad-wide and 1024-quad-wide strips, Gray + phase and 4-frequency."""
     h, w = shape
@@ -274,7 +274,7 @@ def test_strip_variant_refuses_ineligible_operands(api, synth):
     big = dict(small_spec(synth, "C2", 64, 8), periods=[40000, 160, 20])   # period > 2^14: exact-division kernel
     ph, _ = synth.random_planes(big, seed=2)
     with api.Context(big) as ctx:
-        ctx.set_variant(api.VARIANT_STRIP_LUT)
+        ctx.set_variant(api.VARIANT_STRIP)
         ctx.set_frames(ph, None)
         with pytest.raises(api.SlxError):
             ctx.decode()
@@ -289,13 +289,13 @@ def test_degenerate_depth_quotients(api, oracle, synth):
     spec["calib"] = cal
     ph, _ = synth.random_planes(spec, seed=5)
     ref = oracle.pipeline(spec, ph, None, want=("z",))
-    for variant in (0, 1, 2, 3):
+    for variant in (0, 1, 2):
         got = api.decode_frameset(spec, ph, None, want=("z",), variant=variant)
         assert np.array_equal(got["z"], ref["z"], equal_nan=True), variant
     cal2 = dict(cal, rot=[1.0, 0, 0, 0, 1.0, 0, 0, 0, 1.0], trans=[0.0, 0.0, 0.0])  # num == 0 everywhere, den varies
     spec["calib"] = cal2
     ref = oracle.pipeline(spec, ph, None, want=("z",))
-    for variant in (0, 1, 2, 3):
+    for variant in (0, 1, 2):
         got = api.decode_frameset(spec, ph, None, want=("z",), variant=variant)
         assert np.array_equal(got["z"], ref["z"], equal_nan=True), variant
 

@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Interleaved A/B timing of kernel variants / tuning knobs on the bench workload (GPU box).
+Usage: tools/ab.py "1" "2" "2:SLX_STRIP_ROWS=8" ...   (variant[:ENV=VAL[,ENV=VAL]])
+All arms run in one process on one device, round-robin, and the median over rounds is reported."""
+import importlib, os, sys, statistics
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+synth = importlib.import_module("structured-light-calculation_amd.synth")
+api = importlib.import_module("structured-light-calculation_amd.api")
+arms = []
+for a in sys.argv[1:]:
+    v, _, envs = a.partition(":")
+    env = dict(e.split("=") for e in envs.split(",") if e)
+    arms.append((a, int(v), env))
+cfg = os.environ.get("AB_CONFIG", "C4")
+n_sets = int(os.environ.get("AB_SETS", "32"))
+spec = synth.make_spec(cfg)
+H, W = spec["height"], spec["width"]
+n_phase, n_gray = synth.n_planes(spec)
+phase = torch.randint(0, 256, (n_sets, n_phase, H, W), dtype=torch.uint8, device="cuda") if n_phase else None
+gray = torch.randint(0, 256, (n_sets, n_gray, H, W), dtype=torch.uint8, device="cuda") if n_gray else None
+z = torch.empty((n_sets, H, W), dtype=torch.float64, device="cuda")
+s = torch.cuda.Stream(); torch.cuda.set_stream(s)
+ctxs = {}
+for name, v, env in arms:
+    c = api.Context(spec); c.set_variant(v); ctxs[name] = c
+def run(name, v, env, n):
+    for k in list(os.environ):
+        if k.startswith("SLX_"): del os.environ[k]
+    os.environ.update(env)
+    c = ctxs[name]
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(s)
+    for _ in range(n): c.decode_batch(n_sets, phase, gray, z, stream=s.cuda_stream)
+    e1.record(s); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1000.0 / n
+for name, v, env in arms: run(name, v, env, 20)
+res = {name: [] for name, _, _ in arms}
+for r in range(7):
+    for name, v, env in arms: res[name].append(run(name, v, env, 30))
+bytes_ = n_sets * H * W * synth.algorithmic_bytes_per_pixel(spec)
+for name, _, _ in arms:
+    m = statistics.median(res[name])
+    print("%-40s median %7.1f us  min %7.1f  -> %5.2f TB/s (%.1f %% of 8 TB/s)" % (name, m, min(res[name]), bytes_ / m / 1e6, bytes_ / m / 1e6 / 8 * 100))
