@@ -773,8 +773,17 @@ int slx_launch_fused(const SlxKParams &kp_in, int mode, bool aux, int n_sets, in
     while (h) { const unsigned r = g % h; g = h; h = r; }          // gcd(QR, 64)
     kp.interleave = 64u / g;
     kp.chunks_per_group = kp.interleave * QR / 64u;
-    unsigned rb = 16;                                                // ~2 % item start-up cost (locate, column constants, ring fill)
-    while (rb > 1 && (unsigned long long)kp.interleave * rb * 2ull > (unsigned)kp.height) rb /= 2;   // small tiles: smaller items
+    // rows per item: 16 amortises the item start-up (locate, column constants, ring fill: ~2 % of 16 rows);
+    // smaller launches take smaller items so that the chip still sees ~3 waves per wave slot
+    unsigned rb = 16;
+    {
+        const unsigned long long want_waves = 256ull * 20ull * 3ull;
+        auto waves_at = [&](unsigned r) {
+            const unsigned long long rows_group = (unsigned long long)kp.interleave * r;
+            return (((unsigned)kp.height + rows_group - 1) / rows_group) * kp.chunks_per_group * (unsigned long long)n_sets;
+        };
+        while (rb > 1 && waves_at(rb) < want_waves) rb /= 2;
+    }
     if (const char *e = getenv("SLX_DBG")) kp.dbg = atoi(e);
     if (const char *e = getenv("SLX_STRIP_ROWS")) {                  // tuning hook
         const int v = atoi(e);
@@ -787,7 +796,12 @@ int slx_launch_fused(const SlxKParams &kp_in, int mode, bool aux, int n_sets, in
     kp.total_items = (unsigned long long)kp.items_per_set * (unsigned)n_sets;
     // LDS per wave: 2 rows of the fringe stack (n_freq * 4 planes * 256 B each) + 2 KiB of depth staging
     const unsigned lds_wave = 2u * (unsigned)kp.n_freq * 4u * 256u + 2048u;
-    const unsigned threads = 256u, waves_per_wg = threads / 64u;
+    unsigned waves_per_wg = 4u;
+    if (const char *e = getenv("SLX_STRIP_WAVES")) {               // tuning hook
+        const int v = atoi(e);
+        if (v >= 1 && v <= 4) waves_per_wg = (unsigned)v;
+    }
+    const unsigned threads = waves_per_wg * 64u;
     const unsigned long long need_wgs = (kp.total_items + waves_per_wg - 1) / waves_per_wg;
     if (need_wgs == 0 || need_wgs >= (1ull << 31)) return (int)hipErrorInvalidValue;
     kernel_fn fn = mode == SLX_MODE_MULTIFREQ ? pick_strip<SLX_MODE_MULTIFREQ>(kp.n_freq) : pick_strip<SLX_MODE_GRAY_PHASE>(1);
