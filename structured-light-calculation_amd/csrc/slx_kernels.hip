@@ -518,6 +518,14 @@ __global__ __launch_bounds__(256) void slx_strip_kernel(const SlxKParams p)
     float Tf[F];
 #pragma unroll
     for (int f = 0; f < F; f++) Tf[f] = (float)p.period[f];
+    // A VOP3 instruction takes one scalar operand: fma(d, 1/T, 0.5+eps) with both constants in SGPRs costs
+    // a v_mov_b64 per use.  Keeping the addend in a VGPR pair for the whole item removes it.
+    double hb[F];
+#pragma unroll
+    for (int f = 0; f < F; f++) {
+        hb[f] = p.half_biased[f];
+        asm volatile("" : "+v"(hb[f]));
+    }
 
     const StripPos pos = strip_locate(p, item);
     const size_t pset = (size_t)pos.set * p.phase_set_stride;
@@ -527,28 +535,41 @@ __global__ __launch_bounds__(256) void slx_strip_kernel(const SlxKParams p)
     // buffer_load ... lds: one 32-bit lane offset for every plane, the plane's offset in an SGPR, no VALU
     const __amdgpu_buffer_rsrc_t rsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(p.phase_base + pset), 0, 0xFFFFFFFFu, 0x00020000);
-    auto issue_row = [&](unsigned slot, unsigned i) {                  // DMA of row i of the item into ring[slot]
-        unsigned r = pos.row + i * step_rows;
-        r = r < last_row ? r : last_row;                               // rows past the tile: harmless re-read
-        const unsigned voff = r * row_stride + pos.cq * SLX_QUAD;
+    // lane offsets advance by a constant per row: one add (and a clamp for the DMA) instead of a multiply-add
+    const unsigned dma_step = step_rows * row_stride;
+    const unsigned dma_last = last_row * row_stride + pos.cq * SLX_QUAD;   // rows past the tile: harmless re-read of the last row
+    unsigned dma_off = pos.row * row_stride + pos.cq * SLX_QUAD;           // offset of the next row to issue
+    auto issue_row = [&](unsigned slot, unsigned) {                    // DMA of the next row of the item into ring[slot]
+        const unsigned voff = dma_off < dma_last ? dma_off : dma_last;
+        dma_off += dma_step;
         uint32_t *dst = ring + slot * ROW_DW;
 #pragma unroll
         for (int k = 0; k < NP; k++)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void *)(dst + k * 64), 4, voff, p.phase_rel[k], 0, 0);
     };
-    auto flush_row = [&](unsigned i) {                                 // depth of row i of the item, in store order
+    const unsigned out_step = step_rows * W;
+    unsigned out_off[2] = {pos.out_off[0], pos.out_off[1]};            // next row to store, per store slot
+    auto rows_left = [&](unsigned first) { return first < H ? (H - first + step_rows - 1) / step_rows : 0u; };
+    const unsigned out_end[2] = {pos.out_off[0] + rows_left(pos.out_row[0]) * out_step,
+                                 pos.out_off[1] + rows_left(pos.out_row[1]) * out_step};
+    auto flush_row = [&](unsigned) {                                   // depth of the oldest unstored row, in store order
 #pragma unroll
         for (int k = 0; k < 2; k++) {
             const vec2 v = stage[k * 64 + lane];
-            if (pos.out_row[k] + i * step_rows < H && p.dbg != 1)
-                __builtin_nontemporal_store(v, reinterpret_cast<vec2 *>(zset + (pos.out_off[k] + i * step_rows * W)));
+            if (out_off[k] < out_end[k] && p.dbg != 1)                  // rows past the tile are not stored
+                __builtin_nontemporal_store(v, reinterpret_cast<vec2 *>(zset + out_off[k]));
+            out_off[k] += out_step;
         }
     };
 
-    // a6, column part: a = (u - cx)*fv
-    double acol[SLX_QUAD];
+    // a6, column part: a = (u - cx)*fv ; aC = a*P00 ; aD = a*P20
+    double aC[SLX_QUAD], aD[SLX_QUAD];
 #pragma unroll
-    for (int j = 0; j < SLX_QUAD; j++) acol[j] = ((double)(int)(pos.cq * SLX_QUAD + j) - p.cx) * p.fv;
+    for (int j = 0; j < SLX_QUAD; j++) {
+        const double a = ((double)(int)(pos.cq * SLX_QUAD + j) - p.cx) * p.fv;
+        aC[j] = a * p.P00;
+        aD[j] = a * p.P20;
+    }
 
     issue_row(0, 0);
     if (RB > 1) issue_row(1, 1);
@@ -621,7 +642,7 @@ __global__ __launch_bounds__(256) void slx_strip_kernel(const SlxKParams p)
 #pragma unroll
                     for (int f = 1; f < F; f++) {
                         int k;
-                        Uf = unwrap_stage<true>(Uf, (double)pix[f][j], p.period[f], p.inv_period[f], p.half_biased[f], k);
+                        Uf = unwrap_stage<true>(Uf, (double)pix[f][j], p.period[f], p.inv_period[f], hb[f], k);
                     }
                     U[j] = Uf;
                 }
@@ -636,8 +657,8 @@ __global__ __launch_bounds__(256) void slx_strip_kernel(const SlxKParams p)
                 const double tvC = vf * p.P01, tvD = vf * p.P21;
 #pragma unroll
                 for (int j = 0; j < SLX_QUAD; j++) {
-                    const double cC = (acol[j] * p.P00 + tvC) + p.K1;
-                    const double cD = (acol[j] * p.P20 + tvD) + p.K2;
+                    const double cC = (aC[j] + tvC) + p.K1;
+                    const double cD = (aD[j] + tvD) + p.K2;
                     z[j] = tri_depth<true>(U[j], cC, cD, p.cA, p.cB, p.fov_min, p.fov_max, true);
                 }
             }
@@ -806,7 +827,8 @@ int slx_launch_fused(const SlxKParams &kp_in, int mode, bool aux, int n_sets, in
     if (need_wgs == 0 || need_wgs >= (1ull << 31)) return (int)hipErrorInvalidValue;
     kernel_fn fn = mode == SLX_MODE_MULTIFREQ ? pick_strip<SLX_MODE_MULTIFREQ>(kp.n_freq) : pick_strip<SLX_MODE_GRAY_PHASE>(1);
     if (!fn) return (int)hipErrorInvalidValue;
-    const size_t lds = (size_t)waves_per_wg * lds_wave;
+    size_t lds = (size_t)waves_per_wg * lds_wave;
+    if (const char *e = getenv("SLX_LDS_PAD")) lds += (size_t)atoi(e) * 1024u;   // experiments: lower the occupancy
     // operand shapes were validated by the caller (slx_api.cpp: check_launch_shapes) and slx_strip_eligible
     hipLaunchKernelGGL(fn, dim3((unsigned)need_wgs, 1, 1), dim3(threads, 1, 1), lds, (hipStream_t)stream, kp);
     return (int)hipGetLastError();
