@@ -87,12 +87,15 @@ def cpu_baseline(spec, phase_np, budget_s=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=10)
+    # the chip needs ~100 launches (~35 ms) of this kernel after an idle spell before its clock settles
+    # (tools/ramp.py: 504, 359, 331, 325, 317, 316 ... us per launch in blocks of 25), hence the warm-up default
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--sets-per-gpu", type=int, default=32)
     ap.add_argument("--config", default="C4")
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="nccl (= RCCL) on GPUs; gloo only to rehearse the multi-rank path on one GPU")
     args = ap.parse_args()
 
     import numpy as np
@@ -108,11 +111,15 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the decode has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    dev_index = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     synth = importlib.import_module(PKG + ".synth")
     api = importlib.import_module(PKG + ".api")
@@ -135,7 +142,7 @@ def main():
         log("[bench] rendered %d frame-sets (%.2f GB in, %.2f GB out per step) in %.1f s" %
             (n_sets, phase.numel() / 1e9, z.numel() * 8 / 1e9, time.perf_counter() - t0))
 
-    ctx = api.Context(spec, device=local_rank)
+    ctx = api.Context(spec, device=dev_index)
     ctx.set_variant(args.variant)
     stream = torch.cuda.Stream(device=device)      # an explicit stream: the library treats NULL as "my own stream"
     torch.cuda.set_stream(stream)
@@ -164,7 +171,8 @@ def main():
     t_local = time.perf_counter() - t0
     fence()
     kernel_ms = ev0.elapsed_time(ev1) / args.steps          # average launch duration over the timed region
-    t = torch.tensor([t_local, kernel_ms], dtype=torch.float64, device=device)
+    coll_dev = device if args.backend == "nccl" else torch.device("cpu")
+    t = torch.tensor([t_local, kernel_ms], dtype=torch.float64, device=coll_dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     t_max, kernel_ms_max = float(t[0]), float(t[1])
@@ -173,20 +181,26 @@ def main():
     result = {}
     gather = None
     if world > 1:
-        full = shard.gather_depth(z, dst=0)
+        def gather():
+            if args.backend == "nccl":
+                return shard.gather_depth(z, dst=0)
+            torch.cuda.synchronize()
+            return shard.gather_depth(z.cpu(), dst=0)            # rehearsal only
+        full = gather()
         fence()
         tg = time.perf_counter()
-        reps = max(3, min(20, args.steps // 5))
+        reps = max(3, min(20, args.steps // 15))
         for _ in range(reps):
             step()
-            full = shard.gather_depth(z, dst=0)
+            full = gather()
         torch.cuda.synchronize()
         tg_local = time.perf_counter() - tg
         fence()
-        tt = torch.tensor([tg_local], dtype=torch.float64, device=device)
+        tt = torch.tensor([tg_local], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         gather = {"value": world * n_sets * reps / float(tt[0]), "unit": "frames/s", "steps": reps,
-                  "collective": "torch.distributed.gather (RCCL) of f64 depth maps to rank 0",
+                  "collective": "torch.distributed.gather (%s) of f64 depth maps to rank 0" % ("RCCL" if args.backend == "nccl" else args.backend),
+                  "gathered_bytes_per_step": int(world * n_sets * H * W * 8),
                   "gathered_shape": list(full.shape) if rank == 0 else None}
 
     if rank == 0:
@@ -205,7 +219,8 @@ def main():
         tp = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tp):
             try:
-                traffic = json.load(open(tp)).get(args.config, {}).get("hbm_bytes_per_launch")
+                ent = json.load(open(tp)).get(args.config, {})
+                traffic = ent["hbm_bytes_per_launch"] * n_sets / ent["sets_per_launch"]     # measured per frame-set, scaled to this launch
             except Exception:
                 traffic = None
         result = {

@@ -258,7 +258,7 @@ class Context:
         self._check(lib().slx_set_variant(self._h, int(v)))
 
 
-VARIANT_AUTO, VARIANT_GENERIC, VARIANT_STRIP = range(3)
+VARIANT_AUTO, VARIANT_GENERIC, VARIANT_STRIP, VARIANT_GENERIC_FAST = range(4)
 
 
 def decode_frameset(spec, phase=None, gray=None, want=("z",), device=-1, variant=0):

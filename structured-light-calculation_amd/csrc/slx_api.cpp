@@ -400,8 +400,10 @@ static int launch(slx_ctx *ctx, SlxKParams &kp, int n_sets, bool aux, void *stre
     kp.aligned = al ? 1 : 0;
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
     SLX_HIP(ctx, hipSetDevice(ctx->device));
-    if (ctx->variant >= SLX_VARIANT_STRIP && !slx_strip_eligible(kp, c.mode, aux))
+    if (ctx->variant == SLX_VARIANT_STRIP && !slx_strip_eligible(kp, c.mode, aux))
         return fail(ctx, SLX_ERR_UNAVAILABLE, "variant %d (strip kernel) cannot run this configuration or these operands", ctx->variant);
+    if (ctx->variant == SLX_VARIANT_GENERIC_FAST && !(mode_has_depth(c.mode) && slx_fast_arith_ok(kp)))
+        return fail(ctx, SLX_ERR_UNAVAILABLE, "variant %d (cheap exact arithmetic) needs a depth mode, periods <= 2^14 and moderate calibration magnitudes", ctx->variant);
     if (ctx->timed) SLX_HIP(ctx, hipEventRecord(ctx->ev0, s));
     int e = slx_launch_fused(kp, c.mode, aux, n_sets, ctx->variant, s);
     if (e != 0) return hip_fail(ctx, (hipError_t)e, "kernel launch");

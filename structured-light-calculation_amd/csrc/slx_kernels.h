@@ -47,14 +47,22 @@ struct SlxKParams {
     unsigned rows_per_lane;                     // rows one lane walks per work item (even)
     unsigned items_per_set;                     // ceil(H / (interleave * rows_per_lane)) * chunks_per_group
     unsigned long long total_items;             // items_per_set * n_sets
+    int fast_arith;                             // generic kernel: use the bit-identical cheap unwrap / in-range division (host-checked)
     int dbg;                                    // experiments only (SLX_DBG): 1 = skip stores, 2 = skip compute
     unsigned long long *stamps;                 // diagnostics: 4 words per workgroup (s_memtime / s_memrealtime at start, end) or null
 };
 
-// Kernel variants (slx_set_variant): 0 = automatic, 1 = generic kernel only, 2 = strip kernel only.
+// Kernel variants (slx_set_variant): 0 = automatic (strip kernel when eligible, else the generic kernel with
+// the cheap exact arithmetic when its preconditions hold), 1 = generic kernel with the reference's literal
+// arithmetic, 2 = strip kernel only, 3 = generic kernel with the cheap exact arithmetic.
 #define SLX_VARIANT_AUTO 0
 #define SLX_VARIANT_GENERIC 1
 #define SLX_VARIANT_STRIP 2
+#define SLX_VARIANT_GENERIC_FAST 3
+
+// True when unwrap_stage<true> and tri_depth<true> are bit-identical to the literal arithmetic for these
+// parameters: every period <= 2^14, calibration magnitudes < 2^90.
+bool slx_fast_arith_ok(const SlxKParams &kp);
 
 // True when the strip kernel can run this configuration / these operands.
 bool slx_strip_eligible(const SlxKParams &kp, int mode, bool aux);

@@ -347,8 +347,13 @@ __global__ __launch_bounds__(256) void slx_fused_kernel(const SlxKParams p)
 #pragma unroll
                 for (int f = 1; f < F; f++) {
                     const double pf = (double)pix[f][j];
-                    const int k = (int)__builtin_floor((Uf - pf) / (double)p.period[f] + 0.5);
-                    Uf = pf + (double)(k * p.period[f]);
+                    int k;
+                    if (p.fast_arith) {
+                        Uf = unwrap_stage<true>(Uf, pf, p.period[f], p.inv_period[f], p.half_biased[f], k);
+                    } else {
+                        k = (int)__builtin_floor((Uf - pf) / (double)p.period[f] + 0.5);
+                        Uf = pf + (double)(k * p.period[f]);
+                    }
                     kf[f - 1][j] = k;
                 }
                 U[j] = Uf;
@@ -391,9 +396,8 @@ __global__ __launch_bounds__(256) void slx_fused_kernel(const SlxKParams p)
             const double cC = (a * p.P00 + tvC) + p.K1;
             const double cD = (a * p.P20 + tvD) + p.K2;
             const double Uv = U[j];
-            double zz = -(p.cA - p.cB * Uv) / (cC - cD * Uv);
-            if ((zz < p.fov_min) || (zz > p.fov_max)) zz = 0.0;
-            if (Uv == 0.0 || !valid[j]) zz = 0.0;
+            const double zz = p.fast_arith ? tri_depth<true>(Uv, cC, cD, p.cA, p.cB, p.fov_min, p.fov_max, valid[j])
+                                           : tri_depth<false>(Uv, cC, cD, p.cA, p.cB, p.fov_min, p.fov_max, valid[j]);
             z[j] = zz;
             if constexpr (AUX) {
                 xo[j] = zz * uc / p.fu;
@@ -725,15 +729,25 @@ kernel_fn pick_strip(int F)
 
 }  // namespace
 
-int slx_num_variants(void) { return 3; }
+int slx_num_variants(void) { return 4; }
+
+bool slx_fast_arith_ok(const SlxKParams &kp)
+{
+    for (int f = 0; f < kp.n_freq; f++)
+        if (kp.period[f] > (1 << 14)) return false;
+    // the depth quotient's operands must stay far inside the double range (tri_depth<LEAN>)
+    const double big = 0x1p90;
+    for (double v : {kp.cA, kp.cB, kp.K1, kp.K2, kp.P00, kp.P01, kp.P20, kp.P21, kp.fu, kp.fv, kp.cx, kp.cy})
+        if (!(__builtin_fabs(v) < big)) return false;
+    return true;
+}
 
 bool slx_strip_eligible(const SlxKParams &kp, int mode, bool aux)
 {
     if (aux || !kp.aligned || kp.n_steps != 4) return false;
     if (mode != SLX_MODE_MULTIFREQ && mode != SLX_MODE_GRAY_PHASE) return false;
     if (kp.quads_per_row == 0 || kp.quads_per_row > 1024) return false;
-    for (int f = 0; f < kp.n_freq; f++)
-        if (kp.period[f] > (1 << 14)) return false;
+    if (!slx_fast_arith_ok(kp)) return false;
     if ((unsigned long long)kp.row_stride * (unsigned)kp.height >= (1ull << 31)) return false;   // 32-bit plane offsets
     {
         // every phase plane must sit within 2 GiB of the lowest one (32-bit buffer offsets)
@@ -747,10 +761,6 @@ bool slx_strip_eligible(const SlxKParams &kp, int mode, bool aux)
         if (hi - lo >= (1ull << 31)) return false;
     }
     if ((unsigned long long)kp.width * (unsigned)kp.height >= (1ull << 29)) return false;          // 32-bit output offsets
-    // the depth quotient's operands must stay far inside the double range (tri_depth<LEAN>)
-    const double big = 0x1p90;
-    for (double v : {kp.cA, kp.cB, kp.K1, kp.K2, kp.P00, kp.P01, kp.P20, kp.P21, kp.fu, kp.fv, kp.cx, kp.cy})
-        if (!(__builtin_fabs(v) < big)) return false;
     return true;
 }
 
@@ -776,9 +786,12 @@ static int launch_generic(const SlxKParams &kp, int mode, bool aux, int n_sets, 
 int slx_launch_fused(const SlxKParams &kp_in, int mode, bool aux, int n_sets, int variant, void *stream)
 {
     const bool can_strip = slx_strip_eligible(kp_in, mode, aux);
-    if (variant == SLX_VARIANT_GENERIC || !can_strip) {
+    if (variant == SLX_VARIANT_GENERIC || variant == SLX_VARIANT_GENERIC_FAST || !can_strip) {
         if (variant == SLX_VARIANT_STRIP) return (int)hipErrorInvalidValue;
-        return launch_generic(kp_in, mode, aux, n_sets, stream);
+        SlxKParams kg = kp_in;
+        kg.fast_arith = (variant != SLX_VARIANT_GENERIC && mode >= SLX_MODE_GRAY_PHASE && slx_fast_arith_ok(kp_in)) ? 1 : 0;
+        if (variant == SLX_VARIANT_GENERIC_FAST && !kg.fast_arith) return (int)hipErrorInvalidValue;
+        return launch_generic(kg, mode, aux, n_sets, stream);
     }
     SlxKParams kp = kp_in;
     {

@@ -147,14 +147,15 @@ def test_baseline_config_c5(api, oracle, synth):
 # ------------------------------------------------------------------ unstructured inputs, every branch
 @pytest.mark.parametrize("name", ["C1", "C1x4", "C2", "C3", "C5"])
 @pytest.mark.parametrize("shape", [(48, 64), (31, 250), (9, 511), (3, 1001), (1, 1), (2, 3), (5, 130)])
-def test_random_bytes_all_outputs(api, oracle, synth, name, shape):
+@pytest.mark.parametrize("variant", [0, 1])
+def test_random_bytes_all_outputs(api, oracle, synth, name, shape, variant):
     h, w = shape
     spec = small_spec(synth, name, w, h)
     ph, gr = synth.random_planes(spec, seed=h * 7919 + w)
     if gr is not None and w > 8:
         gr[:, :, : w // 2] = np.where(gr[:, :, : w // 2] > 127, 220, 20)
     want = all_outputs(spec)
-    got = api.decode_frameset(spec, ph, gr, want=want)
+    got = api.decode_frameset(spec, ph, gr, want=want, variant=variant)   # 0: cheap exact arithmetic, 1: literal
     ref = oracle.pipeline(spec, ph, gr, want=want)
     assert_same(got, ref, want)
 
@@ -212,12 +213,14 @@ def test_unwrap_rounding_ties(api, oracle, synth, name):
     assert np.any(r == np.floor(r))
     got = api.decode_frameset(spec, ph, None, want=("z", "k", "U"), variant=api.VARIANT_GENERIC)
     assert_same(got, ref, ("z", "k", "U"))
+    got = api.decode_frameset(spec, ph, None, want=("z", "k", "U"), variant=api.VARIANT_GENERIC_FAST)
+    assert_same(got, ref, ("z", "k", "U"))
     for variant in (api.VARIANT_AUTO, api.VARIANT_STRIP):
         got = api.decode_frameset(spec, ph, None, want=("z",), variant=variant)
         assert_same(got, ref, ("z",))
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3])
 def test_variants_exhaustive_wrapped_phase_through_depth(api, oracle, synth, variant):
     """The fast kernels only emit depth; with an unbounded FOV depth is a strictly monotonic function
     of pix, so depth parity over all 511 x 511 inputs checks their wrapped phase exhaustively
@@ -236,12 +239,14 @@ def test_variants_exhaustive_wrapped_phase_through_depth(api, oracle, synth, var
         assert len(np.unique(np.round(zr, 12))) >= len(np.unique(pr)) * 0.99
 
 
-@pytest.mark.parametrize("name,scene", [("C1", "sphere"), ("C1x4", "tilted"), ("REF", "tilted"), ("C2", "tilted"), ("C4", "sphere")])
-@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("name,scene", [("C1", "sphere"), ("C1x4", "tilted"), ("REF", "tilted"), ("C2", "tilted"), ("C3", "sphere"), ("C4", "sphere")])
+@pytest.mark.parametrize("variant", [1, 2, 3])
 def test_variants_full_size(api, oracle, synth, name, scene, variant):
     spec = synth.make_spec(name)
     ph, gr, _ = synth.render(spec, scene, seed=11, noise_sigma=3.0)
     ref = oracle.pipeline(spec, ph, gr, want=("z",), threads=8)
+    if variant == 2 and spec["mode"] not in (synth.MODE_MULTIFREQ, synth.MODE_GRAY_PHASE):
+        pytest.skip("the strip kernel covers the Gray-free and Gray+phase depth modes")
     got = api.decode_frameset(spec, ph, gr, want=("z",), variant=variant)
     assert_same(got, ref, ("z",))
 
@@ -289,13 +294,13 @@ def test_degenerate_depth_quotients(api, oracle, synth):
     spec["calib"] = cal
     ph, _ = synth.random_planes(spec, seed=5)
     ref = oracle.pipeline(spec, ph, None, want=("z",))
-    for variant in (0, 1, 2):
+    for variant in (0, 1, 2, 3):
         got = api.decode_frameset(spec, ph, None, want=("z",), variant=variant)
         assert np.array_equal(got["z"], ref["z"], equal_nan=True), variant
     cal2 = dict(cal, rot=[1.0, 0, 0, 0, 1.0, 0, 0, 0, 1.0], trans=[0.0, 0.0, 0.0])  # num == 0 everywhere, den varies
     spec["calib"] = cal2
     ref = oracle.pipeline(spec, ph, None, want=("z",))
-    for variant in (0, 1, 2):
+    for variant in (0, 1, 2, 3):
         got = api.decode_frameset(spec, ph, None, want=("z",), variant=variant)
         assert np.array_equal(got["z"], ref["z"], equal_nan=True), variant
 
