@@ -31,13 +31,15 @@ def log(*a):
 
 def make_batch(torch, synth, spec, n_sets, device, seed):
     """Synthetic camera images of n_sets scenes, rendered on the GPU (same forward model as
-    synth.render): uint8 [n_sets, F*N, H, W]."""
+    synth.render): phase uint8 [n_sets, F*N, H, W] and, for modes with a Gray code, gray uint8 [n_sets, 2G, H, W]."""
     import numpy as np
     H, W = spec["height"], spec["width"]
     N, periods = spec["n_steps"], spec["periods"]
     g = torch.Generator(device=device)
     g.manual_seed(seed)
     out = torch.empty((n_sets, len(periods) * N, H, W), dtype=torch.uint8, device=device)
+    n_gray = synth.n_planes(spec)[1]
+    gray = torch.empty((n_sets, n_gray, H, W), dtype=torch.uint8, device=device) if n_gray else None
     scenes = ("tilted", "sphere", "plane")
     for s in range(n_sets):
         z = synth.scene_depth(spec, scenes[s % len(scenes)]) + 3.0 * (s // len(scenes))
@@ -51,10 +53,21 @@ def make_batch(torch, synth, spec, n_sets, device, seed):
                 img = val.clamp_(0, 255).to(torch.uint8)
                 img[~lit] = 0
                 out[s, f * N + k] = img
-    return out
+        if n_gray:
+            G, S = spec["gray_bits"], spec["gray_stripe"]
+            b = (U / S).to(torch.int64).clamp_(0, (1 << G) - 1)
+            code = b ^ (b >> 1)
+            for bit in range(G):
+                on = ((code >> bit) & 1).bool()
+                for inv in (0, 1):
+                    val = torch.where(on ^ bool(inv), 220.0, 20.0) + torch.randn(U.shape, generator=g, device=device, dtype=torch.float64) * 2.0
+                    img = val.clamp_(0, 255).to(torch.uint8)
+                    img[~lit] = 0
+                    gray[s, 2 * bit + inv] = img
+    return out, gray
 
 
-def cpu_baseline(spec, phase_np, budget_s=12.0):
+def cpu_baseline(spec, phase_np, gray_np=None, budget_s=12.0):
     """The oracle (CPU restatement, reference loop order, one thread) timed on whole frame-sets of
     the same workload until ~budget_s of CPU work; then once more on all host cores."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -63,18 +76,19 @@ def cpu_baseline(spec, phase_np, budget_s=12.0):
     n = 0
     t0 = time.perf_counter()
     while True:
-        O.pipeline(spec, phase_np[n % len(phase_np)], None, want=("z",), threads=1, faithful_order=1)
+        O.pipeline(spec, phase_np[n % len(phase_np)], None if gray_np is None else gray_np[n % len(phase_np)], want=("z",), threads=1, faithful_order=1)
         n += 1
         dt = time.perf_counter() - t0
         if dt >= budget_s or n >= 200:
             break
     single = {"value": n / dt, "unit": "frames/s", "cores": 1, "kind": "port",
-              "sample": "%d frame-sets of 1920x1200 3x4-step, oracle/slx_oracle.c single thread, reference loop order, %.1f s" % (n, dt)}
+              "sample": "%d frame-sets of %dx%d (%s), oracle/slx_oracle.c single thread, reference loop order, %.1f s" % (
+                  n, spec["width"], spec["height"], spec["name"], dt)}
     cores = min(len(os.sched_getaffinity(0)), 16)      # a 1-GPU box gets a 16-core share of the host
     m = 0
     t0 = time.perf_counter()
     while True:
-        O.pipeline(spec, phase_np[m % len(phase_np)], None, want=("z",), threads=cores, faithful_order=0)
+        O.pipeline(spec, phase_np[m % len(phase_np)], None if gray_np is None else gray_np[m % len(phase_np)], want=("z",), threads=cores, faithful_order=0)
         m += 1
         dt2 = time.perf_counter() - t0
         if dt2 >= budget_s / 3 or m >= 400:
@@ -129,13 +143,12 @@ def main():
     spec = synth.make_spec(args.config)
     H, W = spec["height"], spec["width"]
     n_phase, n_gray = synth.n_planes(spec)
-    assert n_gray == 0, "bench workload is the Gray-free 3x4-step configuration"
     n_sets = args.sets_per_gpu
     bytes_per_set = H * W * synth.algorithmic_bytes_per_pixel(spec)
     bytes_per_launch = n_sets * bytes_per_set
 
     t0 = time.perf_counter()
-    phase = make_batch(torch, synth, spec, n_sets, device, seed=0x5EED + 4 + rank)
+    phase, gray = make_batch(torch, synth, spec, n_sets, device, seed=0x5EED + 4 + rank)
     z = torch.empty((n_sets, H, W), dtype=torch.float64, device=device)
     torch.cuda.synchronize()
     if rank == 0:
@@ -150,7 +163,7 @@ def main():
     assert sh != 0
 
     def step():
-        ctx.decode_batch(n_sets, phase, None, z, stream=sh)
+        ctx.decode_batch(n_sets, phase, gray, z, stream=sh)
 
     def fence():
         torch.cuda.synchronize()
@@ -208,8 +221,9 @@ def main():
         parity = None
         if not args.no_cpu_baseline and world == 1:
             sample = phase[: min(4, n_sets)].cpu().numpy()
-            cpu_single, cpu_multi, O = cpu_baseline(spec, sample)
-            ref = O.pipeline(spec, sample[0], None, want=("z",), threads=min(len(os.sched_getaffinity(0)), 16))["z"]
+            gsample = gray[: min(4, n_sets)].cpu().numpy() if gray is not None else None
+            cpu_single, cpu_multi, O = cpu_baseline(spec, sample, gsample)
+            ref = O.pipeline(spec, sample[0], None if gsample is None else gsample[0], want=("z",), threads=min(len(os.sched_getaffinity(0)), 16))["z"]
             got = z[0].cpu().numpy()
             parity = bool(np.array_equal(got, ref, equal_nan=True))
             if not parity:
@@ -227,12 +241,12 @@ def main():
             "metric": "depth_frames_per_sec", "value": world * n_sets * args.steps / t_max, "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": t_max / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32+f64", "data": "synthetic",
-            "config": {"workload": "%s: %dx%d, %d-frequency x %d-step temporal unwrap + triangulation, %d frame-sets per GPU per step"
-                                   % (args.config, W, H, spec["n_freq"], spec["n_steps"], n_sets),
+            "config": {"workload": "%s: %dx%d, %d-frequency x %d-step temporal unwrap%s + triangulation, %d frame-sets per GPU per step"
+                                   % (args.config, W, H, spec["n_freq"], spec["n_steps"], " + %d-bit Gray mask" % spec["gray_bits"] if n_gray else "", n_sets),
                        "periods": spec["periods"], "sharding": "by frame-set, no data-path collective", "kernel_variant": args.variant},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "kernel": {0: "slx_strip_kernel<MULTIFREQ,F=3> (auto)", 1: "slx_fused_kernel<MULTIFREQ,F=3,N4>", 2: "slx_strip_kernel<MULTIFREQ,F=3>"}[args.variant], "launch_ms": kernel_ms_max,
+                         "kernel": ("slx_strip_kernel" if (args.variant in (0, 2) and n_gray == 0 and spec["n_steps"] == 4) else "slx_fused_kernel") + "<mode %d, F=%d>" % (spec["mode"], spec["n_freq"]), "launch_ms": kernel_ms_max,
                          "algorithmic_bytes_per_launch": bytes_per_launch},
             "achieved_hbm_gbps_per_gpu": achieved,
             "cpu_baseline": cpu_single, "cpu_baseline_all_cores": cpu_multi,
