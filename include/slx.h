@@ -21,6 +21,7 @@
  *        R/CCalculation.cpp:525-592, :666-785            -> slx_decode / slx_decode_batch
  *   CDecode*::GetResult, m_x/y/zMat, m_ProjectorU
  *        R/CDecodePhase.cpp:99, R/CCalculation.h:29-38    -> slx_get_output / slx_get_depth
+ *   CCalculation::Result          R/CCalculation.cpp:323  -> slx_get_point_cloud (+ slx::CCalculation::Result text writer)
  *   ~CCalculation / ReleaseSpace  R/CCalculation.cpp:30   -> slx_destroy
  *   ErrorHandling(msg)            R/GlobalFunction.cpp:3  -> int status + slx_last_error
  *                                                           (never prints, never blocks)
@@ -143,6 +144,13 @@ int slx_synchronize(slx_ctx *ctx);
  * size listed at enum slx_output. */
 int slx_get_output(slx_ctx *ctx, int which, void *dst, size_t dst_bytes, int mem_kind);
 int slx_get_depth(slx_ctx *ctx, double *z, int mem_kind);
+
+/* Point cloud of the last slx_decode, the data CCalculation::Result writes (R/CCalculation.cpp:323-357): packed
+ * (x, y, z) f64 triples of every pixel whose depth lies in [fov_min, fov_max], in the reference's order (column u outer,
+ * row v inner), x = z*(u-cx)/fu, y = z*(v-cy)/fv (R/CCalculation.cpp:756-771).  Compacted on the device.
+ * xyz: room for `capacity_points` triples (host or device per mem_kind); *n_points receives the number of valid points
+ * (also when it exceeds the capacity, in which case SLX_ERR_INVALID_ARG is returned and nothing is copied). */
+int slx_get_point_cloud(slx_ctx *ctx, double *xyz, size_t capacity_points, size_t *n_points, int mem_kind);
 
 /* Device pointer of an output buffer owned by the context (valid until slx_destroy). */
 int slx_output_device_ptr(slx_ctx *ctx, int which, void **ptr);

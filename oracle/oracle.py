@@ -157,6 +157,17 @@ def pipeline(spec, phase_planes, gray_planes=None, want=("z",), threads=1, faith
     return res
 
 
+def point_cloud(spec, z):
+    """Packed (x, y, z) of the depths inside the FOV in CCalculation::Result's order: float64 [n, 3]."""
+    L = lib()
+    L.slxo_point_cloud.restype = C.c_size_t
+    cfg = make_config(spec)
+    z = np.ascontiguousarray(z, dtype=np.float64)
+    xyz = np.zeros((z.size, 3))
+    n = L.slxo_point_cloud(C.byref(cfg), _ptr(z, C.c_double), _ptr(xyz, C.c_double))
+    return xyz[:n].copy()
+
+
 def projection_matrix(pro, rot, trans):
     L = lib()
     P = np.zeros(12)

@@ -284,6 +284,27 @@ void slxo_triangulate(const slxo_config *cfg, const double *U, const uint8_t *ma
     }
 }
 
+/* -------------------------------------------------------------- Result --- */
+size_t slxo_point_cloud(const slxo_config *cfg, const double *z, double *xyz)
+{
+    const int W = cfg->width, H = cfg->height;
+    const double fu = cfg->cam[0], fv = cfg->cam[4], cx = cfg->cam[2], cy = cfg->cam[5];
+    size_t n = 0;
+    for (int u = 0; u < W; u++) {                            /* :335 */
+        for (int v = 0; v < H; v++) {
+            double valZ = z[(size_t)v * W + u];              /* :340 */
+            if ((valZ < cfg->fov_min) || (valZ > cfg->fov_max))   /* :341 */
+                continue;
+            double uc = (u + cfg->col_offset) - cx, vc = (v + cfg->row_offset) - cy;   /* :762-763 */
+            xyz[3 * n + 0] = valZ * uc / fu;                 /* :766, written at :347 */
+            xyz[3 * n + 1] = valZ * vc / fv;                 /* :767 */
+            xyz[3 * n + 2] = valZ;
+            n++;
+        }
+    }
+    return n;
+}
+
 /* ------------------------------------------------------------------ x2 --- */
 /* BUILD-DEFINED (SURVEY.md section 8 a-ext x2): U_1 = pix_1;
  * k_f = (int)floor((U_{f-1} - pix_f)/T_f + 0.5); U_f = pix_f + k_f*T_f (double). */

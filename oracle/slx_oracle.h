@@ -101,6 +101,10 @@ void slxo_triangulate(const slxo_config *cfg, const double *U, const uint8_t *ma
                       double cA, double cB, const double *cC, const double *cD,
                       double *z, double *x, double *y);
 
+/* CCalculation::Result, R/CCalculation.cpp:323-357, without the file: packed x y z of the depths inside the FOV,
+ * u outer / v inner.  xyz: room for 3*width*height doubles.  Returns the number of points. */
+size_t slxo_point_cloud(const slxo_config *cfg, const double *z, double *xyz);
+
 /* x2: hierarchical temporal unwrap (BUILD-DEFINED, SURVEY.md section 8 a-ext). */
 void slxo_unwrap_multifreq(const double *pix, int n_freq, const int *period,
                            int width, int height, double *U, int32_t *k);

@@ -28,7 +28,7 @@ OUT_NAMES = {"z": OUT_Z, "x": OUT_X, "y": OUT_Y, "U": OUT_U, "pix": OUT_PIX, "gr
 SYMBOLS = [
     "slx_validate_config", "slx_create", "slx_destroy", "slx_last_error", "slx_set_gray_lut",
     "slx_set_frame", "slx_decode", "slx_decode_batch", "slx_synchronize", "slx_get_output",
-    "slx_get_depth", "slx_output_device_ptr", "slx_get_calibration", "slx_enable_timing",
+    "slx_get_depth", "slx_get_point_cloud", "slx_output_device_ptr", "slx_get_calibration", "slx_enable_timing",
     "slx_last_decode_ms", "slx_debug_stamps", "slx_set_variant", "slx_version",
 ]
 
@@ -76,6 +76,7 @@ def lib():
         L.slx_synchronize.argtypes = [vp]
         L.slx_get_output.argtypes = [vp, C.c_int, vp, sz, C.c_int]
         L.slx_get_depth.argtypes = [vp, vp, C.c_int]
+        L.slx_get_point_cloud.argtypes = [vp, vp, sz, C.POINTER(sz), C.c_int]
         L.slx_output_device_ptr.argtypes = [vp, C.c_int, C.POINTER(vp)]
         L.slx_get_calibration.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.slx_enable_timing.argtypes = [vp, C.c_int]
@@ -230,6 +231,17 @@ class Context:
     def get_depth(self):
         a = np.empty(self.output_shape(OUT_Z), dtype=np.float64)
         self._check(lib().slx_get_depth(self._h, a.ctypes.data, MEM_HOST))
+        return a
+
+    def get_point_cloud(self):
+        """Packed (x, y, z) of the depths inside the FOV, column-major order like CCalculation::Result: float64 [n, 3]."""
+        n = C.c_size_t(0)
+        rc = lib().slx_get_point_cloud(self._h, None, 0, C.byref(n), MEM_HOST)
+        if n.value == 0:
+            self._check(rc)
+            return np.empty((0, 3), dtype=np.float64)
+        a = np.empty((n.value, 3), dtype=np.float64)
+        self._check(lib().slx_get_point_cloud(self._h, a.ctypes.data, n.value, C.byref(n), MEM_HOST))
         return a
 
     def get_calibration(self):

@@ -275,6 +275,43 @@ std::vector<double> CCalculation::Fetch(int which)
     if (!m_ctx || !m_done) return std::vector<double>();
     return fetch(m_ctx, which, (size_t)m_sp.CAMERA_RESROW * m_sp.CAMERA_RESLINE, m_err);
 }
+std::vector<double> CCalculation::GetPointCloud()
+{
+    std::vector<double> pts;
+    if (!m_ctx || !m_done) return pts;
+    size_t n = 0;
+    int rc = slx_get_point_cloud(m_ctx, nullptr, 0, &n, SLX_MEM_HOST);     // first call: the count
+    if (n == 0) {
+        if (rc != SLX_OK) m_err = slx_last_error(m_ctx);
+        return pts;
+    }
+    pts.resize(n * 3);
+    if (slx_get_point_cloud(m_ctx, pts.data(), n, &n, SLX_MEM_HOST) != SLX_OK) {
+        m_err = slx_last_error(m_ctx);
+        pts.clear();
+    }
+    return pts;
+}
+
+bool CCalculation::Result(std::string fileName, int i)
+{
+    if (i != 0 || !m_ctx || !m_done) return false;
+    std::fstream file;
+    file.open(fileName.c_str(), std::ios::out);
+    if (!file) {
+        m_err = "CCalculation::Result() OpenFile Error:" + fileName;
+        return false;
+    }
+    const std::vector<double> pts = GetPointCloud();
+    for (size_t k = 0; k + 2 < pts.size(); k += 3) {
+        file << pts[k] << ' ';
+        file << pts[k + 1] << ' ';
+        file << pts[k + 2] << std::endl;
+    }
+    file.close();
+    return true;
+}
+
 std::vector<double> CCalculation::GetZ() { return Fetch(SLX_OUT_Z); }
 std::vector<double> CCalculation::GetX() { return Fetch(SLX_OUT_X); }
 std::vector<double> CCalculation::GetY() { return Fetch(SLX_OUT_Y); }

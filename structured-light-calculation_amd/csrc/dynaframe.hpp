@@ -108,6 +108,10 @@ public:
     // groupNum 0 = vGray images (2*G of them), 1 = vPhase images (N of them).
     bool SetSensorFrame(int groupNum, int idx, const Image8 &pic);
     bool CalculateFirst();                          // R/CCalculation.cpp:171
+    // R/CCalculation.cpp:323: text point cloud "x y z\n" of the depths inside the FOV, column outer / row inner,
+    // default ostream formatting.  Only frame 0 (the static reconstruction) exists here.
+    bool Result(std::string fileName, int i = 0);
+    std::vector<double> GetPointCloud();            // the same points, packed x y z
     // m_zMat[0], m_xMat[0], m_yMat[0], m_ProjectorU[0] (CV_64FC1, rows x cols)
     std::vector<double> GetZ(), GetX(), GetY(), GetProjectorU();
     const std::string &LastError() const { return m_err; }

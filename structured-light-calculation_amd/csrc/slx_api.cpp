@@ -40,6 +40,9 @@ struct slx_ctx {
     std::vector<int16_t> lut;
     int16_t *d_lut = nullptr;
     std::vector<Plane> phase, gray;
+    unsigned *d_cloud_counts = nullptr, *d_cloud_offsets = nullptr;   // width + 1 each, point-cloud compaction
+    double *d_cloud = nullptr;
+    size_t cloud_capacity = 0;
     void *out[SLX_OUT_COUNT] = {};
     size_t out_bytes[SLX_OUT_COUNT] = {};
     size_t staging_pitch = 0;
@@ -231,6 +234,8 @@ void slx_destroy(slx_ctx *ctx)
     for (void *o : ctx->out)
         if (o) (void)hipFree(o);
     if (ctx->d_lut) (void)hipFree(ctx->d_lut);
+    for (void *q : {(void *)ctx->d_cloud_counts, (void *)ctx->d_cloud_offsets, (void *)ctx->d_cloud})
+        if (q) (void)hipFree(q);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -501,6 +506,47 @@ int slx_get_depth(slx_ctx *ctx, double *z, int mem_kind)
 {
     if (!ctx) return SLX_ERR_INVALID_ARG;
     return slx_get_output(ctx, SLX_OUT_Z, z, ctx->out_bytes[SLX_OUT_Z], mem_kind);
+}
+
+int slx_get_point_cloud(slx_ctx *ctx, double *xyz, size_t capacity_points, size_t *n_points, int mem_kind)
+{
+    if (!ctx || !n_points) return SLX_ERR_INVALID_ARG;
+    const slx_config &c = ctx->cfg;
+    if (!mode_has_depth(c.mode)) return fail(ctx, SLX_ERR_UNAVAILABLE, "mode %d produces no depth", c.mode);
+    if (!ctx->decoded) return fail(ctx, SLX_ERR_NOT_DECODED, "no decode has run yet");
+    if (mem_kind != SLX_MEM_HOST && mem_kind != SLX_MEM_DEVICE) return fail(ctx, SLX_ERR_INVALID_ARG, "unknown mem_kind %d", mem_kind);
+    SLX_HIP(ctx, hipSetDevice(ctx->device));
+    SLX_HIP(ctx, hipDeviceSynchronize());   // the decode may have run on a caller stream
+    const size_t w1 = (size_t)c.width + 1;
+    if (!ctx->d_cloud_counts) SLX_HIP(ctx, hipMalloc((void **)&ctx->d_cloud_counts, w1 * sizeof(unsigned)));
+    if (!ctx->d_cloud_offsets) SLX_HIP(ctx, hipMalloc((void **)&ctx->d_cloud_offsets, w1 * sizeof(unsigned)));
+    const double *z = (const double *)ctx->out[SLX_OUT_Z];
+    int e = slx_launch_cloud_count(ctx->kp, z, ctx->d_cloud_counts, ctx->stream);
+    if (e == 0) e = slx_launch_cloud_scan(c.width, ctx->d_cloud_counts, ctx->d_cloud_offsets, ctx->stream);
+    if (e != 0) return hip_fail(ctx, (hipError_t)e, "point-cloud count");
+    unsigned total = 0;
+    SLX_HIP(ctx, hipMemcpyAsync(&total, ctx->d_cloud_offsets + c.width, sizeof total, hipMemcpyDeviceToHost, ctx->stream));
+    SLX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *n_points = total;
+    if (total == 0) return SLX_OK;
+    if (!xyz || capacity_points < total) return fail(ctx, SLX_ERR_INVALID_ARG, "the cloud has %u points, the buffer holds %zu", total, capacity_points);
+    double *dst = xyz;
+    if (mem_kind == SLX_MEM_HOST) {
+        if (ctx->cloud_capacity < total) {
+            if (ctx->d_cloud) (void)hipFree(ctx->d_cloud);
+            ctx->d_cloud = nullptr;
+            ctx->cloud_capacity = 0;
+            SLX_HIP(ctx, hipMalloc((void **)&ctx->d_cloud, (size_t)total * 3 * sizeof(double)));
+            ctx->cloud_capacity = total;
+        }
+        dst = ctx->d_cloud;
+    }
+    e = slx_launch_cloud_write(ctx->kp, z, ctx->d_cloud_offsets, dst, ctx->stream);
+    if (e != 0) return hip_fail(ctx, (hipError_t)e, "point-cloud write");
+    if (mem_kind == SLX_MEM_HOST)
+        SLX_HIP(ctx, hipMemcpyAsync(xyz, dst, (size_t)total * 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    SLX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return SLX_OK;
 }
 
 int slx_get_calibration(const slx_ctx *ctx, double P[12], double *cA, double *cB)

@@ -682,6 +682,72 @@ __global__ __launch_bounds__(256) void slx_strip_kernel(const SlxKParams p)
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Point cloud (CCalculation::Result, R/CCalculation.cpp:323-357): the reference walks u outer / v inner and
+// writes "x y z" for every depth inside the FOV.  Here: per-column counts, an exclusive scan over the columns,
+// and a per-column write.  One lane per column: a wave reads 64 adjacent doubles of a row at a time.
+__device__ __forceinline__ bool cloud_keep(double zz, double fov_min, double fov_max)
+{
+    return !((zz < fov_min) || (zz > fov_max));                     // the reference's `continue` test, negated
+}
+
+__global__ __launch_bounds__(256) void slx_cloud_count_kernel(const double *z, unsigned *counts, int W, int H, double fov_min, double fov_max)
+{
+    const int u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= W) return;
+    unsigned n = 0;
+    for (int v = 0; v < H; v++) n += cloud_keep(z[(size_t)v * W + u], fov_min, fov_max) ? 1u : 0u;
+    counts[u] = n;
+}
+
+// offsets[u] = sum of counts[0..u), offsets[W] = total.  One workgroup; W <= a few thousand.
+__global__ __launch_bounds__(1024) void slx_cloud_scan_kernel(const unsigned *counts, unsigned *offsets, int W)
+{
+    __shared__ unsigned part[1024];
+    const unsigned t = threadIdx.x;
+    const int per = (W + 1023) / 1024;
+    unsigned sum = 0;
+    for (int i = 0; i < per; i++) {
+        const int u = (int)t * per + i;
+        if (u < W) sum += counts[u];
+    }
+    part[t] = sum;
+    __syncthreads();
+    for (unsigned d = 1; d < 1024; d <<= 1) {                       // Hillis-Steele inclusive scan of the partials
+        const unsigned v = t >= d ? part[t - d] : 0u;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    unsigned run = t ? part[t - 1] : 0u;
+    for (int i = 0; i < per; i++) {
+        const int u = (int)t * per + i;
+        if (u < W) {
+            offsets[u] = run;
+            run += counts[u];
+        }
+    }
+    if (t == 1023) offsets[W] = part[1023];
+}
+
+__global__ __launch_bounds__(256) void slx_cloud_write_kernel(const double *z, const unsigned *offsets, double *xyz, int W, int H, int row_offset,
+                                                             double fov_min, double fov_max, double cx, double cy, double fu, double fv)
+{
+    const int u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= W) return;
+    size_t o = (size_t)offsets[u] * 3;
+    const double uc = (double)u - cx;                                // R/CCalculation.cpp:762
+    for (int v = 0; v < H; v++) {
+        const double zz = z[(size_t)v * W + u];
+        if (!cloud_keep(zz, fov_min, fov_max)) continue;
+        const double vc = (double)(v + row_offset) - cy;            // :763
+        xyz[o + 0] = zz * uc / fu;                                   // :766
+        xyz[o + 1] = zz * vc / fv;                                   // :767
+        xyz[o + 2] = zz;
+        o += 3;
+    }
+}
+
 typedef void (*kernel_fn)(const SlxKParams);
 
 template <int MODE, int F>
@@ -730,6 +796,26 @@ kernel_fn pick_strip(int F)
 }  // namespace
 
 int slx_num_variants(void) { return 4; }
+
+int slx_launch_cloud_count(const SlxKParams &kp, const double *z, unsigned *counts, void *stream)
+{
+    hipLaunchKernelGGL(slx_cloud_count_kernel, dim3((kp.width + 255) / 256), dim3(256), 0, (hipStream_t)stream, z, counts, kp.width, kp.height,
+                       kp.fov_min, kp.fov_max);
+    return (int)hipGetLastError();
+}
+
+int slx_launch_cloud_scan(int width, const unsigned *counts, unsigned *offsets, void *stream)
+{
+    hipLaunchKernelGGL(slx_cloud_scan_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, counts, offsets, width);
+    return (int)hipGetLastError();
+}
+
+int slx_launch_cloud_write(const SlxKParams &kp, const double *z, const unsigned *offsets, double *xyz, void *stream)
+{
+    hipLaunchKernelGGL(slx_cloud_write_kernel, dim3((kp.width + 255) / 256), dim3(256), 0, (hipStream_t)stream, z, offsets, xyz, kp.width, kp.height,
+                       kp.row_offset, kp.fov_min, kp.fov_max, kp.cx, kp.cy, kp.fu, kp.fv);
+    return (int)hipGetLastError();
+}
 
 bool slx_fast_arith_ok(const SlxKParams &kp)
 {

@@ -87,6 +87,9 @@ int main(int argc, char **argv)
     if (vGrayMat.size() != n || vPhaseMat.size() != n || z.size() != n || x.size() != n || y.size() != n || U.size() != n)
         return die("results", "wrong size");
 
+    if (!calc.Result(std::string(argv[2]) + ".txt", 0)) return die("Result", calc.LastError());   // R/CCalculation.cpp:195-200
+    if (calc.Result("/nonexistent-dir/cloud.txt", 0)) return die("Result", "unwritable path accepted");
+
     f = std::fopen(argv[2], "wb");
     if (!f) return die("write", argv[2]);
     for (const std::vector<double> *v : {&vGrayMat, &vPhaseMat, &z, &x, &y, &U}) std::fwrite(v->data(), sizeof(double), n, f);

@@ -405,6 +405,27 @@ def test_gray_lut_replacement(api, oracle, synth):
             assert np.array_equal(ctx.get_output(w), ref[w], equal_nan=True), w
 
 
+# ------------------------------------------------------------------ point cloud (CCalculation::Result)
+@pytest.mark.parametrize("name,shape", [("C1x4", (120, 200)), ("C4", (1200, 1920)), ("C3", (33, 130)), ("C2", (1, 4))])
+def test_point_cloud(api, oracle, synth, name, shape):
+    h, w = shape
+    spec = small_spec(synth, name, w, h) if (h, w) != (1200, 1920) else synth.make_spec(name)
+    ph, gr, _ = synth.render(spec, "sphere", seed=9, noise_sigma=2.0)
+    z = oracle.pipeline(spec, ph, gr, want=("z",), threads=8)["z"]
+    ref = oracle.point_cloud(spec, z)
+    with api.Context(spec) as ctx:
+        ctx.set_frames(ph, gr)
+        ctx.decode()
+        got = ctx.get_point_cloud()
+    assert got.shape == ref.shape and ref.shape[0] > 0
+    assert np.array_equal(got, ref)
+    # nothing in the FOV -> an empty cloud, not an error
+    with api.Context(dict(spec, fov_min=1e9, fov_max=2e9)) as ctx:
+        ctx.set_frames(ph, gr)
+        ctx.decode()
+        assert ctx.get_point_cloud().shape == (0, 3)
+
+
 # ------------------------------------------------------------------ sharding on the device
 def test_row_tiles_and_frameset_shards_on_gpu(api, oracle, synth, shard):
     spec = small_spec(synth, "C3", 128, 50)
@@ -472,6 +493,10 @@ def test_cpp_host_loop(tmp_path, oracle, synth, golden_dir):
     subprocess.check_call([exe, code_dir + "in.bin", code_dir + "out.bin", str(W), str(H), str(PW), code_dir, "vGrayCode.txt"])
     out = np.fromfile(code_dir + "out.bin", dtype=np.float64).reshape(6, H, W)
     ref = oracle.pipeline(spec, ph, gr, want=("gray", "pix", "z", "x", "y", "U"))
+    # CCalculation::Result: the text point cloud, default ostream formatting == "%g"
+    pts = oracle.point_cloud(spec, ref["z"])
+    want_txt = "".join("%g %g %g\n" % tuple(p) for p in pts)
+    assert open(code_dir + "out.bin.txt").read() == want_txt
     for i, w in enumerate(("gray", "pix", "z", "x", "y", "U")):
         r = ref[w][0] if w == "pix" else ref[w]
         assert np.array_equal(out[i], r, equal_nan=True), w

@@ -201,6 +201,24 @@ def test_gray_mask_three_tap(oracle, synth):
     assert np.array_equal(res2["z"][keep], res["z"][keep])
 
 
+def test_point_cloud_order_and_filter(oracle, synth):
+    """CCalculation::Result: column outer / row inner, only depths inside [fov_min, fov_max]."""
+    spec = small_spec(synth, "C1x4", 16, 12)
+    ph, gr, _ = synth.render(spec, "sphere")
+    res = oracle.pipeline(spec, ph, gr, want=("z", "x", "y"))
+    z = res["z"].copy()
+    z[3, 5] = 0.0                                                 # an invalid pixel is dropped
+    z[4, 5] = spec["fov_max"]                                     # the bounds themselves are kept
+    pts = oracle.point_cloud(spec, z)
+    keep = ~((z < spec["fov_min"]) | (z > spec["fov_max"]))
+    assert pts.shape == (int(keep.sum()), 3)
+    vv, uu = np.nonzero(keep.T)                                   # column-major walk
+    assert np.array_equal(pts[:, 2], z.T[keep.T])
+    cam = spec["calib"]["cam"]
+    assert np.array_equal(pts[:, 0], z.T[keep.T] * (vv - cam[2]) / cam[0])
+    assert np.array_equal(pts[:, 1], z.T[keep.T] * (uu - cam[5]) / cam[4])
+
+
 # ---------------------------------------------------------------- regression vectors
 @pytest.mark.parametrize("name", GOLDEN_SCENES)
 def test_scene_golden(oracle, synth, golden_dir, name):
