@@ -39,6 +39,8 @@ struct SlxKParams {
     // ---- fast path (slx_strip_kernel) ----
     const uint8_t *phase_base;                  // lowest phase-plane address: the buffer descriptor's base
     unsigned phase_rel[SLX_MAX_PHASE_PLANES];   // phase[k] - phase_base (fits 32 bits, checked by slx_strip_eligible)
+    unsigned gray_rel[SLX_MAX_GRAY_PLANES];     // gray[k] + set offset difference - phase_base, when the Gray planes ride the ring
+    long long gray_set_delta;                   // gray_set_stride - phase_set_stride (the descriptor's base advances by phase_set_stride)
     double inv_period[SLX_MAX_FREQ];            // RN(1/T_f)
     double half_biased[SLX_MAX_FREQ];           // 0.5 + 2^-30/T_f
     int std_gray;                               // lut is the reflected Gray code: bin = prefix-xor(gray)

@@ -465,10 +465,14 @@ struct StripPos {
     unsigned out_off[2];               // ... and offset in doubles within the frame-set's depth map
 };
 
-// Store slot s = k*64 + lane of store instruction k holds pixels 2s, 2s+1 of the wave's 256-pixel
-// run, i.e. half of source lane s/2's quad.
-__device__ __forceinline__ StripPos strip_locate(const SlxKParams &p, unsigned item)
+// Store slot s = k*64 + lane of store instruction k holds pixels 2s, 2s+1 of the wave's pixel run, i.e. half
+// of a source lane's quad.  HALO (Gray-mask mode): a wave owns 62 quads and carries one halo quad on
+// either side (lanes 0 and 63), so the 3-tap horizontal AND of x3 never leaves the wave; chunks then
+// advance by 62 quads and the run a wave stores is the 62 inner quads.
+template <bool HALO>
+__device__ __forceinline__ StripPos strip_locate(const SlxKParams &p, unsigned item, bool &lane_valid)
 {
+    constexpr unsigned SPAN = HALO ? 62u : 64u;
     StripPos s;
     const unsigned lane = threadIdx.x & 63u;
     s.set = item / p.items_per_set;
@@ -476,27 +480,35 @@ __device__ __forceinline__ StripPos strip_locate(const SlxKParams &p, unsigned i
     const unsigned g = rem / p.chunks_per_group;
     const unsigned c = rem - g * p.chunks_per_group;
     const unsigned row_base = g * p.rows_per_lane * p.interleave;
-    const unsigned idx = c * 64u + lane;
+    const unsigned total = p.interleave * p.quads_per_row;           // quads of one row group, rows laid end to end
+    const int idx_raw = (int)(c * SPAN + lane) - (HALO ? 1 : 0);
+    lane_valid = idx_raw >= 0 && (unsigned)idx_raw < total;
+    const unsigned idx = lane_valid ? (unsigned)idx_raw : 0u;
     const unsigned sub = idx / p.quads_per_row;
     s.cq = idx - sub * p.quads_per_row;
     s.row = row_base + sub;
 #pragma unroll
     for (int k = 0; k < 2; k++) {
         const unsigned slot = (unsigned)k * 64u + lane;
-        const unsigned vidx = c * 64u + (slot >> 1);
+        const unsigned vidx = c * SPAN + (slot >> 1);                // the quad whose pixels this slot stores
+        const bool ok = vidx < total && (!HALO || slot < 2u * SPAN);
         const unsigned vsub = vidx / p.quads_per_row;
         const unsigned vcq = vidx - vsub * p.quads_per_row;
-        s.out_row[k] = row_base + vsub;
+        s.out_row[k] = ok ? row_base + vsub : 0xFFFFFFFFu;           // never < H: nothing is stored
         s.out_off[k] = (row_base + vsub) * (unsigned)p.width + vcq * SLX_QUAD + (slot & 1u) * 2u;
     }
     return s;
 }
 
-template <int MODE, int F>
+// GB > 0: the 2*GB Gray planes ride the DMA ring behind the phase planes (GB = gray_bits, compile time because
+// s_waitcnt takes an immediate); GB == 0: Gray planes, if any, are read with ordinary loads inside the step.
+template <int MODE, int F, int GB>
 __global__ __launch_bounds__(256) void slx_strip_kernel(const SlxKParams p)
 {
-    constexpr bool HAS_GRAY = MODE == SLX_MODE_GRAY_PHASE;
-    constexpr int NP = F * 4;                     // phase planes
+    constexpr bool MASKED = MODE == SLX_MODE_MULTIFREQ_GRAYMASK;
+    constexpr bool HAS_GRAY = MODE == SLX_MODE_GRAY_PHASE || MASKED;
+    constexpr int NPH = F * 4;                    // phase planes
+    constexpr int NP = NPH + 2 * GB;              // planes in the ring
     constexpr unsigned ROW_DW = NP * 64;          // one row of the fringe stack in LDS, dwords per wave
     typedef double vec2 __attribute__((ext_vector_type(2)));
     typedef __attribute__((address_space(3))) void lds_void;
@@ -531,7 +543,8 @@ __global__ __launch_bounds__(256) void slx_strip_kernel(const SlxKParams p)
         asm volatile("" : "+v"(hb[f]));
     }
 
-    const StripPos pos = strip_locate(p, item);
+    bool lane_valid;
+    const StripPos pos = strip_locate<MASKED>(p, item, lane_valid);
     const size_t pset = (size_t)pos.set * p.phase_set_stride;
     const size_t gset = (size_t)pos.set * p.gray_set_stride;
     double *zset = p.z + (size_t)pos.set * p.out_set_stride;
@@ -543,13 +556,19 @@ __global__ __launch_bounds__(256) void slx_strip_kernel(const SlxKParams p)
     const unsigned dma_step = step_rows * row_stride;
     const unsigned dma_last = last_row * row_stride + pos.cq * SLX_QUAD;   // rows past the tile: harmless re-read of the last row
     unsigned dma_off = pos.row * row_stride + pos.cq * SLX_QUAD;           // offset of the next row to issue
+    unsigned gray_soff[GB > 0 ? 2 * GB : 1];                           // scalar: plane offset + this set's extra offset
+#pragma unroll
+    for (int k = 0; k < 2 * GB; k++) gray_soff[k] = p.gray_rel[k] + (unsigned)((long long)pos.set * p.gray_set_delta);
     auto issue_row = [&](unsigned slot, unsigned) {                    // DMA of the next row of the item into ring[slot]
         const unsigned voff = dma_off < dma_last ? dma_off : dma_last;
         dma_off += dma_step;
         uint32_t *dst = ring + slot * ROW_DW;
 #pragma unroll
-        for (int k = 0; k < NP; k++)
+        for (int k = 0; k < NPH; k++)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void *)(dst + k * 64), 4, voff, p.phase_rel[k], 0, 0);
+#pragma unroll
+        for (int k = 0; k < 2 * GB; k++)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void *)(dst + (NPH + k) * 64), 4, voff, gray_soff[k], 0, 0);
     };
     const unsigned out_step = step_rows * W;
     unsigned out_off[2] = {pos.out_off[0], pos.out_off[1]};            // next row to store, per store slot
@@ -587,6 +606,7 @@ __global__ __launch_bounds__(256) void slx_strip_kernel(const SlxKParams p)
         if (i > 0) flush_row(i - 1);                                    // last row's stores, one step late
 
         double z[SLX_QUAD] = {0.0, 0.0, 0.0, 0.0};
+        int v0[SLX_QUAD] = {1, 1, 1, 1};                                // x3: lanes without pixels never veto
         if (row < H) {
             const uint32_t *src = ring + slot * ROW_DW + lane;
             float pix[F][SLX_QUAD];
@@ -599,39 +619,57 @@ __global__ __launch_bounds__(256) void slx_strip_kernel(const SlxKParams p)
                 pix[f][2] = wrapped_pix_from_diffs((float)byte_diff<2>(w0, w2), (float)byte_diff<2>(w1, w3), Tf[f]);
                 pix[f][3] = wrapped_pix_from_diffs((float)byte_diff<3>(w0, w2), (float)byte_diff<3>(w1, w3), Tf[f]);
             }
+            uint32_t gw[GB > 0 ? 2 * GB : 1];
+#pragma unroll
+            for (int k = 0; k < 2 * GB; k++) gw[k] = src[(NPH + k) * 64];
             // the slot is free once it has been read: row i+2 goes into it
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             if (i + 2 < RB) issue_row(slot, i + 2);
 
             double U[SLX_QUAD];
+            int bin[SLX_QUAD] = {0, 0, 0, 0};
             if constexpr (HAS_GRAY) {
                 const unsigned voff = row * row_stride + pos.cq * SLX_QUAD;
                 unsigned code[SLX_QUAD] = {0u, 0u, 0u, 0u};
-                for (int b = p.gray_bits - 1; b >= 0; b--) {           // MSB first: code = 2*code + bit
-                    const uint32_t wa = *reinterpret_cast<const uint32_t *>(p.gray[2 * b] + gset + voff);
-                    const uint32_t wb = *reinterpret_cast<const uint32_t *>(p.gray[2 * b + 1] + gset + voff);
+                if constexpr (GB > 0) {
 #pragma unroll
-                    for (int j = 0; j < SLX_QUAD; j++)
-                        code[j] = code[j] + code[j] + (ibyte(wa, j) > ibyte(wb, j) ? 1u : 0u);
+                    for (int b = GB - 1; b >= 0; b--) {                 // MSB first: code = 2*code + bit
+                        const uint32_t wa = gw[2 * b], wb = gw[2 * b + 1];
+#pragma unroll
+                        for (int j = 0; j < SLX_QUAD; j++)
+                            code[j] = code[j] + code[j] + (ibyte(wa, j) > ibyte(wb, j) ? 1u : 0u);
+                    }
+                } else {
+                    for (int b = p.gray_bits - 1; b >= 0; b--) {
+                        const uint32_t wa = *reinterpret_cast<const uint32_t *>(p.gray[2 * b] + gset + voff);
+                        const uint32_t wb = *reinterpret_cast<const uint32_t *>(p.gray[2 * b + 1] + gset + voff);
+#pragma unroll
+                        for (int j = 0; j < SLX_QUAD; j++)
+                            code[j] = code[j] + code[j] + (ibyte(wa, j) > ibyte(wb, j) ? 1u : 0u);
+                    }
                 }
-                const double Td = (double)p.period[0], Sd = (double)p.gray_stripe;
 #pragma unroll
                 for (int j = 0; j < SLX_QUAD; j++) {
-                    int bin;
                     if (p.std_gray) {                                   // inverse reflected Gray code: prefix xor
                         unsigned g = code[j];
                         g ^= g >> 1;
                         g ^= g >> 2;
                         g ^= g >> 4;
                         g ^= g >> 8;
-                        bin = (int)g;
+                        bin[j] = (int)g;
                     } else {
-                        bin = (int)p.lut[code[j]];
+                        bin[j] = (int)p.lut[code[j]];
                     }
-                    const double grayv = (double)bin * Sd;
+                }
+            }
+            if constexpr (MODE == SLX_MODE_GRAY_PHASE) {
+                const double Td = (double)p.period[0], Sd = (double)p.gray_stripe;
+#pragma unroll
+                for (int j = 0; j < SLX_QUAD; j++) {
+                    const double grayv = (double)bin[j] * Sd;
                     const double phaseVal = (double)pix[0][j];
                     double ph = phaseVal;
-                    if ((bin & 1) == 0) {
+                    if ((bin[j] & 1) == 0) {
                         if (phaseVal > Td * 0.75) ph = phaseVal - Td;
                     } else {
                         if (phaseVal < Td * 0.25) ph = phaseVal + Td;
@@ -649,6 +687,14 @@ __global__ __launch_bounds__(256) void slx_strip_kernel(const SlxKParams p)
                         Uf = unwrap_stage<true>(Uf, (double)pix[f][j], p.period[f], p.inv_period[f], hb[f], k);
                     }
                     U[j] = Uf;
+                }
+            }
+            if constexpr (MASKED) {                                     // x3, stripe agreement of this lane's pixels
+                const double Sd = (double)p.gray_stripe;
+#pragma unroll
+                for (int j = 0; j < SLX_QUAD; j++) {
+                    const bool ok = __builtin_fabs(U[j] - ((double)bin[j] * Sd + Sd * 0.5)) <= Sd;
+                    v0[j] = (!lane_valid || ok) ? 1 : 0;
                 }
             }
 
@@ -669,9 +715,30 @@ __global__ __launch_bounds__(256) void slx_strip_kernel(const SlxKParams p)
         } else if (i + 2 < RB) {
             issue_row(slot, i + 2);                                     // keeps the DMA count per step fixed
         }
-        // stage this row's depth; it is stored (slot order) at the top of the next step
-        stage[2 * lane + 0] = vec2{z[0], z[1]};
-        stage[2 * lane + 1] = vec2{z[2], z[3]};
+        if constexpr (MASKED) {
+            // x3: 3-tap horizontal AND.  Pixel u0-1 lives in lane-1, pixel u0+4 in lane+1 (DPP wave shifts; every
+            // lane is active here); lanes 0 and 63 are the halo quads and store nothing.
+            const int left = __builtin_amdgcn_update_dpp(1, v0[SLX_QUAD - 1], 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+            const int right = __builtin_amdgcn_update_dpp(1, v0[0], 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
+            const int u0 = (int)(pos.cq * SLX_QUAD);
+#pragma unroll
+            for (int j = 0; j < SLX_QUAD; j++) {
+                int ok = v0[j];
+                const int l = j == 0 ? left : v0[j > 0 ? j - 1 : 0];
+                const int r = j == SLX_QUAD - 1 ? right : v0[j < SLX_QUAD - 1 ? j + 1 : 0];
+                if (u0 + j > 0) ok &= l;
+                if (u0 + j + 1 < (int)W) ok &= r;
+                if (!ok) z[j] = 0.0;
+            }
+            if (lane >= 1u && lane <= 62u) {
+                stage[2 * (lane - 1u) + 0] = vec2{z[0], z[1]};
+                stage[2 * (lane - 1u) + 1] = vec2{z[2], z[3]};
+            }
+        } else {
+            // stage this row's depth; it is stored (slot order) at the top of the next step
+            stage[2 * lane + 0] = vec2{z[0], z[1]};
+            stage[2 * lane + 1] = vec2{z[2], z[3]};
+        }
         __builtin_amdgcn_wave_barrier();
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -781,14 +848,14 @@ kernel_fn pick(int mode, int F, bool n4, bool aux)
     return nullptr;
 }
 
-template <int MODE>
+template <int MODE, int GB>
 kernel_fn pick_strip(int F)
 {
     switch (F) {
-    case 1: return slx_strip_kernel<MODE, 1>;
-    case 2: return slx_strip_kernel<MODE, 2>;
-    case 3: return slx_strip_kernel<MODE, 3>;
-    case 4: return slx_strip_kernel<MODE, 4>;
+    case 1: return slx_strip_kernel<MODE, 1, GB>;
+    case 2: return slx_strip_kernel<MODE, 2, GB>;
+    case 3: return slx_strip_kernel<MODE, 3, GB>;
+    case 4: return slx_strip_kernel<MODE, 4, GB>;
     }
     return nullptr;
 }
@@ -831,7 +898,7 @@ bool slx_fast_arith_ok(const SlxKParams &kp)
 bool slx_strip_eligible(const SlxKParams &kp, int mode, bool aux)
 {
     if (aux || !kp.aligned || kp.n_steps != 4) return false;
-    if (mode != SLX_MODE_MULTIFREQ && mode != SLX_MODE_GRAY_PHASE) return false;
+    if (mode != SLX_MODE_MULTIFREQ && mode != SLX_MODE_GRAY_PHASE && mode != SLX_MODE_MULTIFREQ_GRAYMASK) return false;
     if (kp.quads_per_row == 0 || kp.quads_per_row > 1024) return false;
     if (!slx_fast_arith_ok(kp)) return false;
     if ((unsigned long long)kp.row_stride * (unsigned)kp.height >= (1ull << 31)) return false;   // 32-bit plane offsets
@@ -892,7 +959,8 @@ int slx_launch_fused(const SlxKParams &kp_in, int mode, bool aux, int n_sets, in
     unsigned g = QR, h = 64;
     while (h) { const unsigned r = g % h; g = h; h = r; }          // gcd(QR, 64)
     kp.interleave = 64u / g;
-    kp.chunks_per_group = kp.interleave * QR / 64u;
+    kp.chunks_per_group = mode == SLX_MODE_MULTIFREQ_GRAYMASK ? (kp.interleave * QR + 61u) / 62u   // 62 quads + 2 halo lanes per wave
+                                                             : kp.interleave * QR / 64u;
     // rows per item: 16 amortises the item start-up (locate, column constants, ring fill: ~2 % of 16 rows);
     // smaller launches take smaller items so that the chip still sees ~3 waves per wave slot
     unsigned rb = 16;
@@ -914,17 +982,44 @@ int slx_launch_fused(const SlxKParams &kp_in, int mode, bool aux, int n_sets, in
     const unsigned groups = ((unsigned)kp.height + rows_group - 1) / rows_group;
     kp.items_per_set = groups * kp.chunks_per_group;
     kp.total_items = (unsigned long long)kp.items_per_set * (unsigned)n_sets;
-    // LDS per wave: 2 rows of the fringe stack (n_freq * 4 planes * 256 B each) + 2 KiB of depth staging
-    const unsigned lds_wave = 2u * (unsigned)kp.n_freq * 4u * 256u + 2048u;
+    // Gray planes ride the DMA ring when there are 6 bits of them (the reference's and config 3's count) and every
+    // plane, in every frame-set of the launch, sits within 2 GiB above the lowest plane; otherwise the kernel reads
+    // them with ordinary loads
+    int gb = 0;
+    if (mode != SLX_MODE_MULTIFREQ && kp.gray_bits == 6 && !getenv("SLX_GRAY_PLAIN")) {
+        gb = 6;
+        const uint8_t *lo = kp.phase_base;
+        for (int k = 0; k < 12; k++) lo = kp.gray[k] < lo ? kp.gray[k] : lo;
+        const long long delta = (long long)kp.gray_set_stride - (long long)kp.phase_set_stride;
+        for (int k = 0; k < 12; k++) {
+            const long long rel = (long long)(kp.gray[k] - lo);
+            const long long hi = rel + delta * (long long)(n_sets - 1);
+            if (rel >= (1ll << 31) || hi < 0 || hi >= (1ll << 31)) gb = 0;
+        }
+        for (int k = 0; k < kp.n_freq * 4; k++)
+            if ((long long)(kp.phase[k] - lo) >= (1ll << 31)) gb = 0;
+        if (gb) {
+            kp.phase_base = lo;
+            for (int k = 0; k < kp.n_freq * 4; k++) kp.phase_rel[k] = (unsigned)(kp.phase[k] - lo);
+            for (int k = 0; k < 12; k++) kp.gray_rel[k] = (unsigned)(kp.gray[k] - lo);
+            kp.gray_set_delta = delta;
+        }
+    }
+    // LDS per wave: 2 rows of the fringe stack ((4 n_freq + 2 gb) planes * 256 B each) + 2 KiB of depth staging
     unsigned waves_per_wg = 4u;
     if (const char *e = getenv("SLX_STRIP_WAVES")) {               // tuning hook
         const int v = atoi(e);
         if (v >= 1 && v <= 4) waves_per_wg = (unsigned)v;
     }
+    const unsigned lds_wave = 2u * ((unsigned)kp.n_freq * 4u + 2u * (unsigned)gb) * 256u + 2048u;
+    if (lds_wave * waves_per_wg > 32u * 1024u) waves_per_wg = 2u;       // keep >= 5 workgroups per CU
     const unsigned threads = waves_per_wg * 64u;
     const unsigned long long need_wgs = (kp.total_items + waves_per_wg - 1) / waves_per_wg;
     if (need_wgs == 0 || need_wgs >= (1ull << 31)) return (int)hipErrorInvalidValue;
-    kernel_fn fn = mode == SLX_MODE_MULTIFREQ ? pick_strip<SLX_MODE_MULTIFREQ>(kp.n_freq) : pick_strip<SLX_MODE_GRAY_PHASE>(1);
+    kernel_fn fn = mode == SLX_MODE_MULTIFREQ ? pick_strip<SLX_MODE_MULTIFREQ, 0>(kp.n_freq)
+                   : mode == SLX_MODE_MULTIFREQ_GRAYMASK
+                       ? (gb ? pick_strip<SLX_MODE_MULTIFREQ_GRAYMASK, 6>(kp.n_freq) : pick_strip<SLX_MODE_MULTIFREQ_GRAYMASK, 0>(kp.n_freq))
+                       : (gb ? pick_strip<SLX_MODE_GRAY_PHASE, 6>(1) : pick_strip<SLX_MODE_GRAY_PHASE, 0>(1));
     if (!fn) return (int)hipErrorInvalidValue;
     size_t lds = (size_t)waves_per_wg * lds_wave;
     if (const char *e = getenv("SLX_LDS_PAD")) lds += (size_t)atoi(e) * 1024u;   // experiments: lower the occupancy

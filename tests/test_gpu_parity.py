@@ -160,21 +160,28 @@ def test_random_bytes_all_outputs(api, oracle, synth, name, shape, variant):
     assert_same(got, ref, want)
 
 
-def test_mask_halo_crosses_wave_boundaries(api, oracle, synth):
-    """x3's 3-tap AND: invalid pixels planted on every quad / wave seam of a wide row."""
+@pytest.mark.parametrize("variant", [1, 2])
+def test_mask_halo_crosses_wave_boundaries(api, oracle, synth, variant):
+    """x3's 3-tap AND: invalid pixels planted on every quad / wave seam of a wide row (generic kernel: shuffles,
+    62-quad waves; strip kernel: DPP wave shifts, 62-quad chunks of interleaved rows)."""
     spec = small_spec(synth, "C3", 1920, 6)
     ph, gr, _ = synth.render(spec, "tilted")
     rng = np.random.default_rng(3)
-    cols = sorted(set([0, 1, 3, 4, 5, 247, 248, 249, 250, 251, 252, 255, 256, 1916, 1917, 1918, 1919]
+    cols = sorted(set([0, 1, 3, 4, 5, 243, 244, 247, 248, 249, 250, 251, 252, 255, 256, 491, 492, 495, 496, 1916, 1917, 1918, 1919]
                       + [int(c) for c in rng.integers(0, 1920, 60)]))
     for r in range(6):
         for c in cols[r::3]:
             for b in range(6):
                 gr[2 * b, r, c], gr[2 * b + 1, r, c] = gr[2 * b + 1, r, c], gr[2 * b, r, c]
-    got = api.decode_frameset(spec, ph, gr, want=("mask", "z"))
     ref = oracle.pipeline(spec, ph, gr, want=("mask", "z"))
     assert ref["mask"].min() == 0 and ref["mask"].max() == 1
-    assert_same(got, ref, ("mask", "z"))
+    if variant == 1:
+        got = api.decode_frameset(spec, ph, gr, want=("mask", "z"), variant=variant)
+        assert_same(got, ref, ("mask", "z"))
+    else:
+        got = api.decode_frameset(spec, ph, gr, want=("z",), variant=variant)
+        assert_same(got, ref, ("z",))
+        assert np.all(got["z"][ref["mask"] == 0] == 0)
 
 
 # ------------------------------------------------------------------ kernel variants (fast paths)
@@ -245,8 +252,6 @@ def test_variants_full_size(api, oracle, synth, name, scene, variant):
     spec = synth.make_spec(name)
     ph, gr, _ = synth.render(spec, scene, seed=11, noise_sigma=3.0)
     ref = oracle.pipeline(spec, ph, gr, want=("z",), threads=8)
-    if variant == 2 and spec["mode"] not in (synth.MODE_MULTIFREQ, synth.MODE_GRAY_PHASE):
-        pytest.skip("the strip kernel covers the Gray-free and Gray+phase depth modes")
     got = api.decode_frameset(spec, ph, gr, want=("z",), variant=variant)
     assert_same(got, ref, ("z",))
 
@@ -256,10 +261,12 @@ def test_variants_full_size(api, oracle, synth, name, scene, variant):
 def test_strip_kernel_geometries(api, oracle, synth, variant, shape):
     """Row bands, partial last bands, one-quad-wide and 1024-quad-wide strips, Gray + phase and 4-frequency."""
     h, w = shape
-    for name in ("C1x4", "C5x4"):
+    for name in ("C1x4", "C5x4", "C3"):
         spec = small_spec(synth, "C5" if name == "C5x4" else name, w, h)
         spec["n_steps"] = 4
         ph, gr = synth.random_planes(spec, seed=h + w)
+        if gr is not None and w >= 8:
+            gr[:, :, : w // 2] = np.where(gr[:, :, : w // 2] > 127, 220, 20)
         ref = oracle.pipeline(spec, ph, gr, want=("z",))
         got = api.decode_frameset(spec, ph, gr, want=("z",), variant=variant)
         assert_same(got, ref, ("z",))
