@@ -21,6 +21,8 @@
  *        R/CCalculation.cpp:525-592, :666-785            -> slx_decode / slx_decode_batch
  *   CDecode*::GetResult, m_x/y/zMat, m_ProjectorU
  *        R/CDecodePhase.cpp:99, R/CCalculation.h:29-38    -> slx_get_output / slx_get_depth
+ *   cv::FileStorage (calibration) R/CCalculation.cpp:124  -> slx_read_calibration_yaml
+ *   cv::imread (CSensor)          R/CSensorV.cpp:111      -> slx_read_bmp_gray (+ slx::CSensor, csrc/sensor.hpp)
  *   CCalculation::Result          R/CCalculation.cpp:323  -> slx_get_point_cloud (+ slx::CCalculation::Result text writer)
  *   ~CCalculation / ReleaseSpace  R/CCalculation.cpp:30   -> slx_destroy
  *   ErrorHandling(msg)            R/GlobalFunction.cpp:3  -> int status + slx_last_error
@@ -170,6 +172,14 @@ int slx_debug_stamps(slx_ctx *ctx, unsigned long long *device_words, size_t n_wo
 
 /* Selects the kernel variant (0 = default); tuning / A-B benchmarking only. */
 int slx_set_variant(slx_ctx *ctx, int variant);
+
+/* ---- file formats of a DynaFrame data directory (host only, no GPU needed) ----
+ * 8-bit grey pixels of an uncompressed BMP (8-bit paletted or 24/32-bit colour, converted like
+ * imread(..., CV_LOAD_IMAGE_GRAYSCALE), R/CSensorV.cpp:111-114), top-down, dense.  pixels == NULL: only the size.
+ * SLX_ERR_UNAVAILABLE: missing or unsupported file. */
+int slx_read_bmp_gray(const char *path, uint8_t *pixels, size_t capacity, int *rows, int *cols);
+/* CamMat, ProMat, R, T of the cv::FileStorage YAML Init reads (R/CCalculation.cpp:124-132; format of R/Result.yml). */
+int slx_read_calibration_yaml(const char *path, double cam[9], double pro[9], double rot[9], double trans[3]);
 
 int slx_version(void);
 

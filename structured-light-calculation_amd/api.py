@@ -29,7 +29,7 @@ SYMBOLS = [
     "slx_validate_config", "slx_create", "slx_destroy", "slx_last_error", "slx_set_gray_lut",
     "slx_set_frame", "slx_decode", "slx_decode_batch", "slx_synchronize", "slx_get_output",
     "slx_get_depth", "slx_get_point_cloud", "slx_output_device_ptr", "slx_get_calibration", "slx_enable_timing",
-    "slx_last_decode_ms", "slx_debug_stamps", "slx_set_variant", "slx_version",
+    "slx_last_decode_ms", "slx_debug_stamps", "slx_set_variant", "slx_read_bmp_gray", "slx_read_calibration_yaml", "slx_version",
 ]
 
 
@@ -83,6 +83,8 @@ def lib():
         L.slx_last_decode_ms.argtypes = [vp, C.POINTER(C.c_float)]
         L.slx_set_variant.argtypes = [vp, C.c_int]
         L.slx_debug_stamps.argtypes = [vp, vp, sz]
+        L.slx_read_bmp_gray.argtypes = [C.c_char_p, vp, sz, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.slx_read_calibration_yaml.argtypes = [C.c_char_p] + [C.POINTER(C.c_double)] * 4
         for name in SYMBOLS:
             if name not in ("slx_destroy", "slx_last_error"):
                 getattr(L, name).restype = C.c_int
@@ -271,6 +273,28 @@ class Context:
 
 
 VARIANT_AUTO, VARIANT_GENERIC, VARIANT_STRIP, VARIANT_GENERIC_FAST = range(4)
+
+
+def read_bmp_gray(path):
+    """uint8 [rows, cols] of an uncompressed BMP, converted like imread(..., CV_LOAD_IMAGE_GRAYSCALE)."""
+    r, c = C.c_int(), C.c_int()
+    rc = lib().slx_read_bmp_gray(path.encode(), None, 0, C.byref(r), C.byref(c))
+    if rc != OK:
+        raise SlxError(rc, "cannot read %s" % path)
+    a = np.empty((r.value, c.value), dtype=np.uint8)
+    rc = lib().slx_read_bmp_gray(path.encode(), a.ctypes.data, a.size, C.byref(r), C.byref(c))
+    if rc != OK:
+        raise SlxError(rc, "cannot read %s" % path)
+    return a
+
+
+def read_calibration_yaml(path):
+    """{'cam','pro','rot','trans'} from the cv::FileStorage YAML CCalculation::Init reads."""
+    bufs = [(C.c_double * n)() for n in (9, 9, 9, 3)]
+    rc = lib().slx_read_calibration_yaml(path.encode(), *bufs)
+    if rc != OK:
+        raise SlxError(rc, "cannot read %s" % path)
+    return {k: list(b) for k, b in zip(("cam", "pro", "rot", "trans"), bufs)}
 
 
 def decode_frameset(spec, phase=None, gray=None, want=("z",), device=-1, variant=0):

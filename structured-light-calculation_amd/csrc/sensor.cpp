@@ -1,0 +1,227 @@
+// sensor.cpp -- see sensor.hpp.  Host-only file I/O; nothing here touches the GPU.
+#include "sensor.hpp"
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <sstream>
+
+namespace slx {
+
+namespace {
+
+uint32_t rd32(const unsigned char *p) { return (uint32_t)p[0] | (uint32_t)p[1] << 8 | (uint32_t)p[2] << 16 | (uint32_t)p[3] << 24; }
+uint16_t rd16(const unsigned char *p) { return (uint16_t)(p[0] | p[1] << 8); }
+
+// cv::cvtColor BGR2GRAY of OpenCV 2.4 (8-bit): yuv_shift = 14, B2Y = 1868, G2Y = 9617, R2Y = 4899
+inline uint8_t luma(unsigned b, unsigned g, unsigned r) { return (uint8_t)((b * 1868u + g * 9617u + r * 4899u + (1u << 13)) >> 14); }
+
+}  // namespace
+
+bool ReadBmpGray(const std::string &path, std::vector<uint8_t> &pixels, int &rows, int &cols)
+{
+    std::ifstream f(path.c_str(), std::ios::in | std::ios::binary);
+    if (!f) return false;
+    std::vector<unsigned char> buf((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+    if (buf.size() < 54 || buf[0] != 'B' || buf[1] != 'M') return false;
+    const uint32_t data_off = rd32(&buf[10]), hdr = rd32(&buf[14]);
+    if (hdr < 40) return false;
+    const int32_t w = (int32_t)rd32(&buf[18]);
+    int32_t h = (int32_t)rd32(&buf[22]);
+    const uint16_t bpp = rd16(&buf[28]);
+    const uint32_t comp = rd32(&buf[30]);
+    if (w <= 0 || h == 0 || comp != 0) return false;
+    const bool top_down = h < 0;
+    if (top_down) h = -h;
+    if (bpp != 8 && bpp != 24 && bpp != 32) return false;
+    const size_t row_bytes = (((size_t)w * bpp + 31) / 32) * 4;
+    if ((size_t)data_off + row_bytes * (size_t)h > buf.size()) return false;
+    uint8_t pal[256];
+    if (bpp == 8) {
+        uint32_t n_col = rd32(&buf[46]);
+        if (n_col == 0 || n_col > 256) n_col = 256;
+        const size_t pal_off = 14 + (size_t)hdr;
+        if (pal_off + 4 * (size_t)n_col > buf.size()) return false;
+        for (uint32_t i = 0; i < 256; i++) {
+            if (i < n_col) {
+                const unsigned char *e = &buf[pal_off + 4 * i];
+                pal[i] = (e[0] == e[1] && e[1] == e[2]) ? e[0] : luma(e[0], e[1], e[2]);
+            } else {
+                pal[i] = 0;
+            }
+        }
+    }
+    rows = h;
+    cols = w;
+    pixels.resize((size_t)w * (size_t)h);
+    for (int y = 0; y < h; y++) {
+        const unsigned char *src = &buf[data_off + row_bytes * (size_t)(top_down ? y : h - 1 - y)];
+        uint8_t *dst = &pixels[(size_t)y * (size_t)w];
+        if (bpp == 8) {
+            for (int x = 0; x < w; x++) dst[x] = pal[src[x]];
+        } else {
+            const int step = bpp / 8;
+            for (int x = 0; x < w; x++) dst[x] = luma(src[x * step], src[x * step + 1], src[x * step + 2]);
+        }
+    }
+    return true;
+}
+
+bool ReadCalibrationYaml(const std::string &path, Calibration &calib)
+{
+    std::ifstream f(path.c_str());
+    if (!f) return false;
+    std::stringstream ss;
+    ss << f.rdbuf();
+    const std::string text = ss.str();
+    struct Want { const char *key; double *dst; int n; } wants[] = {
+        {"CamMat", calib.CamMat, 9}, {"ProMat", calib.ProMat, 9}, {"R", calib.R, 9}, {"T", calib.T, 3}};
+    for (const Want &w : wants) {
+        // a top-level key starts a line: "<key>: !!opencv-matrix"
+        size_t pos = std::string::npos, from = 0;
+        const std::string key = std::string(w.key) + ":";
+        while ((from = text.find(key, from)) != std::string::npos) {
+            if (from == 0 || text[from - 1] == '\n') { pos = from; break; }
+            from += key.size();
+        }
+        if (pos == std::string::npos) return false;
+        const size_t d = text.find("data:", pos);
+        const size_t lb = d == std::string::npos ? d : text.find('[', d);
+        const size_t rb = lb == std::string::npos ? lb : text.find(']', lb);
+        if (rb == std::string::npos) return false;
+        std::string list = text.substr(lb + 1, rb - lb - 1);
+        for (char &c : list)
+            if (c == ',' || c == '\n' || c == '\r') c = ' ';
+        std::stringstream ls(list);
+        std::string tok;
+        int n = 0;
+        while (ls >> tok) {
+            if (n >= w.n) return false;
+            char *end = nullptr;
+            const double v = std::strtod(tok.c_str(), &end);      // "0." and "1.2e+003" both parse
+            if (end == tok.c_str()) return false;
+            w.dst[n++] = v;
+        }
+        if (n != w.n) return false;
+    }
+    return true;
+}
+
+CSensor::CSensor(const StaticParameters &sp, int dynaFrameMaxNum) : m_sp(sp), m_dynaMax(dynaFrameMaxNum) {}
+CSensor::~CSensor() {}
+
+bool CSensor::InitSensor(const std::string &groupDataPath)
+{
+    m_groupDataPath = groupDataPath;
+    if (!m_groupDataPath.empty() && m_groupDataPath[m_groupDataPath.size() - 1] != '/') m_groupDataPath += '/';
+    m_iFramePath = "iFrame/";
+    m_cFramePath = "cFrame/";
+    m_vGrayName = "vGrayCam";
+    m_vPhaseName = "vPhaseCam";
+    m_dynaName = "dynaCam";
+    m_dataFileSuffix = ".bmp";
+    return true;
+}
+
+bool CSensor::CloseSensor() { return UnloadDatas(); }
+
+bool CSensor::UnloadDatas()
+{
+    m_dataMats.clear();
+    m_rows.clear();
+    m_cols.clear();
+    m_dataNum = 0;
+    m_nowNum = 0;
+    return true;
+}
+
+bool CSensor::LoadDatas(int groupNum)
+{
+    if (!m_dataMats.empty()) UnloadDatas();
+    std::string filePath, fileName;
+    int n = 0;
+    if (groupNum == 0) {
+        n = m_sp.GRAY_V_NUMDIGIT * 2;
+        filePath = m_groupDataPath + m_iFramePath;
+        fileName = m_vGrayName;
+    } else if (groupNum == 1) {
+        n = m_sp.PHASE_NUMDIGIT;
+        filePath = m_groupDataPath + m_iFramePath;
+        fileName = m_vPhaseName;
+    } else if (groupNum == 2) {
+        n = m_dynaMax;
+        filePath = m_groupDataPath + m_cFramePath;
+        fileName = m_dynaName;
+    } else {
+        return false;
+    }
+    m_dataMats.resize((size_t)n);
+    m_rows.assign((size_t)n, 0);
+    m_cols.assign((size_t)n, 0);
+    bool ok = true;
+    for (int i = 0; i < n; i++) {
+        std::ostringstream name;
+        name << filePath << fileName << i << m_dataFileSuffix;
+        if (!ReadBmpGray(name.str(), m_dataMats[(size_t)i], m_rows[(size_t)i], m_cols[(size_t)i])) {
+            // the reference reports and carries on with an empty Mat (R/CSensorV.cpp:122-129); here the load fails
+            m_err = "CSensor::LoadPatterns::<Read>, imread error: " + name.str();
+            ok = false;
+        }
+    }
+    m_dataNum = n;
+    m_nowNum = 0;
+    return ok;
+}
+
+bool CSensor::SetProPicture(int nowNum)
+{
+    if (nowNum < 0 || nowNum >= m_dataNum) return false;
+    m_nowNum = nowNum;
+    return true;
+}
+
+Image8 CSensor::GetCamPicture() const
+{
+    Image8 im;
+    if (m_nowNum < 0 || (size_t)m_nowNum >= m_dataMats.size() || m_dataMats[(size_t)m_nowNum].empty()) return im;
+    im.data = m_dataMats[(size_t)m_nowNum].data();
+    im.rows = m_rows[(size_t)m_nowNum];
+    im.cols = m_cols[(size_t)m_nowNum];
+    im.step = (size_t)im.cols;
+    im.on_device = false;
+    return im;
+}
+
+}  // namespace slx
+
+// ---- plain-C access to the two file readers (declared in include/slx.h) ----
+extern "C" {
+
+int slx_read_bmp_gray(const char *path, uint8_t *pixels, size_t capacity, int *rows, int *cols)
+{
+    if (!path || !rows || !cols) return SLX_ERR_INVALID_ARG;
+    std::vector<uint8_t> px;
+    int r = 0, c = 0;
+    if (!slx::ReadBmpGray(path, px, r, c)) return SLX_ERR_UNAVAILABLE;
+    *rows = r;
+    *cols = c;
+    if (!pixels) return SLX_OK;                                   // size query
+    if (capacity < px.size()) return SLX_ERR_INVALID_ARG;
+    std::memcpy(pixels, px.data(), px.size());
+    return SLX_OK;
+}
+
+int slx_read_calibration_yaml(const char *path, double cam[9], double pro[9], double rot[9], double trans[3])
+{
+    if (!path || !cam || !pro || !rot || !trans) return SLX_ERR_INVALID_ARG;
+    slx::Calibration c;
+    if (!slx::ReadCalibrationYaml(path, c)) return SLX_ERR_UNAVAILABLE;
+    std::memcpy(cam, c.CamMat, sizeof c.CamMat);
+    std::memcpy(pro, c.ProMat, sizeof c.ProMat);
+    std::memcpy(rot, c.R, sizeof c.R);
+    std::memcpy(trans, c.T, sizeof c.T);
+    return SLX_OK;
+}
+
+}  // extern "C"

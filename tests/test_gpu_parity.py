@@ -507,3 +507,35 @@ def test_cpp_host_loop(tmp_path, oracle, synth, golden_dir):
     for i, w in enumerate(("gray", "pix", "z", "x", "y", "U")):
         r = ref[w][0] if w == "pix" else ref[w]
         assert np.array_equal(out[i], r, equal_nan=True), w
+
+
+def test_cpp_data_directory(tmp_path, oracle, synth, golden_dir):
+    """The reference's main() over a DynaFrame data directory: parameters.yml, iFrame/v{Gray,Phase}Cam<i>.bmp,
+    Patterns/vGrayCode.txt in, PointCloud/iFrame.txt out (tests/cpp/dynaframe_data_dir.cpp)."""
+    import subprocess
+    from conftest import ROOT
+    from dynaframe_files import write_bmp, write_calibration_yaml
+    exe = os.path.join(ROOT, "tests", "cpp", "dynaframe_data_dir")
+    assert os.path.exists(exe), "run __graft_entry__.build() first"
+    W, H, PW = 256, 130, 1280
+    spec = small_spec(synth, "C1x4", W, H)
+    ph, gr, _ = synth.render(spec, "sphere", seed=5, noise_sigma=2.0)
+    d = str(tmp_path)
+    for sub in ("g/iFrame", "Patterns", "PointCloud"):
+        os.makedirs(os.path.join(d, sub))
+    cal = spec["calib"]
+    write_calibration_yaml(os.path.join(d, "parameters.yml"), cal["cam"], cal["pro"], cal["rot"], cal["trans"])
+    rows = json.load(open(os.path.join(golden_dir, "vGrayCode_rows.json")))["rows"]
+    with open(os.path.join(d, "Patterns", "vGrayCode.txt"), "w") as f:
+        f.write("\n".join("%d %d" % (b, g) for b, g in rows) + "\n")
+    for i in range(12):
+        write_bmp(os.path.join(d, "g/iFrame/vGrayCam%d.bmp" % i), gr[i], bits=8 if i % 2 else 24, top_down=bool(i % 3 == 0))
+    for i in range(4):
+        write_bmp(os.path.join(d, "g/iFrame/vPhaseCam%d.bmp" % i), ph[i], bits=8)
+    out = subprocess.check_output([exe, d, "g", str(PW), str(spec["fov_min"]), str(spec["fov_max"])]).decode()
+    assert out.startswith("ok %d x %d" % (W, H))
+    ref = oracle.pipeline(spec, ph, gr, want=("z",))
+    z = np.fromfile(os.path.join(d, "z.bin"), dtype=np.float64).reshape(H, W)
+    assert np.array_equal(z, ref["z"], equal_nan=True)
+    pts = oracle.point_cloud(spec, ref["z"])
+    assert open(os.path.join(d, "PointCloud", "iFrame.txt")).read() == "".join("%g %g %g\n" % tuple(p) for p in pts)

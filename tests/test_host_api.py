@@ -148,3 +148,60 @@ def test_synthetic_source_is_deterministic(synth):
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
     assert a[0].shape == (12, 48, 64) and a[1].shape == (12, 48, 64)
     assert a[0].dtype == np.uint8
+
+
+# ---------------------------------------------------------------- file formats of a data directory
+def test_bmp_reader(api, tmp_path):
+    from dynaframe_files import write_bmp
+    rng = np.random.default_rng(3)
+    for w, h in ((7, 5), (64, 48), (1, 1), (130, 3)):            # widths that need row padding included
+        img = rng.integers(0, 256, size=(h, w), dtype=np.uint8)
+        for bits, top_down in ((8, False), (8, True), (24, False), (24, True)):
+            path = str(tmp_path / ("a_%d_%d_%d_%d.bmp" % (w, h, bits, top_down)))
+            write_bmp(path, img, bits=bits, top_down=top_down)
+            assert np.array_equal(api.read_bmp_gray(path), img), (w, h, bits, top_down)
+    # a palette that is not the identity: pixel values are indices (cv::imread goes through the palette)
+    pal = np.arange(256, dtype=np.uint8)[::-1].copy()
+    img = rng.integers(0, 256, size=(9, 11), dtype=np.uint8)
+    write_bmp(str(tmp_path / "p.bmp"), img, palette=pal)
+    assert np.array_equal(api.read_bmp_gray(str(tmp_path / "p.bmp")), pal[img])
+    with pytest.raises(api.SlxError):
+        api.read_bmp_gray(str(tmp_path / "missing.bmp"))
+    (tmp_path / "junk.bmp").write_bytes(b"BM" + b"\0" * 10)
+    with pytest.raises(api.SlxError):
+        api.read_bmp_gray(str(tmp_path / "junk.bmp"))
+
+
+def test_bmp_colour_to_grey_matches_opencv_formula(api, tmp_path):
+    import struct
+    rng = np.random.default_rng(4)
+    h, w = 6, 10
+    bgr = rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8)
+    row = (3 * w + 3) // 4 * 4
+    body = np.zeros((h, row), dtype=np.uint8)
+    body[:, : 3 * w] = bgr.reshape(h, 3 * w)
+    path = str(tmp_path / "c.bmp")
+    with open(path, "wb") as f:
+        f.write(b"BM" + struct.pack("<IHHI", 54 + body.size, 0, 0, 54))
+        f.write(struct.pack("<IiiHHIIiiII", 40, w, -h, 1, 24, 0, body.size, 2835, 2835, 0, 0))
+        f.write(body.tobytes())
+    b, g, r = (bgr[..., i].astype(np.uint32) for i in range(3))
+    want = ((b * 1868 + g * 9617 + r * 4899 + 8192) >> 14).astype(np.uint8)     # OpenCV 2.4 BGR2GRAY, 8-bit
+    assert np.array_equal(api.read_bmp_gray(path), want)
+
+
+def test_calibration_yaml_reader(api, synth, tmp_path, golden_dir):
+    import json
+    from dynaframe_files import write_calibration_yaml
+    yml = json.load(open(os.path.join(golden_dir, "result_yml.json")))
+    path = str(tmp_path / "parameters.yml")
+    write_calibration_yaml(path, yml["CamMat"], yml["ProMat"], yml["R"], yml["T"])
+    text = open(path).read()
+    assert text.startswith("%YAML:1.0") and "!!opencv-matrix" in text and "1.2138714552009253e+003" in text
+    got = api.read_calibration_yaml(path)
+    assert got["cam"] == yml["CamMat"] and got["pro"] == yml["ProMat"] and got["rot"] == yml["R"] and got["trans"] == yml["T"]
+    with pytest.raises(api.SlxError):
+        api.read_calibration_yaml(str(tmp_path / "none.yml"))
+    (tmp_path / "short.yml").write_text(text.replace("ProMat", "Other"))
+    with pytest.raises(api.SlxError):
+        api.read_calibration_yaml(str(tmp_path / "short.yml"))
