@@ -119,6 +119,46 @@ __device__ __forceinline__ float pix_tail_literal(float sinValue, float cosValue
     return pix;
 }
 
+// n/d for 0 <= n <= d, d in [2^-53, 2^12]: hipcc's f32 division (v_rcp_f32, one Newton step, two residual
+// corrections) without its range scaling and special-case fix-up, which are no-ops in this range.
+__device__ __forceinline__ float div_f32_inrange(float n, float d)
+{
+    float r = __builtin_amdgcn_rcpf(d);
+    r = __builtin_fmaf(__builtin_fmaf(-d, r, 1.0f), r, r);
+    float q = n * r;
+    q = __builtin_fmaf(__builtin_fmaf(-d, q, n), r, q);
+    return __builtin_fmaf(__builtin_fmaf(-d, q, n), r, q);
+}
+
+// a2 with the in-range division; |x|, |y| <= 2^11 (sums of at most 16 bytes times weights <= 1, scaled by 2/N).
+__device__ __forceinline__ float fast_atan2_deg_inrange(float y, float x)
+{
+    const float ax = __builtin_fabsf(x), ay = __builtin_fabsf(y);
+    const float mx = __builtin_fmaxf(ax, ay), mn = __builtin_fminf(ax, ay);
+    const float c = div_f32_inrange(mn, mx + kEps);                  // ax >= ay: ay/(ax+eps), else ax/(ay+eps)
+    const float cc = c * c;
+    float a = (((kP7 * cc + kP5) * cc + kP3) * cc + kP1) * c;
+    a = (ay > ax) ? 90.f - a : a;
+    a = (x < 0.f) ? 180.f - a : a;
+    a = (y < 0.f) ? 360.f - a : a;
+    return a;
+}
+
+// R/CDecodePhase.cpp:67-75 for arbitrary float sums (x1, N != 4), all in f32: the casts through double are exact
+// or round identically (the double product of a float and an integer < 2^24 is exact; the double sum with 0.5 is
+// either exact or rounds to the float the f32 add gives), and RN(x/360) comes from one residual correction
+// (x/360 is never within 1/90 ulp of a rounding tie).  The angle itself keeps the IEEE division of a2.
+__device__ __forceinline__ float pix_tail_f32(float sinValue, float cosValue, float Tf)
+{
+    const float x = fast_atan2_deg_inrange(sinValue, cosValue);
+    const float d0 = x * kInv360;
+    const float d = __builtin_fmaf(__builtin_fmaf(-360.f, d0, x), kInv360, d0);
+    float pix = d * Tf;
+    pix = pix + 0.5f;
+    pix = (pix > Tf) ? pix - Tf : pix;
+    return pix;
+}
+
 // IEEE-754 correctly rounded num/den without the range scaling and special-case fix-up of the
 // general f64 division: the same v_rcp_f64 + two Newton steps + residual correction hipcc emits,
 // so the quotient is bit-identical whenever no scaling would have happened.  Callers guarantee
@@ -502,12 +542,14 @@ __device__ __forceinline__ StripPos strip_locate(const SlxKParams &p, unsigned i
 
 // GB > 0: the 2*GB Gray planes ride the DMA ring behind the phase planes (GB = gray_bits, compile time because
 // s_waitcnt takes an immediate); GB == 0: Gray planes, if any, are read with ordinary loads inside the step.
-template <int MODE, int F, int GB>
+// NS: phase-shift steps, 4 (the reference's, planes through the DMA ring) or another compile-time count (x1:
+// the planes are read with ordinary loads, F * NS of them would not fit the ring at a useful occupancy).
+template <int MODE, int F, int GB, int NS>
 __global__ __launch_bounds__(256) void slx_strip_kernel(const SlxKParams p)
 {
     constexpr bool MASKED = MODE == SLX_MODE_MULTIFREQ_GRAYMASK;
     constexpr bool HAS_GRAY = MODE == SLX_MODE_GRAY_PHASE || MASKED;
-    constexpr int NPH = F * 4;                    // phase planes
+    constexpr int NPH = NS == 4 ? F * 4 : 0;      // phase planes in the ring
     constexpr int NP = NPH + 2 * GB;              // planes in the ring
     constexpr unsigned ROW_DW = NP * 64;          // one row of the fringe stack in LDS, dwords per wave
     typedef double vec2 __attribute__((ext_vector_type(2)));
@@ -610,8 +652,31 @@ __global__ __launch_bounds__(256) void slx_strip_kernel(const SlxKParams p)
         if (row < H) {
             const uint32_t *src = ring + slot * ROW_DW + lane;
             float pix[F][SLX_QUAD];
+            if constexpr (NS != 4) {                                    // x1: weighted sums, k ascending, no contraction
+                const size_t roff = pset + (size_t)(row * row_stride + pos.cq * SLX_QUAD);
 #pragma unroll
-            for (int f = 0; f < F; f++) {
+                for (int f = 0; f < F; f++) {
+                    float sy[SLX_QUAD], sx[SLX_QUAD];
+                    static_assert(NS == 8 || NS == 4, "the x1 fast path is written for 8 steps");
+                    // 8 steps: weights (cos, sin)(k pi/4) = (1,0) (r,r) (0,1) (-r,r) (-1,0) (-r,-r) (0,-1) (r,-r), r = wy[1]
+                    // (checked on the host).  Adding g*0 changes nothing and g*(+-1) is exact, so the k-ascending sums are
+                    //   sy = ((((g0 + m1) - m3) - g4) - m5) + m7,   sx = ((((m1 + g2) + m3) - m5) - g6) - m7,   m_k = RN(g_k r)
+                    uint32_t w[8];
+#pragma unroll
+                    for (int k = 0; k < 8; k++) w[k] = *reinterpret_cast<const uint32_t *>(p.phase[f * NS + k] + roff);
+                    const float r = p.wy[1];
+#pragma unroll
+                    for (int j = 0; j < SLX_QUAD; j++) {
+                        const float m1 = ubyte(w[1], j) * r, m3 = ubyte(w[3], j) * r, m5 = ubyte(w[5], j) * r, m7 = ubyte(w[7], j) * r;
+                        sy[j] = ((((ubyte(w[0], j) + m1) - m3) - ubyte(w[4], j)) - m5) + m7;
+                        sx[j] = ((((m1 + ubyte(w[2], j)) + m3) - m5) - ubyte(w[6], j)) - m7;
+                    }
+#pragma unroll
+                    for (int j = 0; j < SLX_QUAD; j++) pix[f][j] = pix_tail_f32(sy[j] * p.wscale, sx[j] * p.wscale, Tf[f]);
+                }
+            }
+#pragma unroll
+            for (int f = 0; f < (NS == 4 ? F : 0); f++) {
                 const uint32_t w0 = src[(f * 4 + 0) * 64], w1 = src[(f * 4 + 1) * 64];
                 const uint32_t w2 = src[(f * 4 + 2) * 64], w3 = src[(f * 4 + 3) * 64];
                 pix[f][0] = wrapped_pix_from_diffs((float)byte_diff<0>(w0, w2), (float)byte_diff<0>(w1, w3), Tf[f]);
@@ -848,14 +913,14 @@ kernel_fn pick(int mode, int F, bool n4, bool aux)
     return nullptr;
 }
 
-template <int MODE, int GB>
+template <int MODE, int GB, int NS = 4>
 kernel_fn pick_strip(int F)
 {
     switch (F) {
-    case 1: return slx_strip_kernel<MODE, 1, GB>;
-    case 2: return slx_strip_kernel<MODE, 2, GB>;
-    case 3: return slx_strip_kernel<MODE, 3, GB>;
-    case 4: return slx_strip_kernel<MODE, 4, GB>;
+    case 1: return slx_strip_kernel<MODE, 1, GB, NS>;
+    case 2: return slx_strip_kernel<MODE, 2, GB, NS>;
+    case 3: return slx_strip_kernel<MODE, 3, GB, NS>;
+    case 4: return slx_strip_kernel<MODE, 4, GB, NS>;
     }
     return nullptr;
 }
@@ -897,14 +962,22 @@ bool slx_fast_arith_ok(const SlxKParams &kp)
 
 bool slx_strip_eligible(const SlxKParams &kp, int mode, bool aux)
 {
-    if (aux || !kp.aligned || kp.n_steps != 4) return false;
+    if (aux || !kp.aligned) return false;
+    if (kp.n_steps != 4) {                                           // x1 fast path: 8 steps, Gray-free, the expected weight table
+        if (!(kp.n_steps == 8 && mode == SLX_MODE_MULTIFREQ)) return false;
+        const float r = kp.wy[1];
+        const float ey[8] = {1.f, r, 0.f, -r, -1.f, -r, 0.f, r}, ex[8] = {0.f, r, 1.f, r, 0.f, -r, -1.f, -r};
+        for (int k = 0; k < 8; k++)
+            if (kp.wy[k] != ey[k] || kp.wx[k] != ex[k]) return false;
+        if (!(r > 0.70f && r < 0.71f) || kp.wscale != 0.25f) return false;
+    }
     if (mode != SLX_MODE_MULTIFREQ && mode != SLX_MODE_GRAY_PHASE && mode != SLX_MODE_MULTIFREQ_GRAYMASK) return false;
     if (kp.quads_per_row == 0 || kp.quads_per_row > 1024) return false;
     if (!slx_fast_arith_ok(kp)) return false;
     if ((unsigned long long)kp.row_stride * (unsigned)kp.height >= (1ull << 31)) return false;   // 32-bit plane offsets
     {
         // every phase plane must sit within 2 GiB of the lowest one (32-bit buffer offsets)
-        const int np = kp.n_freq * 4;
+        const int np = kp.n_freq * kp.n_steps;
         uintptr_t lo = ~(uintptr_t)0, hi = 0;
         for (int k = 0; k < np; k++) {
             const uintptr_t a = reinterpret_cast<uintptr_t>(kp.phase[k]);
@@ -948,7 +1021,7 @@ int slx_launch_fused(const SlxKParams &kp_in, int mode, bool aux, int n_sets, in
     }
     SlxKParams kp = kp_in;
     {
-        const int np = kp.n_freq * 4;
+        const int np = kp.n_freq * kp.n_steps;
         const uint8_t *lo = kp.phase[0];
         for (int k = 1; k < np; k++) lo = kp.phase[k] < lo ? kp.phase[k] : lo;
         kp.phase_base = lo;
@@ -1011,12 +1084,12 @@ int slx_launch_fused(const SlxKParams &kp_in, int mode, bool aux, int n_sets, in
         const int v = atoi(e);
         if (v >= 1 && v <= 4) waves_per_wg = (unsigned)v;
     }
-    const unsigned lds_wave = 2u * ((unsigned)kp.n_freq * 4u + 2u * (unsigned)gb) * 256u + 2048u;
+    const unsigned lds_wave = 2u * ((kp.n_steps == 4 ? (unsigned)kp.n_freq * 4u : 0u) + 2u * (unsigned)gb) * 256u + 2048u;
     if (lds_wave * waves_per_wg > 32u * 1024u) waves_per_wg = 2u;       // keep >= 5 workgroups per CU
     const unsigned threads = waves_per_wg * 64u;
     const unsigned long long need_wgs = (kp.total_items + waves_per_wg - 1) / waves_per_wg;
     if (need_wgs == 0 || need_wgs >= (1ull << 31)) return (int)hipErrorInvalidValue;
-    kernel_fn fn = mode == SLX_MODE_MULTIFREQ ? pick_strip<SLX_MODE_MULTIFREQ, 0>(kp.n_freq)
+    kernel_fn fn = mode == SLX_MODE_MULTIFREQ ? (kp.n_steps == 8 ? pick_strip<SLX_MODE_MULTIFREQ, 0, 8>(kp.n_freq) : pick_strip<SLX_MODE_MULTIFREQ, 0>(kp.n_freq))
                    : mode == SLX_MODE_MULTIFREQ_GRAYMASK
                        ? (gb ? pick_strip<SLX_MODE_MULTIFREQ_GRAYMASK, 6>(kp.n_freq) : pick_strip<SLX_MODE_MULTIFREQ_GRAYMASK, 0>(kp.n_freq))
                        : (gb ? pick_strip<SLX_MODE_GRAY_PHASE, 6>(1) : pick_strip<SLX_MODE_GRAY_PHASE, 0>(1));

@@ -136,12 +136,16 @@ def test_baseline_configs_full_size(api, oracle, synth, name, scene):
 
 
 def test_baseline_config_c5(api, oracle, synth):
-    """4096 x 3000, 4-frequency x 8-step, tolerance 1e-5 mm RMS (bit-exact in fact)."""
+    """4096 x 3000, 4-frequency x 8-step, tolerance 1e-5 mm RMS (bit-exact in fact): the generic kernel with every
+    output, then the depth of the literal-arithmetic kernel and of the 8-step strip kernel."""
     spec = synth.make_spec("C5")
     ph, _, _ = synth.render(spec, "tilted", seed=0x5EED + 5, noise_sigma=1.0)
-    got = api.decode_frameset(spec, ph, None, want=("z", "k", "U"))
     ref = oracle.pipeline(spec, ph, None, want=("z", "k", "U"), threads=8)
+    got = api.decode_frameset(spec, ph, None, want=("z", "k", "U"))
     assert_same(got, ref, ("z", "k", "U"), RMS_TOL_MM_C5)
+    for variant in (api.VARIANT_GENERIC, api.VARIANT_STRIP):
+        got = api.decode_frameset(spec, ph, None, want=("z",), variant=variant)
+        assert_same(got, ref, ("z",), RMS_TOL_MM_C5)
 
 
 # ------------------------------------------------------------------ unstructured inputs, every branch
@@ -261,9 +265,10 @@ def test_variants_full_size(api, oracle, synth, name, scene, variant):
 def test_strip_kernel_geometries(api, oracle, synth, variant, shape):
     """Row bands, partial last bands, one-quad-wide and 1024-quad-wide strips, Gray + phase and 4-frequency."""
     h, w = shape
-    for name in ("C1x4", "C5x4", "C3"):
+    for name in ("C1x4", "C5x4", "C3", "C5"):
         spec = small_spec(synth, "C5" if name == "C5x4" else name, w, h)
-        spec["n_steps"] = 4
+        if name != "C5":
+            spec["n_steps"] = 4                                        # "C5": the 8-step x1 fast path
         ph, gr = synth.random_planes(spec, seed=h + w)
         if gr is not None and w >= 8:
             gr[:, :, : w // 2] = np.where(gr[:, :, : w // 2] > 127, 220, 20)
