@@ -199,22 +199,27 @@ def main():
                 return shard.gather_depth(z, dst=0)
             torch.cuda.synchronize()
             return shard.gather_depth(z.cpu(), dst=0)            # rehearsal only
-        full = gather()
-        fence()
-        tg = time.perf_counter()
-        reps = max(3, min(20, args.steps // 15))
-        for _ in range(reps):
-            step()
+        gather_error = None
+        try:
             full = gather()
-        torch.cuda.synchronize()
-        tg_local = time.perf_counter() - tg
-        fence()
-        tt = torch.tensor([tg_local], dtype=torch.float64, device=coll_dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        gather = {"value": world * n_sets * reps / float(tt[0]), "unit": "frames/s", "steps": reps,
+            fence()
+            tg = time.perf_counter()
+            reps = max(3, min(20, args.steps // 15))
+            for _ in range(reps):
+                step()
+                full = gather()
+            torch.cuda.synchronize()
+            tg_local = time.perf_counter() - tg
+            fence()
+            tt = torch.tensor([tg_local], dtype=torch.float64, device=coll_dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        except Exception as e:      # the decode-only line above must still be reported
+            full, reps, tt = None, 0, None
+            gather_error = "%s: %s" % (type(e).__name__, e)
+        gather = {"error": gather_error} if tt is None else {"value": world * n_sets * reps / float(tt[0]), "unit": "frames/s", "steps": reps,
                   "collective": "torch.distributed.gather (%s) of f64 depth maps to rank 0" % ("RCCL" if args.backend == "nccl" else args.backend),
                   "gathered_bytes_per_step": int(world * n_sets * H * W * 8),
-                  "gathered_shape": list(full.shape) if rank == 0 else None}
+                  "gathered_shape": list(full.shape) if (rank == 0 and full is not None) else None}
 
     if rank == 0:
         cpu_single = cpu_multi = None
