@@ -129,7 +129,9 @@ int slx_set_frame(slx_ctx *ctx, int group, int idx, const uint8_t *data, size_t 
                   int mem_kind);
 
 /* One frame-set: every stage of the mode, fused, on `stream` (a hipStream_t, or NULL for the
- * context's own stream).  Asynchronous; outputs are read with slx_get_output. */
+ * context's own stream, which is non-blocking: it does not order itself against work the caller has
+ * queued on other streams, the legacy default stream included).  Asynchronous; outputs are read with
+ * slx_get_output. */
 int slx_decode(slx_ctx *ctx, void *stream);
 
 /* n_sets frame-sets resident in device memory, one launch.  Plane p of set s starts at

@@ -563,7 +563,16 @@ __global__ __launch_bounds__(256) void slx_strip_kernel(const SlxKParams p)
     const unsigned wave_in_wg = __builtin_amdgcn_readfirstlane(t >> 6);
     uint32_t *ring = lds_raw + wave_in_wg * (2u * ROW_DW + 512u);
     vec2 *stage = reinterpret_cast<vec2 *>(ring + 2u * ROW_DW);
-    const unsigned item = blockIdx.x * (blockDim.x >> 6) + wave_in_wg;
+    // XCD-aware item order: the dispatcher deals workgroups round-robin over the 8 XCDs (blocks b and b + 8 share
+    // an L2), so consecutive items go to ONE XCD: neighbouring chunks of the Gray-mask mode overlap by a halo quad
+    // and start at 248-byte multiples, and their shared 128-byte lines are then fetched from HBM once, not twice.
+    // Placement only affects speed; any dispatch order gives the same result.
+    unsigned wg = blockIdx.x;
+    if (p.dbg != 4) {                                               // SLX_DBG=4: plain order, for A/B measurements
+        const unsigned nb = gridDim.x, q = nb >> 3, r = nb & 7u, x = wg & 7u, within = wg >> 3;
+        wg = x * q + (x < r ? x : r) + within;
+    }
+    const unsigned item = wg * (blockDim.x >> 6) + wave_in_wg;
     if (item >= p.total_items) return;
     if (p.stamps && lane == 0 && item < 8192) {   // diagnostics only (slx_debug_stamps)
         p.stamps[4 * item + 0] = __builtin_amdgcn_s_memtime();

@@ -331,6 +331,7 @@ def test_device_frames_strides_and_batch(api, oracle, synth, torch_cuda):
         for s, (p, g) in enumerate(sets):
             ph[s, :, :, :W] = torch.from_numpy(p).cuda()
             gr[s, :, :, :W] = torch.from_numpy(g).cuda()
+        torch.cuda.synchronize()              # the context's stream does not order itself against torch's stream
         with api.Context(spec) as ctx:
             # borrowed device planes, one frame-set at a time
             for s in range(n_sets):
@@ -339,6 +340,7 @@ def test_device_frames_strides_and_batch(api, oracle, synth, torch_cuda):
                 assert np.array_equal(ctx.get_depth(), ref[s], equal_nan=True), (pitch, s)
             # one launch for the whole batch
             z = torch.full((n_sets, H, W), -1.0, dtype=torch.float64, device="cuda")
+            torch.cuda.synchronize()          # the context's stream does not order itself against torch's stream
             ctx.decode_batch(n_sets, ph, gr, z, row_stride=pitch)
             ctx.synchronize()
             torch.cuda.synchronize()
@@ -472,6 +474,7 @@ def test_full_size_batch_properties(api, oracle, synth, torch_cuda):
     for s in range(n_sets):
         batch[s] = d1 if s in odd else d0
     z = torch.empty((n_sets, H, W), dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()                  # the context's stream does not order itself against torch's stream
     with api.Context(spec) as ctx:
         ctx.decode_batch(n_sets, batch, None, z)
         ctx.synchronize()
@@ -481,6 +484,7 @@ def test_full_size_batch_properties(api, oracle, synth, torch_cuda):
             want = r1 if s in odd else r0
             assert torch.equal(torch.nan_to_num(z[s], nan=-7.0), torch.nan_to_num(want, nan=-7.0)), s
         z.fill_(-1.0)
+        torch.cuda.synchronize()              # or the fill could land after the decode
         ctx.decode_batch(n_sets, batch, None, z)
         ctx.synchronize()
         assert torch.equal(torch.nan_to_num(z, nan=-7.0), torch.nan_to_num(first, nan=-7.0))
