@@ -251,7 +251,7 @@ def main():
                        "periods": spec["periods"], "sharding": "by frame-set, no data-path collective", "kernel_variant": args.variant},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "kernel": ("slx_strip_kernel" if (args.variant in (0, 2) and n_gray == 0 and spec["n_steps"] == 4) else "slx_fused_kernel") + "<mode %d, F=%d>" % (spec["mode"], spec["n_freq"]), "launch_ms": kernel_ms_max,
+                         "kernel": ("slx_strip_kernel" if (args.variant in (0, 2) and ((spec["mode"] == 3 and spec["n_steps"] in (4, 8)) or (spec["mode"] in (2, 4) and spec["n_steps"] == 4))) else "slx_fused_kernel") + "<mode %d, F=%d, N=%d>" % (spec["mode"], spec["n_freq"], spec["n_steps"]), "launch_ms": kernel_ms_max,
                          "algorithmic_bytes_per_launch": bytes_per_launch},
             "achieved_hbm_gbps_per_gpu": achieved,
             "cpu_baseline": cpu_single, "cpu_baseline_all_cores": cpu_multi,
