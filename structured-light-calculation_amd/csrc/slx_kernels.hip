@@ -178,16 +178,17 @@ __device__ __forceinline__ double tri_depth(double Uv, double cC, double cD, dou
                                             double fov_min, double fov_max, bool valid)
 {
     const double num = cA - cB * Uv;
-    const double den = cC - cD * Uv;
     double zz;
     if constexpr (LEAN) {
-        // The host guarantees |num|, |den| < 2^111 (slx_strip_eligible) and num is 0 or >= one ulp of
-        // cA (no tiny non-zero numerators), so the unscaled sequence can only go wrong when den is
-        // zero or denormal -- and then it yields NaN, never a wrong finite value.  NaN -> general division.
-        zz = -div_f64_inrange(num, den);
-        if (__builtin_expect(zz != zz, 0)) zz = -num / den;
+        // -(num/den) == num/(-den), and -den = cD U - cC bit for bit when den != 0 (negation commutes with the
+        // rounding); this saves the sign flip of the quotient.  The host guarantees |num|, |den| < 2^111
+        // (slx_fast_arith_ok) and num is 0 or >= one ulp of cA, so the unscaled sequence can only go wrong when den is
+        // zero or denormal -- and then it yields NaN, never a wrong finite value.  NaN -> the literal expression.
+        const double nden = cD * Uv - cC;
+        zz = div_f64_inrange(num, nden);
+        if (__builtin_expect(zz != zz, 0)) zz = -num / (cC - cD * Uv);
     } else {
-        zz = -num / den;
+        zz = -num / (cC - cD * Uv);
     }
     if ((zz < fov_min) || (zz > fov_max)) zz = 0.0;
     if (Uv == 0.0 || !valid) zz = 0.0;
@@ -656,7 +657,11 @@ __global__ __launch_bounds__(256) void slx_strip_kernel(const SlxKParams p)
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (i > 0) flush_row(i - 1);                                    // last row's stores, one step late
 
-        double z[SLX_QUAD] = {0.0, 0.0, 0.0, 0.0};
+        double z[SLX_QUAD];
+        if constexpr (MASKED) {                                         // the mask pass below runs for every lane
+#pragma unroll
+            for (int j = 0; j < SLX_QUAD; j++) z[j] = 0.0;
+        }
         int v0[SLX_QUAD] = {1, 1, 1, 1};                                // x3: lanes without pixels never veto
         if (row < H) {
             const uint32_t *src = ring + slot * ROW_DW + lane;
@@ -786,6 +791,12 @@ __global__ __launch_bounds__(256) void slx_strip_kernel(const SlxKParams p)
                     z[j] = tri_depth<true>(U[j], cC, cD, p.cA, p.cB, p.fov_min, p.fov_max, true);
                 }
             }
+            if constexpr (!MASKED) {
+                // stage this row's depth; it is stored (slot order) at the top of the next step.  Rows past the
+                // tile stage nothing and are never stored.
+                stage[2 * lane + 0] = vec2{z[0], z[1]};
+                stage[2 * lane + 1] = vec2{z[2], z[3]};
+            }
         } else if (i + 2 < RB) {
             issue_row(slot, i + 2);                                     // keeps the DMA count per step fixed
         }
@@ -808,10 +819,6 @@ __global__ __launch_bounds__(256) void slx_strip_kernel(const SlxKParams p)
                 stage[2 * (lane - 1u) + 0] = vec2{z[0], z[1]};
                 stage[2 * (lane - 1u) + 1] = vec2{z[2], z[3]};
             }
-        } else {
-            // stage this row's depth; it is stored (slot order) at the top of the next step
-            stage[2 * lane + 0] = vec2{z[0], z[1]};
-            stage[2 * lane + 1] = vec2{z[2], z[3]};
         }
         __builtin_amdgcn_wave_barrier();
     }
