@@ -622,18 +622,24 @@ __global__ __launch_bounds__(256) void slx_strip_kernel(const SlxKParams p)
         for (int k = 0; k < 2 * GB; k++)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void *)(dst + (NPH + k) * 64), 4, voff, gray_soff[k], 0, 0);
     };
-    const unsigned out_step = step_rows * W;
-    unsigned out_off[2] = {pos.out_off[0], pos.out_off[1]};            // next row to store, per store slot
-    auto rows_left = [&](unsigned first) { return first < H ? (H - first + step_rows - 1) / step_rows : 0u; };
-    const unsigned out_end[2] = {pos.out_off[0] + rows_left(pos.out_row[0]) * out_step,
-                                 pos.out_off[1] + rows_left(pos.out_row[1]) * out_step};
+    // Depth stores: buffer stores against a descriptor of this frame-set's depth map -- one 32-bit byte offset per store
+    // slot that advances by a constant per row, and the hardware's range check drops the rows past the tile (and the
+    // slots that store nothing, whose offset stays out of range) without a compare.
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t zrsrc = __builtin_amdgcn_make_buffer_rsrc(zset, 0, H * W * 8u, 0x00020000);
+    unsigned out_boff[2], out_bstep[2];
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        const bool ok = pos.out_row[k] != 0xFFFFFFFFu && p.dbg != 1;
+        out_boff[k] = ok ? pos.out_off[k] * 8u : 0xFFFFFFF0u;
+        out_bstep[k] = ok ? step_rows * W * 8u : 0u;
+    }
     auto flush_row = [&](unsigned) {                                   // depth of the oldest unstored row, in store order
 #pragma unroll
         for (int k = 0; k < 2; k++) {
-            const vec2 v = stage[k * 64 + lane];
-            if (out_off[k] < out_end[k] && p.dbg != 1)                  // rows past the tile are not stored
-                __builtin_nontemporal_store(v, reinterpret_cast<vec2 *>(zset + out_off[k]));
-            out_off[k] += out_step;
+            const u32x4 v = *reinterpret_cast<const u32x4 *>(stage + k * 64 + lane);
+            __builtin_amdgcn_raw_buffer_store_b128(v, zrsrc, out_boff[k], 0, 2 /* nt */);
+            out_boff[k] += out_bstep[k];
         }
     };
 
@@ -1002,7 +1008,7 @@ bool slx_strip_eligible(const SlxKParams &kp, int mode, bool aux)
         }
         if (hi - lo >= (1ull << 31)) return false;
     }
-    if ((unsigned long long)kp.width * (unsigned)kp.height >= (1ull << 29)) return false;          // 32-bit output offsets
+    if ((unsigned long long)kp.width * ((unsigned)kp.height + 2048ull) >= (1ull << 29)) return false;   // 32-bit output byte offsets, rows past the tile included
     return true;
 }
 
