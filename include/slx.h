@@ -24,6 +24,7 @@
  *   cv::FileStorage (calibration) R/CCalculation.cpp:124  -> slx_read_calibration_yaml
  *   cv::imread (CSensor)          R/CSensorV.cpp:111      -> slx_read_bmp_gray (+ slx::CSensor, csrc/sensor.hpp)
  *   CCalculation::Result          R/CCalculation.cpp:323  -> slx_get_point_cloud (+ slx::CCalculation::Result text writer)
+ *   CCalculation::CalculateOther  R/CCalculation.cpp:208  -> slx_track_begin / slx_track_next (+ slx::CCalculation::CalculateOther)
  *   ~CCalculation / ReleaseSpace  R/CCalculation.cpp:30   -> slx_destroy
  *   ErrorHandling(msg)            R/GlobalFunction.cpp:3  -> int status + slx_last_error
  *                                                           (never prints, never blocks)
@@ -87,7 +88,12 @@ enum slx_output {
     SLX_OUT_GRAY = 5,  /* f64 [H][W]   Gray stripe left edge                        */
     SLX_OUT_K = 6,     /* i32 [F-1][H][W] fringe orders of the temporal unwrap      */
     SLX_OUT_MASK = 7,  /* u8  [H][W]   1 = valid                                    */
-    SLX_OUT_COUNT = 8
+    /* dynamic frames (slx_track_*), available after slx_track_begin: */
+    SLX_OUT_DELTAZ = 8,  /* f64 [H][W] z of this frame - z of the previous one (m_deltaZ)   */
+    SLX_OUT_DELTAP = 9,  /* f32 [H][W] projector-column increment after the 3x3 blur (m_deltaP) */
+    SLX_OUT_STRIPW = 10, /* f32 [H][W] offset of the brightest column sum (m_stripW)        */
+    SLX_OUT_STRIPB = 11, /* f32 [H][W] offset of the darkest column sum (m_stripB)          */
+    SLX_OUT_COUNT = 12
 };
 
 typedef struct slx_config {
@@ -155,6 +161,16 @@ int slx_get_depth(slx_ctx *ctx, double *z, int mem_kind);
  * xyz: room for `capacity_points` triples (host or device per mem_kind); *n_points receives the number of valid points
  * (also when it exceeds the capacity, in which case SLX_ERR_INVALID_ARG is returned and nothing is copied). */
 int slx_get_point_cloud(slx_ctx *ctx, double *xyz, size_t capacity_points, size_t *n_points, int mem_kind);
+
+/* Dynamic frames, CCalculation::CalculateOther (R/CCalculation.cpp:208-320).  The context must be a depth mode created
+ * with SLX_OUT_U in aux_outputs and hold a decoded frame 0.
+ * slx_track_begin = StripRegression(0) (R/CCalculation.cpp:203): column-sum extrema of the first dynamic camera image.
+ * slx_track_next  = StripRegression(fN) + FillOtherDeltaProU(fN) + FillCoordinate(fN) for the next camera image: updates
+ * SLX_OUT_U / Z (/ X / Y when enabled) in place and produces SLX_OUT_DELTAZ, DELTAP, STRIPW, STRIPB.  `window` is
+ * RECO_WINDOW_SIZE (21 in the reference; odd, 3..201).  Images: 8-bit, height x width, host (copied) or device (borrowed
+ * until the call's work has completed; slx_synchronize). */
+int slx_track_begin(slx_ctx *ctx, const uint8_t *image, size_t stride_bytes, int mem_kind, int window);
+int slx_track_next(slx_ctx *ctx, const uint8_t *image, size_t stride_bytes, int mem_kind);
 
 /* Device pointer of an output buffer owned by the context (valid until slx_destroy). */
 int slx_output_device_ptr(slx_ctx *ctx, int which, void **ptr);

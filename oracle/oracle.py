@@ -61,6 +61,8 @@ def lib():
         L.slxo_fast_atan2_deg.restype = C.c_float
         L.slxo_fast_atan2_deg.argtypes = [C.c_float, C.c_float]
         L.slxo_pipeline.restype = C.c_int
+        L.slxo_triangulate.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double] + [C.c_void_p] * 5
+        L.slxo_calib_tables.argtypes = [C.c_void_p] * 5
         L.slxo_pipeline_mt.restype = C.c_int
         _lib = L
     return _lib
@@ -166,6 +168,39 @@ def point_cloud(spec, z):
     xyz = np.zeros((z.size, 3))
     n = L.slxo_point_cloud(C.byref(cfg), _ptr(z, C.c_double), _ptr(xyz, C.c_double))
     return xyz[:n].copy()
+
+
+def strip_regression(cam, win=21):
+    """CCalculation::StripRegression: (stripW, stripB) float32 [H, W]."""
+    cam = np.ascontiguousarray(cam, dtype=np.uint8)
+    H, W = cam.shape
+    sw, sb = np.zeros((H, W), dtype=np.float32), np.zeros((H, W), dtype=np.float32)
+    lib().slxo_strip_regression(_ptr(cam, C.c_uint8), C.c_size_t(W), W, H, int(win), _ptr(sw, C.c_float), _ptr(sb, C.c_float))
+    return sw, sb
+
+
+def delta_p(W0, B0, W1, B1):
+    """FillOtherDeltaProU up to and including the 3x3 blur: float32 [H, W]."""
+    arrs = [np.ascontiguousarray(a, dtype=np.float32) for a in (W0, B0, W1, B1)]
+    H, W = arrs[0].shape
+    out = np.zeros((H, W), dtype=np.float32)
+    lib().slxo_delta_p(*[_ptr(a, C.c_float) for a in arrs], W, H, _ptr(out, C.c_float))
+    return out
+
+
+def triangulate(spec, U, want=("z",)):
+    """FillCoordinate on a given projector-column map."""
+    L = lib()
+    cfg = make_config(spec)
+    H, W = spec["height"], spec["width"]
+    U = np.ascontiguousarray(U, dtype=np.float64)
+    cC, cD = np.zeros((H, W)), np.zeros((H, W))
+    cA, cB = C.c_double(), C.c_double()
+    L.slxo_calib_tables(C.byref(cfg), C.byref(cA), C.byref(cB), _ptr(cC, C.c_double), _ptr(cD, C.c_double))
+    z, x, y = np.zeros((H, W)), np.zeros((H, W)), np.zeros((H, W))
+    L.slxo_triangulate(C.byref(cfg), _ptr(U, C.c_double), None, cA, cB, _ptr(cC, C.c_double), _ptr(cD, C.c_double),
+                       _ptr(z, C.c_double), _ptr(x, C.c_double), _ptr(y, C.c_double))
+    return {"z": z, "x": x, "y": y}
 
 
 def projection_matrix(pro, rot, trans):

@@ -305,6 +305,73 @@ size_t slxo_point_cloud(const slxo_config *cfg, const double *z, double *xyz)
     return n;
 }
 
+/* ------------------------------------------------------- dynamic frames --- */
+void slxo_strip_regression(const uint8_t *cam, size_t stride, int W, int H, int win, float *stripW, float *stripB)
+{
+    const int hw = win / 2;
+    float *valSum = (float *)calloc((size_t)W * H, sizeof(float));                 /* :799-801 setTo(0) */
+    for (int w = hw; w < W - hw; w++) {                                              /* :802 */
+        float sum = 0;
+        for (int hc = 0; hc < win; hc++)
+            sum += (float)cam[(size_t)hc * stride + w];                              /* :810 */
+        valSum[(size_t)hw * W + w] = sum;                                            /* :812 */
+    }
+    for (int h = hw + 1; h < H - hw; h++)                                            /* :815 */
+        for (int w = hw; w < W - hw; w++)
+            valSum[(size_t)h * W + w] = valSum[(size_t)(h - 1) * W + w]
+                - (float)cam[(size_t)(h - hw - 1) * stride + w]
+                + (float)cam[(size_t)(h + hw) * stride + w];                         /* :820-822 */
+    memset(stripW, 0, sizeof(float) * (size_t)W * H);                                /* :827-828 */
+    memset(stripB, 0, sizeof(float) * (size_t)W * H);
+    for (int h = hw; h < H - hw; h++) {
+        for (int w = hw; w < W - hw; w++) {
+            float max = valSum[(size_t)h * W + w], maxIdx = 0;                       /* :834-837 */
+            float min = max, minIdx = 0;
+            for (int i = -hw; i < hw; i++) {                                         /* :838 */
+                float value = valSum[(size_t)h * W + w + i];
+                if (value > max) { max = value; maxIdx = (float)i; }
+                if (value < min) { min = value; minIdx = (float)i; }
+            }
+            stripB[(size_t)h * W + w] = minIdx;                                      /* :888 */
+            stripW[(size_t)h * W + w] = maxIdx;                                      /* :889 */
+        }
+    }
+    free(valSum);
+}
+
+static inline int reflect101(int i, int n)
+{
+    if (n == 1) return 0;
+    while (i < 0 || i >= n) i = i < 0 ? -i : 2 * n - 2 - i;
+    return i;
+}
+
+void slxo_delta_p(const float *W0, const float *B0, const float *W1, const float *B1, int W, int H, float *deltaP)
+{
+    const size_t n = (size_t)W * H;
+    float *tmp = (float *)malloc(n * sizeof(float));
+    for (size_t i = 0; i < n; i++) {
+        float f0W = W0[i], f0B = B0[i], f1W = W1[i], f1B = B1[i];                    /* :602-605 */
+        float fBbias = fabsf(f0B - f1B), fWbias = fabsf(f0W - f1W);                  /* :607-608 */
+        tmp[i] = (fBbias < fWbias) ? f0B - f1B : f0W - f1W;                          /* :610-617 */
+    }
+    const double scale = 1. / 9;                                                     /* cv::blur(.., Size(3,3)), :650 */
+    for (int h = 0; h < H; h++)
+        for (int w = 0; w < W; w++) {
+            double s = 0;
+            for (int dy = -1; dy <= 1; dy++)
+                for (int dx = -1; dx <= 1; dx++)
+                    s += (double)tmp[(size_t)reflect101(h + dy, H) * W + reflect101(w + dx, W)];
+            deltaP[(size_t)h * W + w] = (float)(s * scale);
+        }
+    free(tmp);
+}
+
+void slxo_track_update(const double *Uprev, const float *deltaP, size_t n, double *U)
+{
+    for (size_t i = 0; i < n; i++) U[i] = Uprev[i] + deltaP[i];                      /* :656-658 */
+}
+
 /* ------------------------------------------------------------------ x2 --- */
 /* BUILD-DEFINED (SURVEY.md section 8 a-ext x2): U_1 = pix_1;
  * k_f = (int)floor((U_{f-1} - pix_f)/T_f + 0.5); U_f = pix_f + k_f*T_f (double). */

@@ -105,6 +105,15 @@ void slxo_triangulate(const slxo_config *cfg, const double *U, const uint8_t *ma
  * u outer / v inner.  xyz: room for 3*width*height doubles.  Returns the number of points. */
 size_t slxo_point_cloud(const slxo_config *cfg, const double *z, double *xyz);
 
+/* Dynamic frames (CCalculation::CalculateOther, R/CCalculation.cpp:208-320).
+ * StripRegression, R/CCalculation.cpp:789-892: 21-row sliding column sums, then per pixel the offset (in [-win/2, win/2))
+ * of the largest (stripW) and smallest (stripB) sum among the horizontal neighbours; 0 outside the interior. */
+void slxo_strip_regression(const uint8_t *cam, size_t stride, int width, int height, int win, float *stripW, float *stripB);
+/* FillOtherDeltaProU, R/CCalculation.cpp:595-663: deltaP selection, cv::blur 3x3 (OpenCV 2.4.9 boxFilter, restated:
+ * normalised, BORDER_REFLECT_101, double column sums scaled by 1./9 -- unpinned), U = Uprev + deltaP. */
+void slxo_delta_p(const float *W0, const float *B0, const float *W1, const float *B1, int width, int height, float *deltaP);
+void slxo_track_update(const double *Uprev, const float *deltaP, size_t n, double *U);
+
 /* x2: hierarchical temporal unwrap (BUILD-DEFINED, SURVEY.md section 8 a-ext). */
 void slxo_unwrap_multifreq(const double *pix, int n_freq, const int *period,
                            int width, int height, double *U, int32_t *k);

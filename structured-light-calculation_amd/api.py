@@ -21,14 +21,15 @@ ERR_HIP, ERR_OUT_OF_MEMORY, ERR_NOT_DECODED, ERR_UNAVAILABLE = -5, -6, -7, -8
 MODE_PHASE_ONLY, MODE_GRAY_ONLY, MODE_GRAY_PHASE, MODE_MULTIFREQ, MODE_MULTIFREQ_GRAYMASK = range(5)
 MEM_HOST, MEM_DEVICE = 0, 1
 GROUP_GRAY, GROUP_PHASE = 0, 1
-OUT_Z, OUT_X, OUT_Y, OUT_U, OUT_PIX, OUT_GRAY, OUT_K, OUT_MASK = range(8)
-OUT_NAMES = {"z": OUT_Z, "x": OUT_X, "y": OUT_Y, "U": OUT_U, "pix": OUT_PIX, "gray": OUT_GRAY, "k": OUT_K, "mask": OUT_MASK}
+OUT_Z, OUT_X, OUT_Y, OUT_U, OUT_PIX, OUT_GRAY, OUT_K, OUT_MASK, OUT_DELTAZ, OUT_DELTAP, OUT_STRIPW, OUT_STRIPB = range(12)
+OUT_NAMES = {"z": OUT_Z, "x": OUT_X, "y": OUT_Y, "U": OUT_U, "pix": OUT_PIX, "gray": OUT_GRAY, "k": OUT_K, "mask": OUT_MASK,
+             "deltaZ": OUT_DELTAZ, "deltaP": OUT_DELTAP, "stripW": OUT_STRIPW, "stripB": OUT_STRIPB}
 
 # every symbol include/slx.h declares
 SYMBOLS = [
     "slx_validate_config", "slx_create", "slx_destroy", "slx_last_error", "slx_set_gray_lut",
     "slx_set_frame", "slx_decode", "slx_decode_batch", "slx_synchronize", "slx_get_output",
-    "slx_get_depth", "slx_get_point_cloud", "slx_output_device_ptr", "slx_get_calibration", "slx_enable_timing",
+    "slx_get_depth", "slx_get_point_cloud", "slx_track_begin", "slx_track_next", "slx_output_device_ptr", "slx_get_calibration", "slx_enable_timing",
     "slx_last_decode_ms", "slx_debug_stamps", "slx_set_variant", "slx_read_bmp_gray", "slx_read_calibration_yaml", "slx_version",
 ]
 
@@ -77,6 +78,8 @@ def lib():
         L.slx_get_output.argtypes = [vp, C.c_int, vp, sz, C.c_int]
         L.slx_get_depth.argtypes = [vp, vp, C.c_int]
         L.slx_get_point_cloud.argtypes = [vp, vp, sz, C.POINTER(sz), C.c_int]
+        L.slx_track_begin.argtypes = [vp, vp, sz, C.c_int, C.c_int]
+        L.slx_track_next.argtypes = [vp, vp, sz, C.c_int]
         L.slx_output_device_ptr.argtypes = [vp, C.c_int, C.POINTER(vp)]
         L.slx_get_calibration.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.slx_enable_timing.argtypes = [vp, C.c_int]
@@ -131,7 +134,7 @@ def validate_config(cfg):
     return rc, buf.value.decode()
 
 
-_OUT_DTYPE = {OUT_K: np.int32, OUT_MASK: np.uint8}
+_OUT_DTYPE = {OUT_K: np.int32, OUT_MASK: np.uint8, OUT_DELTAP: np.float32, OUT_STRIPW: np.float32, OUT_STRIPB: np.float32}
 
 
 class Context:
@@ -245,6 +248,24 @@ class Context:
         a = np.empty((n.value, 3), dtype=np.float64)
         self._check(lib().slx_get_point_cloud(self._h, a.ctypes.data, n.value, C.byref(n), MEM_HOST))
         return a
+
+    def _image_args(self, image):
+        if isinstance(image, np.ndarray):
+            assert image.dtype == np.uint8 and image.ndim == 2 and image.strides[1] == 1
+            return image.ctypes.data, image.strides[0], MEM_HOST
+        assert image.is_cuda and image.dim() == 2 and image.stride(1) == 1
+        self._borrowed.append(image)
+        return image.data_ptr(), image.stride(0), MEM_DEVICE
+
+    def track_begin(self, image, window=21):
+        """StripRegression(0) on the first dynamic camera image (numpy uint8 [H,W] or a CUDA tensor)."""
+        ptr, stride, kind = self._image_args(image)
+        self._check(lib().slx_track_begin(self._h, ptr, stride, kind, int(window)))
+
+    def track_next(self, image):
+        """One dynamic frame: strips, deltaP, U, z (x, y), deltaZ are updated in place."""
+        ptr, stride, kind = self._image_args(image)
+        self._check(lib().slx_track_next(self._h, ptr, stride, kind))
 
     def get_calibration(self):
         P = (C.c_double * 12)()

@@ -295,7 +295,7 @@ std::vector<double> CCalculation::GetPointCloud()
 
 bool CCalculation::Result(std::string fileName, int i)
 {
-    if (i != 0 || !m_ctx || !m_done) return false;
+    if (i != m_frame || !m_ctx || !m_done) return false;        // only the current frame's maps exist on the device
     std::fstream file;
     file.open(fileName.c_str(), std::ios::out);
     if (!file) {
@@ -311,6 +311,37 @@ bool CCalculation::Result(std::string fileName, int i)
     file.close();
     return true;
 }
+
+bool CCalculation::StripRegression0(const Image8 &dynaCam0, int recoWindowSize)
+{
+    if (!m_ctx || !m_done) return false;
+    if (dynaCam0.empty() || dynaCam0.rows != m_sp.CAMERA_RESROW || dynaCam0.cols != m_sp.CAMERA_RESLINE) {
+        m_err = "image is empty or has the wrong size";
+        return false;
+    }
+    if (slx_track_begin(m_ctx, dynaCam0.data, dynaCam0.step, dynaCam0.on_device ? SLX_MEM_DEVICE : SLX_MEM_HOST, recoWindowSize) != SLX_OK) {
+        m_err = slx_last_error(m_ctx);
+        return false;
+    }
+    return true;
+}
+
+bool CCalculation::CalculateOtherFrame(int fN, const Image8 &dynaCam)
+{
+    if (!m_ctx || !m_done || fN != m_frame + 1) return false;   // frames come in order: each builds on the previous one
+    if (dynaCam.empty() || dynaCam.rows != m_sp.CAMERA_RESROW || dynaCam.cols != m_sp.CAMERA_RESLINE) {
+        m_err = "image is empty or has the wrong size";
+        return false;
+    }
+    if (slx_track_next(m_ctx, dynaCam.data, dynaCam.step, dynaCam.on_device ? SLX_MEM_DEVICE : SLX_MEM_HOST) != SLX_OK) {
+        m_err = slx_last_error(m_ctx);
+        return false;
+    }
+    m_frame = fN;
+    return true;
+}
+
+std::vector<double> CCalculation::GetDeltaZ() { return m_frame > 0 ? Fetch(SLX_OUT_DELTAZ) : std::vector<double>(); }
 
 std::vector<double> CCalculation::GetZ() { return Fetch(SLX_OUT_Z); }
 std::vector<double> CCalculation::GetX() { return Fetch(SLX_OUT_X); }

@@ -93,7 +93,9 @@ struct Calibration {
     double CamMat[9], ProMat[9], R[9], T[3];
 };
 
-// Static reconstruction of frame 0: Gray + phase decode, merge, triangulation.
+class CSensor;
+
+// Static reconstruction of frame 0 (Gray + phase decode, merge, triangulation) and the dynamic frames after it.
 class CCalculation {
 public:
     CCalculation();
@@ -111,6 +113,15 @@ public:
     // R/CCalculation.cpp:323: text point cloud "x y z\n" of the depths inside the FOV, column outer / row inner,
     // default ostream formatting.  Only frame 0 (the static reconstruction) exists here.
     bool Result(std::string fileName, int i = 0);
+    // Dynamic frames, R/CCalculation.cpp:208-320.  StripRegression(0) is what CalculateFirst ends with in the reference
+    // (:203); here the camera image comes in explicitly.  CalculateOtherFrame(fN, image) = StripRegression(fN) +
+    // FillOtherDeltaProU(fN) + FillCoordinate(fN); afterwards GetZ/GetX/GetY/GetProjectorU/GetDeltaZ/Result refer to frame fN.
+    bool StripRegression0(const Image8 &dynaCam0, int recoWindowSize = 21);
+    bool CalculateOtherFrame(int fN, const Image8 &dynaCam);
+    // The whole loop of CalculateOther over the sensor's dynaCam images (group 2): frame fN's point cloud goes to
+    // <pointCloudPrefix><fN>.txt like m_pcSucceedName (R/CCalculation.cpp:309-314).  Returns the number of frames done.
+    int CalculateOther(CSensor &sensor, const std::string &pointCloudPrefix, int recoWindowSize = 21);
+    std::vector<double> GetDeltaZ();
     std::vector<double> GetPointCloud();            // the same points, packed x y z
     // m_zMat[0], m_xMat[0], m_yMat[0], m_ProjectorU[0] (CV_64FC1, rows x cols)
     std::vector<double> GetZ(), GetX(), GetY(), GetProjectorU();
@@ -122,6 +133,7 @@ private:
     StaticParameters m_sp;
     slx_ctx *m_ctx = nullptr;
     bool m_done = false;
+    int m_frame = 0;               // the frame GetZ etc. refer to
     std::string m_err;
 };
 

@@ -193,6 +193,26 @@ Image8 CSensor::GetCamPicture() const
     return im;
 }
 
+// R/CCalculation.cpp:208-320 with the sensor's group-2 images
+int CCalculation::CalculateOther(CSensor &sensor, const std::string &pointCloudPrefix, int recoWindowSize)
+{
+    if (!m_ctx || !m_done) return 0;
+    if (!sensor.LoadDatas(2) && sensor.DataNum() == 0) return 0;
+    if (!sensor.SetProPicture(0) || !StripRegression0(sensor.GetCamPicture(), recoWindowSize)) return 0;
+    int done = 0;
+    for (int frameNum = 1; frameNum < sensor.DataNum(); frameNum++) {
+        if (!sensor.SetProPicture(frameNum)) break;
+        const Image8 cam = sensor.GetCamPicture();
+        if (cam.empty()) break;                                  // fewer images on disk than DYNAFRAME_MAXNUM
+        if (!CalculateOtherFrame(frameNum, cam)) break;
+        std::ostringstream name;
+        name << pointCloudPrefix << frameNum << ".txt";
+        if (!Result(name.str(), frameNum)) break;
+        done++;
+    }
+    return done;
+}
+
 }  // namespace slx
 
 // ---- plain-C access to the two file readers (declared in include/slx.h) ----

@@ -7,6 +7,7 @@
 // fused HIP kernel.  No OpenCV, no torch, no CPU fallback.
 #include <hip/hip_runtime_api.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -43,6 +44,10 @@ struct slx_ctx {
     unsigned *d_cloud_counts = nullptr, *d_cloud_offsets = nullptr;   // width + 1 each, point-cloud compaction
     double *d_cloud = nullptr;
     size_t cloud_capacity = 0;
+    // dynamic-frame tracker: previous frame's strips, unblurred deltaP, staged camera image
+    float *d_stripW_prev = nullptr, *d_stripB_prev = nullptr, *d_deltaP_raw = nullptr;
+    uint8_t *d_track_img = nullptr;
+    int track_window = 0;
     void *out[SLX_OUT_COUNT] = {};
     size_t out_bytes[SLX_OUT_COUNT] = {};
     size_t staging_pitch = 0;
@@ -122,7 +127,11 @@ int validate(const slx_config *c, std::string &msg)
     return SLX_OK;
 }
 
-size_t out_elem_bytes(int which) { return which == SLX_OUT_K ? 4 : which == SLX_OUT_MASK ? 1 : 8; }
+size_t out_elem_bytes(int which)
+{
+    if (which == SLX_OUT_K || which == SLX_OUT_DELTAP || which == SLX_OUT_STRIPW || which == SLX_OUT_STRIPB) return 4;
+    return which == SLX_OUT_MASK ? 1 : 8;
+}
 
 size_t out_planes(const slx_config &c, int which)
 {
@@ -234,7 +243,8 @@ void slx_destroy(slx_ctx *ctx)
     for (void *o : ctx->out)
         if (o) (void)hipFree(o);
     if (ctx->d_lut) (void)hipFree(ctx->d_lut);
-    for (void *q : {(void *)ctx->d_cloud_counts, (void *)ctx->d_cloud_offsets, (void *)ctx->d_cloud})
+    for (void *q : {(void *)ctx->d_cloud_counts, (void *)ctx->d_cloud_offsets, (void *)ctx->d_cloud, (void *)ctx->d_stripW_prev,
+                    (void *)ctx->d_stripB_prev, (void *)ctx->d_deltaP_raw, (void *)ctx->d_track_img})
         if (q) (void)hipFree(q);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -546,6 +556,85 @@ int slx_get_point_cloud(slx_ctx *ctx, double *xyz, size_t capacity_points, size_
     if (mem_kind == SLX_MEM_HOST)
         SLX_HIP(ctx, hipMemcpyAsync(xyz, dst, (size_t)total * 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     SLX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return SLX_OK;
+}
+
+// Camera image of a dynamic frame on the device: borrowed, or staged through the context's buffer.
+static int track_image(slx_ctx *ctx, const uint8_t *image, size_t stride, int mem_kind, const uint8_t **dev, size_t *dev_stride)
+{
+    const slx_config &c = ctx->cfg;
+    if (!image) return fail(ctx, SLX_ERR_INVALID_ARG, "image is NULL");
+    if (stride < (size_t)c.width) return fail(ctx, SLX_ERR_INVALID_ARG, "stride %zu is smaller than the width %d", stride, c.width);
+    if (mem_kind == SLX_MEM_DEVICE) {
+        *dev = image;
+        *dev_stride = stride;
+        return SLX_OK;
+    }
+    if (mem_kind != SLX_MEM_HOST) return fail(ctx, SLX_ERR_INVALID_ARG, "unknown mem_kind %d", mem_kind);
+    if (!ctx->d_track_img) SLX_HIP(ctx, hipMalloc((void **)&ctx->d_track_img, (size_t)c.width * c.height));
+    SLX_HIP(ctx, hipStreamSynchronize(ctx->stream));     // the previous frame may still be reading the staging buffer
+    SLX_HIP(ctx, hipMemcpy2D(ctx->d_track_img, (size_t)c.width, image, stride, (size_t)c.width, (size_t)c.height, hipMemcpyHostToDevice));
+    *dev = ctx->d_track_img;
+    *dev_stride = (size_t)c.width;
+    return SLX_OK;
+}
+
+int slx_track_begin(slx_ctx *ctx, const uint8_t *image, size_t stride_bytes, int mem_kind, int window)
+{
+    if (!ctx) return SLX_ERR_INVALID_ARG;
+    const slx_config &c = ctx->cfg;
+    if (!mode_has_depth(c.mode) || !ctx->out[SLX_OUT_U])
+        return fail(ctx, SLX_ERR_UNAVAILABLE, "dynamic frames need a depth mode created with SLX_OUT_U in aux_outputs");
+    if (!ctx->decoded) return fail(ctx, SLX_ERR_NOT_DECODED, "decode frame 0 first");
+    if (window < 3 || window > 201 || (window & 1) == 0) return fail(ctx, SLX_ERR_INVALID_ARG, "window must be odd and in [3,201] (got %d)", window);
+    SLX_HIP(ctx, hipSetDevice(ctx->device));
+    SLX_HIP(ctx, hipDeviceSynchronize());                 // frame 0 may have been decoded on a caller stream
+    const size_t hw = (size_t)c.width * c.height;
+    for (int w : {SLX_OUT_DELTAZ, SLX_OUT_DELTAP, SLX_OUT_STRIPW, SLX_OUT_STRIPB}) {
+        if (ctx->out[w]) continue;
+        const size_t bytes = hw * out_elem_bytes(w);
+        SLX_HIP(ctx, hipMalloc(&ctx->out[w], bytes));
+        ctx->out_bytes[w] = bytes;
+    }
+    for (float **q : {&ctx->d_stripW_prev, &ctx->d_stripB_prev, &ctx->d_deltaP_raw})
+        if (!*q) SLX_HIP(ctx, hipMalloc((void **)q, hw * sizeof(float)));
+    for (int w : {SLX_OUT_DELTAZ, SLX_OUT_DELTAP, SLX_OUT_STRIPW, SLX_OUT_STRIPB}) SLX_HIP(ctx, hipMemsetAsync(ctx->out[w], 0, ctx->out_bytes[w], ctx->stream));
+    const uint8_t *img;
+    size_t istride;
+    int rc = track_image(ctx, image, stride_bytes, mem_kind, &img, &istride);
+    if (rc != SLX_OK) return rc;
+    ctx->track_window = window;
+    int e = slx_launch_strip_regression(img, istride, c.width, c.height, window, (float *)ctx->out[SLX_OUT_STRIPW], (float *)ctx->out[SLX_OUT_STRIPB], ctx->stream);
+    if (e != 0) return hip_fail(ctx, (hipError_t)e, "strip regression");
+    return SLX_OK;
+}
+
+int slx_track_next(slx_ctx *ctx, const uint8_t *image, size_t stride_bytes, int mem_kind)
+{
+    if (!ctx) return SLX_ERR_INVALID_ARG;
+    const slx_config &c = ctx->cfg;
+    if (ctx->track_window == 0) return fail(ctx, SLX_ERR_NOT_CONFIGURED, "slx_track_begin has not been called");
+    SLX_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t hw = (size_t)c.width * c.height;
+    const uint8_t *img;
+    size_t istride;
+    int rc = track_image(ctx, image, stride_bytes, mem_kind, &img, &istride);
+    if (rc != SLX_OK) return rc;
+    // the strips of the previous frame move aside; the new ones start from 0 (R/CCalculation.cpp:827-828)
+    float *curW = (float *)ctx->out[SLX_OUT_STRIPW], *curB = (float *)ctx->out[SLX_OUT_STRIPB];
+    std::swap(curW, ctx->d_stripW_prev);
+    std::swap(curB, ctx->d_stripB_prev);
+    ctx->out[SLX_OUT_STRIPW] = curW;
+    ctx->out[SLX_OUT_STRIPB] = curB;
+    SLX_HIP(ctx, hipMemsetAsync(curW, 0, hw * sizeof(float), ctx->stream));
+    SLX_HIP(ctx, hipMemsetAsync(curB, 0, hw * sizeof(float), ctx->stream));
+    int e = slx_launch_strip_regression(img, istride, c.width, c.height, ctx->track_window, curW, curB, ctx->stream);
+    if (e == 0) e = slx_launch_delta_p(ctx->d_stripW_prev, ctx->d_stripB_prev, curW, curB, hw, ctx->d_deltaP_raw, ctx->stream);
+    if (e == 0)
+        e = slx_launch_track_update(ctx->kp, ctx->d_deltaP_raw, (float *)ctx->out[SLX_OUT_DELTAP], (double *)ctx->out[SLX_OUT_U],
+                                    (double *)ctx->out[SLX_OUT_Z], (double *)ctx->out[SLX_OUT_X], (double *)ctx->out[SLX_OUT_Y],
+                                    (double *)ctx->out[SLX_OUT_DELTAZ], ctx->stream);
+    if (e != 0) return hip_fail(ctx, (hipError_t)e, "dynamic-frame kernels");
     return SLX_OK;
 }
 

@@ -72,6 +72,12 @@ int slx_launch_cloud_count(const SlxKParams &kp, const double *z, unsigned *coun
 int slx_launch_cloud_scan(int width, const unsigned *counts, unsigned *offsets, void *stream);
 int slx_launch_cloud_write(const SlxKParams &kp, const double *z, const unsigned *offsets, double *xyz, void *stream);
 
+// Dynamic-frame tracker (slx_track.hip).  Device pointers; 0 or a hipError_t.
+int slx_launch_strip_regression(const uint8_t *cam, size_t stride, int W, int H, int win, float *stripW, float *stripB, void *stream);
+int slx_launch_delta_p(const float *W0, const float *B0, const float *W1, const float *B1, size_t n, float *raw, void *stream);
+int slx_launch_track_update(const SlxKParams &kp, const float *raw, float *deltaP, double *U, double *z, double *x, double *y, double *deltaZ,
+                            void *stream);
+
 // True when the strip kernel can run this configuration / these operands.
 bool slx_strip_eligible(const SlxKParams &kp, int mode, bool aux);
 

@@ -53,11 +53,13 @@ int main(int argc, char **argv)
     }
     if (!calc.CalculateFirst()) return die("CalculateFirst", calc.LastError());
     if (!calc.Result(dir + "PointCloud/iFrame.txt", 0)) return die("Result", calc.LastError());
-    const std::vector<double> z = calc.GetZ();
+    const std::vector<double> z = calc.GetZ();                  // frame 0, before the dynamic frames overwrite it
+    // R/main.cpp:44: CalculateOther over <group>/cFrame/dynaCam<i>.bmp (as many as are on disk)
+    const int frames = calc.CalculateOther(sensor, dir + "PointCloud/cFrame");
     FILE *f = std::fopen((dir + "z.bin").c_str(), "wb");
     if (!f) return die("write", "z.bin");
     std::fwrite(z.data(), sizeof(double), z.size(), f);
     std::fclose(f);
-    std::printf("ok %d x %d\n", sp.CAMERA_RESLINE, sp.CAMERA_RESROW);
+    std::printf("ok %d x %d, dynamic frames %d\n", sp.CAMERA_RESLINE, sp.CAMERA_RESROW, frames);
     return 0;
 }

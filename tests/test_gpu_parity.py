@@ -440,6 +440,84 @@ def test_point_cloud(api, oracle, synth, name, shape):
         assert ctx.get_point_cloud().shape == (0, 3)
 
 
+# ------------------------------------------------------------------ dynamic frames (CCalculation::CalculateOther)
+def dyna_images(h, w, n, seed):
+    """A moving stripe pattern seen by the camera, with noise: what the tracker's column-sum extrema follow."""
+    rng = np.random.default_rng(seed)
+    u = np.arange(w)[None, :] + 0.03 * np.arange(h)[:, None]
+    out = []
+    for f in range(n):
+        img = 128 + 100 * np.sign(np.sin(2 * np.pi * (u + 1.7 * f) / 14.0)) + rng.normal(0, 6, (h, w))
+        out.append(np.clip(img, 0, 255).astype(np.uint8))
+    return out
+
+
+@pytest.mark.parametrize("shape,window", [((96, 160), 21), ((40, 300), 21), ((25, 23), 21), ((64, 64), 5), ((20, 64), 21),
+                                          ((130, 256), 21), ((30, 257), 21), ((70, 492), 21), ((24, 1000), 9)])
+def test_dynamic_frames(api, oracle, synth, shape, window):
+    h, w = shape
+    spec = small_spec(synth, "C1x4", w, h)
+    ph, gr, _ = synth.render(spec, "tilted", noise_sigma=2.0)
+    ref0 = oracle.pipeline(spec, ph, gr, want=("z", "U"))
+    imgs = dyna_images(h, w, 5, seed=h + w)
+    with api.Context(spec, aux=("U", "x", "y")) as ctx:
+        with pytest.raises(api.SlxError) as e:
+            ctx.track_next(imgs[1])
+        assert e.value.code == api.ERR_NOT_CONFIGURED
+        ctx.set_frames(ph, gr)
+        ctx.decode()
+        with pytest.raises(api.SlxError):
+            ctx.track_begin(imgs[0], window=20)               # even window
+        ctx.track_begin(imgs[0], window=window)
+        sw0, sb0 = oracle.strip_regression(imgs[0], window)
+        assert np.array_equal(ctx.get_output("stripW"), sw0) and np.array_equal(ctx.get_output("stripB"), sb0)
+        U, z_prev = ref0["U"], ref0["z"]
+        for f in range(1, 5):
+            ctx.track_next(imgs[f])
+            sw1, sb1 = oracle.strip_regression(imgs[f], window)
+            dP = oracle.delta_p(sw0, sb0, sw1, sb1)
+            U = U + dP.astype(np.float64)
+            tri = oracle.triangulate(spec, U)
+            for name, want in (("stripW", sw1), ("stripB", sb1), ("deltaP", dP), ("U", U), ("z", tri["z"]), ("x", tri["x"]),
+                               ("y", tri["y"]), ("deltaZ", tri["z"] - z_prev)):
+                assert np.array_equal(ctx.get_output(name), want, equal_nan=True), (f, name)
+            assert np.array_equal(ctx.get_point_cloud(), oracle.point_cloud(spec, tri["z"]))
+            sw0, sb0, z_prev = sw1, sb1, tri["z"]
+        if h > 2 * window and w > 2 * window:
+            assert np.any(sw0 != 0) and np.any(dP != 0)
+    with api.Context(spec) as ctx:                            # no U plane: the tracker refuses
+        ctx.set_frames(ph, gr)
+        ctx.decode()
+        with pytest.raises(api.SlxError) as e:
+            ctx.track_begin(imgs[0])
+        assert e.value.code == api.ERR_UNAVAILABLE
+
+
+def test_dynamic_frames_device_images_full_size(api, oracle, synth, torch_cuda):
+    torch = torch_cuda
+    spec = synth.make_spec("REF")                             # 1280 x 1024, the reference's compiled-in camera
+    H, W = spec["height"], spec["width"]
+    ph, gr, _ = synth.render(spec, "sphere", noise_sigma=2.0)
+    imgs = dyna_images(H, W, 3, seed=3)
+    dev = [torch.from_numpy(np.pad(i, ((0, 0), (0, 64)))).cuda()[:, :W] for i in imgs]     # padded rows, borrowed
+    torch.cuda.synchronize()
+    ref0 = oracle.pipeline(spec, ph, gr, want=("z", "U"), threads=8)
+    with api.Context(spec, aux=("U",)) as ctx:
+        ctx.set_frames(ph, gr)
+        ctx.decode()
+        ctx.track_begin(dev[0])
+        sw0, sb0 = oracle.strip_regression(imgs[0])
+        U, z_prev = ref0["U"], ref0["z"]
+        for f in (1, 2):
+            ctx.track_next(dev[f])
+            sw1, sb1 = oracle.strip_regression(imgs[f])
+            U = U + oracle.delta_p(sw0, sb0, sw1, sb1).astype(np.float64)
+            tri = oracle.triangulate(spec, U)
+            assert np.array_equal(ctx.get_output("U"), U) and np.array_equal(ctx.get_depth(), tri["z"], equal_nan=True)
+            assert np.array_equal(ctx.get_output("deltaZ"), tri["z"] - z_prev, equal_nan=True)
+            sw0, sb0, z_prev = sw1, sb1, tri["z"]
+
+
 # ------------------------------------------------------------------ sharding on the device
 def test_row_tiles_and_frameset_shards_on_gpu(api, oracle, synth, shard):
     spec = small_spec(synth, "C3", 128, 50)
@@ -541,10 +619,23 @@ def test_cpp_data_directory(tmp_path, oracle, synth, golden_dir):
         write_bmp(os.path.join(d, "g/iFrame/vGrayCam%d.bmp" % i), gr[i], bits=8 if i % 2 else 24, top_down=bool(i % 3 == 0))
     for i in range(4):
         write_bmp(os.path.join(d, "g/iFrame/vPhaseCam%d.bmp" % i), ph[i], bits=8)
+    os.makedirs(os.path.join(d, "g/cFrame"))
+    dyn = dyna_images(H, W, 4, seed=8)
+    for i, img in enumerate(dyn):
+        write_bmp(os.path.join(d, "g/cFrame/dynaCam%d.bmp" % i), img, bits=8)
     out = subprocess.check_output([exe, d, "g", str(PW), str(spec["fov_min"]), str(spec["fov_max"])]).decode()
-    assert out.startswith("ok %d x %d" % (W, H))
+    assert out.startswith("ok %d x %d" % (W, H)) and "dynamic frames 3" in out
     ref = oracle.pipeline(spec, ph, gr, want=("z",))
     z = np.fromfile(os.path.join(d, "z.bin"), dtype=np.float64).reshape(H, W)
     assert np.array_equal(z, ref["z"], equal_nan=True)
     pts = oracle.point_cloud(spec, ref["z"])
     assert open(os.path.join(d, "PointCloud", "iFrame.txt")).read() == "".join("%g %g %g\n" % tuple(p) for p in pts)
+    # CalculateOther over cFrame/dynaCam<i>.bmp: one point cloud per dynamic frame
+    U = oracle.pipeline(spec, ph, gr, want=("U",))["U"]
+    sw0, sb0 = oracle.strip_regression(dyn[0])
+    for f in (1, 2, 3):
+        sw1, sb1 = oracle.strip_regression(dyn[f])
+        U = U + oracle.delta_p(sw0, sb0, sw1, sb1).astype(np.float64)
+        pts = oracle.point_cloud(spec, oracle.triangulate(spec, U)["z"])
+        assert open(os.path.join(d, "PointCloud", "cFrame%d.txt" % f)).read() == "".join("%g %g %g\n" % tuple(p) for p in pts), f
+        sw0, sb0 = sw1, sb1

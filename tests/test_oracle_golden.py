@@ -219,6 +219,41 @@ def test_point_cloud_order_and_filter(oracle, synth):
     assert np.array_equal(pts[:, 1], z.T[keep.T] * (uu - cam[5]) / cam[4])
 
 
+# ---------------------------------------------------------------- dynamic frames (CalculateOther)
+def test_strip_regression_against_numpy(oracle):
+    """StripRegression restated independently: 21-row column sums by cumulative sums, extrema by argmax/argmin with the
+    reference's tie rule (the centre wins, then the leftmost)."""
+    rng = np.random.default_rng(0)
+    cam = rng.integers(0, 256, (50, 70), dtype=np.uint8)
+    cam[:, 30:40] = (np.arange(10) * 25)[None, :]                 # ties and ramps
+    sw, sb = oracle.strip_regression(cam, 21)
+    H, W, hw = 50, 70, 10
+    vs = np.zeros((H, W))
+    cs = np.cumsum(np.vstack([np.zeros((1, W)), cam.astype(np.float64)]), axis=0)
+    for h in range(hw, H - hw):
+        vs[h, hw:W - hw] = (cs[h + hw + 1] - cs[h - hw])[hw:W - hw]
+    for h in range(H):
+        for w in range(W):
+            if not (hw <= h < H - hw and hw <= w < W - hw):
+                assert sw[h, w] == 0 and sb[h, w] == 0
+                continue
+            seg, c = vs[h, w - hw:w + hw], vs[h, w]
+            assert sw[h, w] == (0 if seg.max() <= c else int(np.argmax(seg)) - hw)
+            assert sb[h, w] == (0 if seg.min() >= c else int(np.argmin(seg)) - hw)
+
+
+def test_delta_p_selection_and_blur(oracle):
+    from scipy.ndimage import uniform_filter
+    rng = np.random.default_rng(1)
+    W0, B0, W1, B1 = (rng.integers(-10, 10, (17, 23)).astype(np.float32) for _ in range(4))
+    raw = np.where(np.abs(B0 - B1) < np.abs(W0 - W1), B0 - B1, W0 - W1)
+    want = uniform_filter(raw.astype(np.float64), size=3, mode="mirror")      # BORDER_REFLECT_101
+    got = oracle.delta_p(W0, B0, W1, B1)
+    assert got.dtype == np.float32 and np.allclose(got, want, rtol=0, atol=2e-6)
+    one = oracle.delta_p(*(a[:1, :1] for a in (W0, B0, W1, B1)))               # 1x1: every tap is the pixel itself
+    assert one[0, 0] == np.float32(float(raw[0, 0]) * 9 * (1.0 / 9))
+
+
 # ---------------------------------------------------------------- regression vectors
 @pytest.mark.parametrize("name", GOLDEN_SCENES)
 def test_scene_golden(oracle, synth, golden_dir, name):
