@@ -85,6 +85,34 @@ __device__ __forceinline__ float wrapped_pix_from_diffs(float s2, float c2, floa
     return pix;
 }
 
+// Two pixels at a time with explicit 2-vectors, so that every multiply / add / fma of the sequence is a packed
+// instruction (v_pk_*_f32 retire two lanes' worth per issue slot); compares and selects stay per component.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 wrapped_pix_from_diffs2(f32x2 s2, f32x2 c2, float Tf)
+{
+    const f32x2 as = {__builtin_fabsf(s2.x), __builtin_fabsf(s2.y)}, ac = {__builtin_fabsf(c2.x), __builtin_fabsf(c2.y)};
+    const f32x2 mx = {__builtin_fmaxf(__builtin_fmaxf(as.x, ac.x), 1.0f), __builtin_fmaxf(__builtin_fmaxf(as.y, ac.y), 1.0f)};
+    const f32x2 mn = {__builtin_fminf(as.x, ac.x), __builtin_fminf(as.y, ac.y)};
+    const f32x2 r = {__builtin_amdgcn_rcpf(mx.x), __builtin_amdgcn_rcpf(mx.y)};
+    const f32x2 q0 = mn * r;
+    const f32x2 c = __builtin_elementwise_fma(__builtin_elementwise_fma(-mx, q0, mn), r, q0);
+    const f32x2 cc = c * c;
+    f32x2 a = (((kP7 * cc + kP5) * cc + kP3) * cc + kP1) * c;
+    const f32x2 a90 = 90.f - a;
+    a = f32x2{as.x > ac.x ? a90.x : a.x, as.y > ac.y ? a90.y : a.y};
+    const f32x2 a180 = 180.f - a;
+    a = f32x2{c2.x < 0.f ? a180.x : a.x, c2.y < 0.f ? a180.y : a.y};
+    const f32x2 a360 = 360.f - a;
+    a = f32x2{s2.x < 0.f ? a360.x : a.x, s2.y < 0.f ? a360.y : a.y};
+    const f32x2 d0 = a * kInv360;
+    const f32x2 k360 = {kInv360, kInv360}, m360 = {-360.f, -360.f};
+    const f32x2 d = __builtin_elementwise_fma(__builtin_elementwise_fma(m360, d0, a), k360, d0);
+    f32x2 pix = d * Tf;
+    pix = pix + 0.5f;
+    const f32x2 wrapped = pix - Tf;
+    return f32x2{pix.x > Tf ? wrapped.x : pix.x, pix.y > Tf ? wrapped.y : pix.y};
+}
+
 __device__ __forceinline__ float wrapped_pix_4step(float g0, float g1, float g2, float g3, float Tf)
 {
     return wrapped_pix_from_diffs(g0 - g2, g1 - g3, Tf);
@@ -699,10 +727,14 @@ __global__ __launch_bounds__(256) void slx_strip_kernel(const SlxKParams p)
             for (int f = 0; f < (NS == 4 ? F : 0); f++) {
                 const uint32_t w0 = src[(f * 4 + 0) * 64], w1 = src[(f * 4 + 1) * 64];
                 const uint32_t w2 = src[(f * 4 + 2) * 64], w3 = src[(f * 4 + 3) * 64];
-                pix[f][0] = wrapped_pix_from_diffs((float)byte_diff<0>(w0, w2), (float)byte_diff<0>(w1, w3), Tf[f]);
-                pix[f][1] = wrapped_pix_from_diffs((float)byte_diff<1>(w0, w2), (float)byte_diff<1>(w1, w3), Tf[f]);
-                pix[f][2] = wrapped_pix_from_diffs((float)byte_diff<2>(w0, w2), (float)byte_diff<2>(w1, w3), Tf[f]);
-                pix[f][3] = wrapped_pix_from_diffs((float)byte_diff<3>(w0, w2), (float)byte_diff<3>(w1, w3), Tf[f]);
+                const f32x2 p01 = wrapped_pix_from_diffs2(f32x2{(float)byte_diff<0>(w0, w2), (float)byte_diff<1>(w0, w2)},
+                                                          f32x2{(float)byte_diff<0>(w1, w3), (float)byte_diff<1>(w1, w3)}, Tf[f]);
+                const f32x2 p23 = wrapped_pix_from_diffs2(f32x2{(float)byte_diff<2>(w0, w2), (float)byte_diff<3>(w0, w2)},
+                                                          f32x2{(float)byte_diff<2>(w1, w3), (float)byte_diff<3>(w1, w3)}, Tf[f]);
+                pix[f][0] = p01.x;
+                pix[f][1] = p01.y;
+                pix[f][2] = p23.x;
+                pix[f][3] = p23.y;
             }
             uint32_t gw[GB > 0 ? 2 * GB : 1];
 #pragma unroll
