@@ -109,6 +109,9 @@ def main():
     ap.add_argument("--config", default="C4")
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--shard", choices=("framesets", "rows"), default="framesets",
+                    help="how ranks split the batch: whole frame-sets (default), or a row tile of every frame-set (north_star's wording); "
+                         "the per-GPU bytes are the same")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL) on GPUs; gloo only to rehearse the multi-rank path on one GPU")
     args = ap.parse_args()
 
@@ -141,9 +144,14 @@ def main():
     api.lib()   # raises if the HIP library is missing
 
     spec = synth.make_spec(args.config)
+    full_h = spec["height"]
+    n_sets = args.sets_per_gpu
+    if args.shard == "rows" and world > 1:
+        # every rank decodes its row tile of all world * sets_per_gpu frame-sets (row_offset keeps v - cy right)
+        spec, _, _ = shard.row_tile_spec(spec, world, rank)
+        n_sets = args.sets_per_gpu * world
     H, W = spec["height"], spec["width"]
     n_phase, n_gray = synth.n_planes(spec)
-    n_sets = args.sets_per_gpu
     bytes_per_set = H * W * synth.algorithmic_bytes_per_pixel(spec)
     bytes_per_launch = n_sets * bytes_per_set
 
@@ -216,7 +224,7 @@ def main():
         except Exception as e:      # the decode-only line above must still be reported
             full, reps, tt = None, 0, None
             gather_error = "%s: %s" % (type(e).__name__, e)
-        gather = {"error": gather_error} if tt is None else {"value": world * n_sets * reps / float(tt[0]), "unit": "frames/s", "steps": reps,
+        gather = {"error": gather_error} if tt is None else {"value": world * args.sets_per_gpu * reps / float(tt[0]), "unit": "frames/s", "steps": reps,
                   "collective": "torch.distributed.gather (%s) of f64 depth maps to rank 0" % ("RCCL" if args.backend == "nccl" else args.backend),
                   "gathered_bytes_per_step": int(world * n_sets * H * W * 8),
                   "gathered_shape": list(full.shape) if (rank == 0 and full is not None) else None}
@@ -243,12 +251,13 @@ def main():
             except Exception:
                 traffic = None
         result = {
-            "metric": "depth_frames_per_sec", "value": world * n_sets * args.steps / t_max, "unit": "frames/s",
+            "metric": "depth_frames_per_sec", "value": world * args.sets_per_gpu * args.steps / t_max, "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": t_max / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32+f64", "data": "synthetic",
             "config": {"workload": "%s: %dx%d, %d-frequency x %d-step temporal unwrap%s + triangulation, %d frame-sets per GPU per step"
                                    % (args.config, W, H, spec["n_freq"], spec["n_steps"], " + %d-bit Gray mask" % spec["gray_bits"] if n_gray else "", n_sets),
-                       "periods": spec["periods"], "sharding": "by frame-set, no data-path collective", "kernel_variant": args.variant},
+                       "periods": spec["periods"], "sharding": ("by frame-set" if args.shard == "framesets" or world == 1 else "by row tile (%d rows of %d per GPU)" % (H, full_h)) + ", no data-path collective",
+                       "kernel_variant": args.variant},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "kernel": ("slx_strip_kernel" if (args.variant in (0, 2) and ((spec["mode"] == 3 and spec["n_steps"] in (4, 8)) or (spec["mode"] in (2, 4) and spec["n_steps"] == 4))) else "slx_fused_kernel") + "<mode %d, F=%d, N=%d>" % (spec["mode"], spec["n_freq"], spec["n_steps"]), "launch_ms": kernel_ms_max,
