@@ -714,7 +714,7 @@ __global__ __launch_bounds__(256) void slx_strip_kernel(const SlxKParams p)
                     //   sy = ((((g0 + m1) - m3) - g4) - m5) + m7,   sx = ((((m1 + g2) + m3) - m5) - g6) - m7,   m_k = RN(g_k r)
                     uint32_t w[8];
 #pragma unroll
-                    for (int k = 0; k < 8; k++) w[k] = *reinterpret_cast<const uint32_t *>(p.phase[f * NS + k] + roff);
+                    for (int k = 0; k < 8; k++) w[k] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(p.phase[f * NS + k] + roff));
                     const float r = p.wy[1];
 #pragma unroll
                     for (int j = 0; j < SLX_QUAD; j++) {
