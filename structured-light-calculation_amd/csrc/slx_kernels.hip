@@ -88,6 +88,19 @@ __device__ __forceinline__ float wrapped_pix_from_diffs(float s2, float c2, floa
 // Two pixels at a time with explicit 2-vectors, so that every multiply / add / fma of the sequence is a packed
 // instruction (v_pk_*_f32 retire two lanes' worth per issue slot); compares and selects stay per component.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+// saturate(-a) and saturate(a * s) to [0, 1], both halves in one packed instruction
+__device__ __forceinline__ f32x2 pk_neg_sat(f32x2 a)
+{
+    f32x2 r;
+    asm("v_pk_mul_f32 %0, %1, -1.0 op_sel_hi:[1,0] clamp" : "=v"(r) : "v"(a));
+    return r;
+}
+__device__ __forceinline__ f32x2 pk_mul_sat(f32x2 a, f32x2 s)
+{
+    f32x2 r;
+    asm("v_pk_mul_f32 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(s));
+    return r;
+}
 __device__ __forceinline__ f32x2 wrapped_pix_from_diffs2(f32x2 s2, f32x2 c2, float Tf)
 {
     const f32x2 as = {__builtin_fabsf(s2.x), __builtin_fabsf(s2.y)}, ac = {__builtin_fabsf(c2.x), __builtin_fabsf(c2.y)};
@@ -100,17 +113,23 @@ __device__ __forceinline__ f32x2 wrapped_pix_from_diffs2(f32x2 s2, f32x2 c2, flo
     f32x2 a = (((kP7 * cc + kP5) * cc + kP3) * cc + kP1) * c;
     const f32x2 a90 = 90.f - a;
     a = f32x2{as.x > ac.x ? a90.x : a.x, as.y > ac.y ? a90.y : a.y};
-    const f32x2 a180 = 180.f - a;
-    a = f32x2{c2.x < 0.f ? a180.x : a.x, c2.y < 0.f ? a180.y : a.y};
-    const f32x2 a360 = 360.f - a;
-    a = f32x2{s2.x < 0.f ? a360.x : a.x, s2.y < 0.f ? a360.y : a.y};
+    // The two sign fix-ups and the final wrap are selects; compares and v_cndmask do not pack, but a saturating
+    // packed multiply does (VOP3P clamp, which hipcc does not emit for f32 pairs): for the integer-valued c2,
+    // m = sat(-c2) is 1 where c2 < 0 and 0 elsewhere, and fma(1 - 2m, a, 180 m) is a where m = 0 and RN(180 - a)
+    // where m = 1 -- the same single rounding as the subtraction.  Likewise m = sat((pix - T) * 2^60) is 1 exactly
+    // where pix > T (the smallest positive difference is an ulp, far above 2^-60) and fma(-T, m, pix) is RN(pix - T) or pix.
+    const f32x2 one = {1.f, 1.f}, mtwo = {-2.f, -2.f};
+    const f32x2 mc = pk_neg_sat(c2);
+    a = __builtin_elementwise_fma(__builtin_elementwise_fma(mtwo, mc, one), a, mc * 180.f);
+    const f32x2 ms = pk_neg_sat(s2);
+    a = __builtin_elementwise_fma(__builtin_elementwise_fma(mtwo, ms, one), a, ms * 360.f);
     const f32x2 d0 = a * kInv360;
     const f32x2 k360 = {kInv360, kInv360}, m360 = {-360.f, -360.f};
     const f32x2 d = __builtin_elementwise_fma(__builtin_elementwise_fma(m360, d0, a), k360, d0);
     f32x2 pix = d * Tf;
     pix = pix + 0.5f;
-    const f32x2 wrapped = pix - Tf;
-    return f32x2{pix.x > Tf ? wrapped.x : pix.x, pix.y > Tf ? wrapped.y : pix.y};
+    const f32x2 mw = pk_mul_sat(pix - Tf, f32x2{0x1p60f, 0x1p60f});
+    return __builtin_elementwise_fma(f32x2{-Tf, -Tf}, mw, pix);
 }
 
 __device__ __forceinline__ float wrapped_pix_4step(float g0, float g1, float g2, float g3, float Tf)
