@@ -36,6 +36,22 @@ constexpr float kInv360 = 1.0f / 360.0f;
 __device__ __forceinline__ float ubyte(uint32_t w, int j) { return (float)((w >> (8 * j)) & 0xffu); }
 __device__ __forceinline__ int ibyte(uint32_t w, int j) { return (int)((w >> (8 * j)) & 0xffu); }
 
+// Two pixels at a time with explicit 2-vectors, so that every multiply / add / fma of the sequence is a packed
+// instruction (v_pk_*_f32 retire two lanes' worth per issue slot); compares and selects stay per component.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// saturate(-a) and saturate(a * s) to [0, 1], both halves in one packed instruction
+__device__ __forceinline__ f32x2 pk_neg_sat(f32x2 a)
+{
+    f32x2 r;
+    asm("v_pk_mul_f32 %0, %1, -1.0 op_sel_hi:[1,0] clamp" : "=v"(r) : "v"(a));
+    return r;
+}
+__device__ __forceinline__ f32x2 pk_mul_sat(f32x2 a, f32x2 s)
+{
+    f32x2 r;
+    asm("v_pk_mul_f32 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(s));
+    return r;
+}
 // (byte J of a) - (byte J of b) in one VALU slot (SDWA operand selects); hipcc finds this form
 // for only some of the 24 differences of a row step.
 template <int J>
@@ -85,22 +101,6 @@ __device__ __forceinline__ float wrapped_pix_from_diffs(float s2, float c2, floa
     return pix;
 }
 
-// Two pixels at a time with explicit 2-vectors, so that every multiply / add / fma of the sequence is a packed
-// instruction (v_pk_*_f32 retire two lanes' worth per issue slot); compares and selects stay per component.
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-// saturate(-a) and saturate(a * s) to [0, 1], both halves in one packed instruction
-__device__ __forceinline__ f32x2 pk_neg_sat(f32x2 a)
-{
-    f32x2 r;
-    asm("v_pk_mul_f32 %0, %1, -1.0 op_sel_hi:[1,0] clamp" : "=v"(r) : "v"(a));
-    return r;
-}
-__device__ __forceinline__ f32x2 pk_mul_sat(f32x2 a, f32x2 s)
-{
-    f32x2 r;
-    asm("v_pk_mul_f32 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(s));
-    return r;
-}
 __device__ __forceinline__ f32x2 wrapped_pix_from_diffs2(f32x2 s2, f32x2 c2, float Tf)
 {
     const f32x2 as = {__builtin_fabsf(s2.x), __builtin_fabsf(s2.y)}, ac = {__builtin_fabsf(c2.x), __builtin_fabsf(c2.y)};
@@ -166,44 +166,41 @@ __device__ __forceinline__ float pix_tail_literal(float sinValue, float cosValue
     return pix;
 }
 
-// n/d for 0 <= n <= d, d in [2^-53, 2^12]: hipcc's f32 division (v_rcp_f32, one Newton step, two residual
-// corrections) without its range scaling and special-case fix-up, which are no-ops in this range.
-__device__ __forceinline__ float div_f32_inrange(float n, float d)
+// R/CDecodePhase.cpp:67-75 for arbitrary float sums (x1, N = 8), all in f32, two pixels at a time.
+//  * the angle's division n/d (0 <= n <= d, d in [2^-53, 2^12]) is hipcc's f32 sequence (v_rcp_f32, one Newton step,
+//    two residual corrections) without its range scaling and special-case fix-up, which are no-ops in this range;
+//  * the casts through double are exact or round identically (the double product of a float and an integer < 2^24
+//    is exact; the double sum with 0.5 is either exact or rounds to the float the f32 add gives), and RN(x/360)
+//    comes from one residual correction (x/360 is never within 1/90 ulp of a rounding tie);
+//  * every mul/add/fma is packed; the sign fix-ups and the wrap are saturating multiplies (see
+//    wrapped_pix_from_diffs2; |x|, |y| are 0 or >= 2^-6 here, far above the 2^-60 the saturation needs).
+__device__ __forceinline__ f32x2 pix_tail_f32x2(f32x2 y, f32x2 x, float Tf)
 {
-    float r = __builtin_amdgcn_rcpf(d);
-    r = __builtin_fmaf(__builtin_fmaf(-d, r, 1.0f), r, r);
-    float q = n * r;
-    q = __builtin_fmaf(__builtin_fmaf(-d, q, n), r, q);
-    return __builtin_fmaf(__builtin_fmaf(-d, q, n), r, q);
-}
-
-// a2 with the in-range division; |x|, |y| <= 2^11 (sums of at most 16 bytes times weights <= 1, scaled by 2/N).
-__device__ __forceinline__ float fast_atan2_deg_inrange(float y, float x)
-{
-    const float ax = __builtin_fabsf(x), ay = __builtin_fabsf(y);
-    const float mx = __builtin_fmaxf(ax, ay), mn = __builtin_fminf(ax, ay);
-    const float c = div_f32_inrange(mn, mx + kEps);                  // ax >= ay: ay/(ax+eps), else ax/(ay+eps)
-    const float cc = c * c;
-    float a = (((kP7 * cc + kP5) * cc + kP3) * cc + kP1) * c;
-    a = (ay > ax) ? 90.f - a : a;
-    a = (x < 0.f) ? 180.f - a : a;
-    a = (y < 0.f) ? 360.f - a : a;
-    return a;
-}
-
-// R/CDecodePhase.cpp:67-75 for arbitrary float sums (x1, N != 4), all in f32: the casts through double are exact
-// or round identically (the double product of a float and an integer < 2^24 is exact; the double sum with 0.5 is
-// either exact or rounds to the float the f32 add gives), and RN(x/360) comes from one residual correction
-// (x/360 is never within 1/90 ulp of a rounding tie).  The angle itself keeps the IEEE division of a2.
-__device__ __forceinline__ float pix_tail_f32(float sinValue, float cosValue, float Tf)
-{
-    const float x = fast_atan2_deg_inrange(sinValue, cosValue);
-    const float d0 = x * kInv360;
-    const float d = __builtin_fmaf(__builtin_fmaf(-360.f, d0, x), kInv360, d0);
-    float pix = d * Tf;
+    const f32x2 ax = {__builtin_fabsf(x.x), __builtin_fabsf(x.y)}, ay = {__builtin_fabsf(y.x), __builtin_fabsf(y.y)};
+    const f32x2 mx = {__builtin_fmaxf(ax.x, ay.x), __builtin_fmaxf(ax.y, ay.y)}, mn = {__builtin_fminf(ax.x, ay.x), __builtin_fminf(ax.y, ay.y)};
+    const f32x2 dd = mx + kEps;
+    f32x2 r = {__builtin_amdgcn_rcpf(dd.x), __builtin_amdgcn_rcpf(dd.y)};
+    const f32x2 one = {1.f, 1.f}, mtwo = {-2.f, -2.f};
+    r = __builtin_elementwise_fma(__builtin_elementwise_fma(-dd, r, one), r, r);
+    f32x2 q = mn * r;
+    q = __builtin_elementwise_fma(__builtin_elementwise_fma(-dd, q, mn), r, q);
+    const f32x2 c = __builtin_elementwise_fma(__builtin_elementwise_fma(-dd, q, mn), r, q);
+    const f32x2 cc = c * c;
+    f32x2 a = (((kP7 * cc + kP5) * cc + kP3) * cc + kP1) * c;
+    const f32x2 a90 = 90.f - a;
+    a = f32x2{ay.x > ax.x ? a90.x : a.x, ay.y > ax.y ? a90.y : a.y};
+    const f32x2 nbig = {-0x1p60f, -0x1p60f};
+    const f32x2 mxn = pk_mul_sat(x, nbig);                          // 1 where x < 0
+    a = __builtin_elementwise_fma(__builtin_elementwise_fma(mtwo, mxn, one), a, mxn * 180.f);
+    const f32x2 myn = pk_mul_sat(y, nbig);                          // 1 where y < 0
+    a = __builtin_elementwise_fma(__builtin_elementwise_fma(mtwo, myn, one), a, myn * 360.f);
+    const f32x2 d0 = a * kInv360;
+    const f32x2 k360 = {kInv360, kInv360}, m360 = {-360.f, -360.f};
+    const f32x2 d = __builtin_elementwise_fma(__builtin_elementwise_fma(m360, d0, a), k360, d0);
+    f32x2 pix = d * Tf;
     pix = pix + 0.5f;
-    pix = (pix > Tf) ? pix - Tf : pix;
-    return pix;
+    const f32x2 mw = pk_mul_sat(pix - Tf, f32x2{0x1p60f, 0x1p60f});
+    return __builtin_elementwise_fma(f32x2{-Tf, -Tf}, mw, pix);
 }
 
 // IEEE-754 correctly rounded num/den without the range scaling and special-case fix-up of the
@@ -597,12 +594,15 @@ __global__ __launch_bounds__(256) void slx_strip_kernel(const SlxKParams p)
 {
     constexpr bool MASKED = MODE == SLX_MODE_MULTIFREQ_GRAYMASK;
     constexpr bool HAS_GRAY = MODE == SLX_MODE_GRAY_PHASE || MASKED;
-    constexpr int NPH = NS == 4 ? F * 4 : 0;      // phase planes in the ring
-    constexpr int NP = NPH + 2 * GB;              // planes in the ring
-    constexpr unsigned ROW_DW = NP * 64;          // one row of the fringe stack in LDS, dwords per wave
+    // The ring moves CHUNKS: with 4 steps a chunk is a whole row of the fringe stack, with 8 steps it is one
+    // frequency of a row (8 planes), so that the ring stays 4 KiB per wave and 4 waves per SIMD still fit.
+    constexpr int CPR = NS == 4 ? 1 : F;          // chunks per row
+    constexpr int NPH = NS == 4 ? F * 4 : 8;      // phase planes in a chunk
+    constexpr int NP = NPH + 2 * GB;              // planes in a chunk
+    constexpr unsigned ROW_DW = NP * 64;          // one chunk in LDS, dwords per wave
     typedef double vec2 __attribute__((ext_vector_type(2)));
     typedef __attribute__((address_space(3))) void lds_void;
-    // LDS per wave: [fringe-stack ring: 2 rows x NP planes x 256 B] [2 KiB depth staging]
+    // LDS per wave: [fringe-stack ring: 2 chunks x NP planes x 256 B] [2 KiB depth staging]
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_raw[];
     const unsigned t = threadIdx.x;
     const unsigned lane = t & 63u;
@@ -654,20 +654,20 @@ __global__ __launch_bounds__(256) void slx_strip_kernel(const SlxKParams p)
     // lane offsets advance by a constant per row: one add (and a clamp for the DMA) instead of a multiply-add
     const unsigned dma_step = step_rows * row_stride;
     const unsigned dma_last = last_row * row_stride + pos.cq * SLX_QUAD;   // rows past the tile: harmless re-read of the last row
-    unsigned dma_off = pos.row * row_stride + pos.cq * SLX_QUAD;           // offset of the next row to issue
+    unsigned dma_off = pos.row * row_stride + pos.cq * SLX_QUAD;           // offset of the row of the next chunk to issue
     unsigned gray_soff[GB > 0 ? 2 * GB : 1];                           // scalar: plane offset + this set's extra offset
 #pragma unroll
     for (int k = 0; k < 2 * GB; k++) gray_soff[k] = p.gray_rel[k] + (unsigned)((long long)pos.set * p.gray_set_delta);
-    auto issue_row = [&](unsigned slot, unsigned) {                    // DMA of the next row of the item into ring[slot]
+    auto issue_chunk = [&](unsigned slot, int cc) {                    // DMA of the item's next chunk (chunk cc of its row) into ring[slot]
         const unsigned voff = dma_off < dma_last ? dma_off : dma_last;
-        dma_off += dma_step;
+        if (cc == CPR - 1) dma_off += dma_step;
         uint32_t *dst = ring + slot * ROW_DW;
         // every byte is read once: nontemporal loads (+1.6 % on config 4) -- except in the Gray-mask mode, whose halo
         // quads are re-read by the neighbouring wave out of L2 (-10 % with nt there)
         constexpr int AUX = MASKED ? 0 : 2;
 #pragma unroll
         for (int k = 0; k < NPH; k++)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void *)(dst + k * 64), 4, voff, p.phase_rel[k], 0, AUX);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void *)(dst + k * 64), 4, voff, p.phase_rel[cc * NPH + k], 0, AUX);
 #pragma unroll
         for (int k = 0; k < 2 * GB; k++)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void *)(dst + (NPH + k) * 64), 4, voff, gray_soff[k], 0, AUX);
@@ -702,16 +702,67 @@ __global__ __launch_bounds__(256) void slx_strip_kernel(const SlxKParams p)
         aD[j] = a * p.P20;
     }
 
-    issue_row(0, 0);
-    if (RB > 1) issue_row(1, 1);
+    const unsigned total_chunks = RB * CPR;
+    issue_chunk(0, 0);
+    if (total_chunks > 1) issue_chunk(1, 1 % CPR);
 
     for (unsigned i = 0; i < RB; i++) {
         const unsigned row = pos.row + i * step_rows;
-        const unsigned slot = i & 1u;
-        // vmcnt retires in issue order: "all but the NP youngest" = everything up to this row's DMA
-        if (i + 1 < RB) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (i > 0) flush_row(i - 1);                                    // last row's stores, one step late
+        float pix[F][SLX_QUAD];
+        uint32_t gw[GB > 0 ? 2 * GB : 1];
+#pragma unroll
+        for (int c = 0; c < CPR; c++) {
+            const unsigned g = i * CPR + c;
+            const unsigned slot = g & 1u;
+            // vmcnt retires in issue order: "all but the NP youngest" = everything up to this chunk's DMA
+            if (g + 1 < total_chunks) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (c == 0 && i > 0) flush_row(i - 1);                      // last row's stores, one step late
+            if (row < H) {
+                const uint32_t *src = ring + slot * ROW_DW + lane;
+                if constexpr (NS != 4) {                                // x1: weighted sums, k ascending, no contraction
+                    static_assert(NS == 8 || NS == 4, "the x1 fast path is written for 8 steps");
+                    // 8 steps: weights (cos, sin)(k pi/4) = (1,0) (r,r) (0,1) (-r,r) (-1,0) (-r,-r) (0,-1) (r,-r), r = wy[1]
+                    // (checked on the host).  Adding g*0 changes nothing and g*(+-1) is exact, so the k-ascending sums are
+                    //   sy = ((((g0 + m1) - m3) - g4) - m5) + m7,   sx = ((((m1 + g2) + m3) - m5) - g6) - m7,   m_k = RN(g_k r)
+                    float sy[SLX_QUAD], sx[SLX_QUAD];
+                    uint32_t w[8];
+#pragma unroll
+                    for (int k = 0; k < 8; k++) w[k] = src[k * 64];
+                    const float r = p.wy[1];
+#pragma unroll
+                    for (int j = 0; j < SLX_QUAD; j++) {
+                        const float m1 = ubyte(w[1], j) * r, m3 = ubyte(w[3], j) * r, m5 = ubyte(w[5], j) * r, m7 = ubyte(w[7], j) * r;
+                        sy[j] = ((((ubyte(w[0], j) + m1) - m3) - ubyte(w[4], j)) - m5) + m7;
+                        sx[j] = ((((m1 + ubyte(w[2], j)) + m3) - m5) - ubyte(w[6], j)) - m7;
+                    }
+                    const f32x2 p01 = pix_tail_f32x2(f32x2{sy[0], sy[1]} * p.wscale, f32x2{sx[0], sx[1]} * p.wscale, Tf[c]);
+                    const f32x2 p23 = pix_tail_f32x2(f32x2{sy[2], sy[3]} * p.wscale, f32x2{sx[2], sx[3]} * p.wscale, Tf[c]);
+                    pix[c][0] = p01.x;
+                    pix[c][1] = p01.y;
+                    pix[c][2] = p23.x;
+                    pix[c][3] = p23.y;
+                }
+#pragma unroll
+                for (int f = 0; f < (NS == 4 ? F : 0); f++) {
+                    const uint32_t w0 = src[(f * 4 + 0) * 64], w1 = src[(f * 4 + 1) * 64];
+                    const uint32_t w2 = src[(f * 4 + 2) * 64], w3 = src[(f * 4 + 3) * 64];
+                    const f32x2 p01 = wrapped_pix_from_diffs2(f32x2{(float)byte_diff<0>(w0, w2), (float)byte_diff<1>(w0, w2)},
+                                                              f32x2{(float)byte_diff<0>(w1, w3), (float)byte_diff<1>(w1, w3)}, Tf[f]);
+                    const f32x2 p23 = wrapped_pix_from_diffs2(f32x2{(float)byte_diff<2>(w0, w2), (float)byte_diff<3>(w0, w2)},
+                                                              f32x2{(float)byte_diff<2>(w1, w3), (float)byte_diff<3>(w1, w3)}, Tf[f]);
+                    pix[f][0] = p01.x;
+                    pix[f][1] = p01.y;
+                    pix[f][2] = p23.x;
+                    pix[f][3] = p23.y;
+                }
+#pragma unroll
+                for (int k = 0; k < 2 * GB; k++) gw[k] = src[(NPH + k) * 64];
+                // the slot is free once it has been read: chunk g+2 goes into it
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+            if (g + 2 < total_chunks) issue_chunk(slot, (c + 2) % CPR); // rows past the tile: keeps the DMA count per step fixed
+        }
 
         double z[SLX_QUAD];
         if constexpr (MASKED) {                                         // the mask pass below runs for every lane
@@ -720,51 +771,6 @@ __global__ __launch_bounds__(256) void slx_strip_kernel(const SlxKParams p)
         }
         int v0[SLX_QUAD] = {1, 1, 1, 1};                                // x3: lanes without pixels never veto
         if (row < H) {
-            const uint32_t *src = ring + slot * ROW_DW + lane;
-            float pix[F][SLX_QUAD];
-            if constexpr (NS != 4) {                                    // x1: weighted sums, k ascending, no contraction
-                const size_t roff = pset + (size_t)(row * row_stride + pos.cq * SLX_QUAD);
-#pragma unroll
-                for (int f = 0; f < F; f++) {
-                    float sy[SLX_QUAD], sx[SLX_QUAD];
-                    static_assert(NS == 8 || NS == 4, "the x1 fast path is written for 8 steps");
-                    // 8 steps: weights (cos, sin)(k pi/4) = (1,0) (r,r) (0,1) (-r,r) (-1,0) (-r,-r) (0,-1) (r,-r), r = wy[1]
-                    // (checked on the host).  Adding g*0 changes nothing and g*(+-1) is exact, so the k-ascending sums are
-                    //   sy = ((((g0 + m1) - m3) - g4) - m5) + m7,   sx = ((((m1 + g2) + m3) - m5) - g6) - m7,   m_k = RN(g_k r)
-                    uint32_t w[8];
-#pragma unroll
-                    for (int k = 0; k < 8; k++) w[k] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(p.phase[f * NS + k] + roff));
-                    const float r = p.wy[1];
-#pragma unroll
-                    for (int j = 0; j < SLX_QUAD; j++) {
-                        const float m1 = ubyte(w[1], j) * r, m3 = ubyte(w[3], j) * r, m5 = ubyte(w[5], j) * r, m7 = ubyte(w[7], j) * r;
-                        sy[j] = ((((ubyte(w[0], j) + m1) - m3) - ubyte(w[4], j)) - m5) + m7;
-                        sx[j] = ((((m1 + ubyte(w[2], j)) + m3) - m5) - ubyte(w[6], j)) - m7;
-                    }
-#pragma unroll
-                    for (int j = 0; j < SLX_QUAD; j++) pix[f][j] = pix_tail_f32(sy[j] * p.wscale, sx[j] * p.wscale, Tf[f]);
-                }
-            }
-#pragma unroll
-            for (int f = 0; f < (NS == 4 ? F : 0); f++) {
-                const uint32_t w0 = src[(f * 4 + 0) * 64], w1 = src[(f * 4 + 1) * 64];
-                const uint32_t w2 = src[(f * 4 + 2) * 64], w3 = src[(f * 4 + 3) * 64];
-                const f32x2 p01 = wrapped_pix_from_diffs2(f32x2{(float)byte_diff<0>(w0, w2), (float)byte_diff<1>(w0, w2)},
-                                                          f32x2{(float)byte_diff<0>(w1, w3), (float)byte_diff<1>(w1, w3)}, Tf[f]);
-                const f32x2 p23 = wrapped_pix_from_diffs2(f32x2{(float)byte_diff<2>(w0, w2), (float)byte_diff<3>(w0, w2)},
-                                                          f32x2{(float)byte_diff<2>(w1, w3), (float)byte_diff<3>(w1, w3)}, Tf[f]);
-                pix[f][0] = p01.x;
-                pix[f][1] = p01.y;
-                pix[f][2] = p23.x;
-                pix[f][3] = p23.y;
-            }
-            uint32_t gw[GB > 0 ? 2 * GB : 1];
-#pragma unroll
-            for (int k = 0; k < 2 * GB; k++) gw[k] = src[(NPH + k) * 64];
-            // the slot is free once it has been read: row i+2 goes into it
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (i + 2 < RB) issue_row(slot, i + 2);
-
             double U[SLX_QUAD];
             int bin[SLX_QUAD] = {0, 0, 0, 0};
             if constexpr (HAS_GRAY) {
@@ -857,8 +863,6 @@ __global__ __launch_bounds__(256) void slx_strip_kernel(const SlxKParams p)
                 stage[2 * lane + 0] = vec2{z[0], z[1]};
                 stage[2 * lane + 1] = vec2{z[2], z[3]};
             }
-        } else if (i + 2 < RB) {
-            issue_row(slot, i + 2);                                     // keeps the DMA count per step fixed
         }
         if constexpr (MASKED) {
             // x3: 3-tap horizontal AND.  Pixel u0-1 lives in lane-1, pixel u0+4 in lane+1 (DPP wave shifts; every
@@ -1154,13 +1158,13 @@ int slx_launch_fused(const SlxKParams &kp_in, int mode, bool aux, int n_sets, in
             kp.gray_set_delta = delta;
         }
     }
-    // LDS per wave: 2 rows of the fringe stack ((4 n_freq + 2 gb) planes * 256 B each) + 2 KiB of depth staging
+    // LDS per wave: 2 ring chunks ((4 n_freq + 2 gb) planes with 4 steps, 8 planes with 8 steps, 256 B each) + 2 KiB of depth staging
     unsigned waves_per_wg = 4u;
     if (const char *e = getenv("SLX_STRIP_WAVES")) {               // tuning hook
         const int v = atoi(e);
         if (v >= 1 && v <= 4) waves_per_wg = (unsigned)v;
     }
-    const unsigned lds_wave = 2u * ((kp.n_steps == 4 ? (unsigned)kp.n_freq * 4u : 0u) + 2u * (unsigned)gb) * 256u + 2048u;
+    const unsigned lds_wave = 2u * ((kp.n_steps == 4 ? (unsigned)kp.n_freq * 4u : 8u) + 2u * (unsigned)gb) * 256u + 2048u;
     if (lds_wave * waves_per_wg > 32u * 1024u) waves_per_wg = 2u;       // keep >= 5 workgroups per CU
     const unsigned threads = waves_per_wg * 64u;
     const unsigned long long need_wgs = (kp.total_items + waves_per_wg - 1) / waves_per_wg;
