@@ -54,6 +54,25 @@ __device__ __forceinline__ f32x2 pk_mul_sat(f32x2 a, f32x2 s)
 }
 // (byte J of a) - (byte J of b) in one VALU slot (SDWA operand selects); hipcc finds this form
 // for only some of the 24 differences of a row step.
+// Byte J of a minus byte J of b as a float, times 2^-149: the SDWA byte select zero-extends the byte into the float
+// operand, where it is the denormal byte * 2^-149, and the subtraction of two denormals is exact (f32 denormals are on:
+// .amdhsa_float_denorm_mode_32 3, hipcc's default for gfx9).  One instruction instead of an integer SDWA subtraction
+// plus v_cvt_f32_i32; the caller rescales two such differences with one packed multiply.
+template <int J>
+__device__ __forceinline__ float byte_diff_denorm(uint32_t a, uint32_t b)
+{
+    float d;
+    if constexpr (J == 0)
+        asm("v_sub_f32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:BYTE_0" : "=v"(d) : "v"(a), "v"(b));
+    else if constexpr (J == 1)
+        asm("v_sub_f32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:BYTE_1" : "=v"(d) : "v"(a), "v"(b));
+    else if constexpr (J == 2)
+        asm("v_sub_f32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:BYTE_2" : "=v"(d) : "v"(a), "v"(b));
+    else
+        asm("v_sub_f32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:BYTE_3" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+
 template <int J>
 __device__ __forceinline__ int byte_diff(uint32_t a, uint32_t b)
 {
@@ -101,10 +120,16 @@ __device__ __forceinline__ float wrapped_pix_from_diffs(float s2, float c2, floa
     return pix;
 }
 
+// SCALED: s2, c2 carry the integer differences times 2^-23 (byte_diff_scaled below).  Every use of them is invariant
+// under a power-of-two scale that stays inside the normal range -- max/min/compare, v_rcp_f32 (a function of the
+// mantissa), the quotient and its residual, the sign tests -- so the result is the same bit for bit; only the
+// 0/0 guard and the saturation factor of the sign tests move with the scale.
+template <bool SCALED = false>
 __device__ __forceinline__ f32x2 wrapped_pix_from_diffs2(f32x2 s2, f32x2 c2, float Tf)
 {
+    constexpr float kGuard = SCALED ? 0x1p-23f : 1.0f;
     const f32x2 as = {__builtin_fabsf(s2.x), __builtin_fabsf(s2.y)}, ac = {__builtin_fabsf(c2.x), __builtin_fabsf(c2.y)};
-    const f32x2 mx = {__builtin_fmaxf(__builtin_fmaxf(as.x, ac.x), 1.0f), __builtin_fmaxf(__builtin_fmaxf(as.y, ac.y), 1.0f)};
+    const f32x2 mx = {__builtin_fmaxf(__builtin_fmaxf(as.x, ac.x), kGuard), __builtin_fmaxf(__builtin_fmaxf(as.y, ac.y), kGuard)};
     const f32x2 mn = {__builtin_fminf(as.x, ac.x), __builtin_fminf(as.y, ac.y)};
     const f32x2 r = {__builtin_amdgcn_rcpf(mx.x), __builtin_amdgcn_rcpf(mx.y)};
     const f32x2 q0 = mn * r;
@@ -119,9 +144,9 @@ __device__ __forceinline__ f32x2 wrapped_pix_from_diffs2(f32x2 s2, f32x2 c2, flo
     // where m = 1 -- the same single rounding as the subtraction.  Likewise m = sat((pix - T) * 2^60) is 1 exactly
     // where pix > T (the smallest positive difference is an ulp, far above 2^-60) and fma(-T, m, pix) is RN(pix - T) or pix.
     const f32x2 one = {1.f, 1.f}, mtwo = {-2.f, -2.f};
-    const f32x2 mc = pk_neg_sat(c2);
+    const f32x2 mc = SCALED ? pk_mul_sat(c2, f32x2{-0x1p60f, -0x1p60f}) : pk_neg_sat(c2);
     a = __builtin_elementwise_fma(__builtin_elementwise_fma(mtwo, mc, one), a, mc * 180.f);
-    const f32x2 ms = pk_neg_sat(s2);
+    const f32x2 ms = SCALED ? pk_mul_sat(s2, f32x2{-0x1p60f, -0x1p60f}) : pk_neg_sat(s2);
     a = __builtin_elementwise_fma(__builtin_elementwise_fma(mtwo, ms, one), a, ms * 360.f);
     const f32x2 d0 = a * kInv360;
     const f32x2 k360 = {kInv360, kInv360}, m360 = {-360.f, -360.f};
@@ -234,9 +259,9 @@ __device__ __forceinline__ double tri_depth(double Uv, double cC, double cD, dou
     } else {
         zz = -num / (cC - cD * Uv);
     }
-    if ((zz < fov_min) || (zz > fov_max)) zz = 0.0;
-    if (Uv == 0.0 || !valid) zz = 0.0;
-    return zz;
+    // one select for the three reasons to drop the depth (a NaN depth fails no test and stays, as in the reference)
+    const bool drop = (zz < fov_min) | (zz > fov_max) | (Uv == 0.0) | !valid;
+    return drop ? 0.0 : zz;
 }
 
 // x2 for one pixel and one stage: k = (int)floor((Uprev - pf)/T + 0.5), U = pf + k*T.
@@ -747,10 +772,12 @@ __global__ __launch_bounds__(256) void slx_strip_kernel(const SlxKParams p)
                 for (int f = 0; f < (NS == 4 ? F : 0); f++) {
                     const uint32_t w0 = src[(f * 4 + 0) * 64], w1 = src[(f * 4 + 1) * 64];
                     const uint32_t w2 = src[(f * 4 + 2) * 64], w3 = src[(f * 4 + 3) * 64];
-                    const f32x2 p01 = wrapped_pix_from_diffs2(f32x2{(float)byte_diff<0>(w0, w2), (float)byte_diff<1>(w0, w2)},
-                                                              f32x2{(float)byte_diff<0>(w1, w3), (float)byte_diff<1>(w1, w3)}, Tf[f]);
-                    const f32x2 p23 = wrapped_pix_from_diffs2(f32x2{(float)byte_diff<2>(w0, w2), (float)byte_diff<3>(w0, w2)},
-                                                              f32x2{(float)byte_diff<2>(w1, w3), (float)byte_diff<3>(w1, w3)}, Tf[f]);
+                    // differences as denormals (x 2^-149), rescaled to x 2^-23 by one packed multiply per pair
+                    const f32x2 kUp = {0x1p126f, 0x1p126f};
+                    const f32x2 p01 = wrapped_pix_from_diffs2<true>(f32x2{byte_diff_denorm<0>(w0, w2), byte_diff_denorm<1>(w0, w2)} * kUp,
+                                                                    f32x2{byte_diff_denorm<0>(w1, w3), byte_diff_denorm<1>(w1, w3)} * kUp, Tf[f]);
+                    const f32x2 p23 = wrapped_pix_from_diffs2<true>(f32x2{byte_diff_denorm<2>(w0, w2), byte_diff_denorm<3>(w0, w2)} * kUp,
+                                                                    f32x2{byte_diff_denorm<2>(w1, w3), byte_diff_denorm<3>(w1, w3)} * kUp, Tf[f]);
                     pix[f][0] = p01.x;
                     pix[f][1] = p01.y;
                     pix[f][2] = p23.x;
