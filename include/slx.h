@@ -22,7 +22,8 @@
  *   CDecode*::GetResult, m_x/y/zMat, m_ProjectorU
  *        R/CDecodePhase.cpp:99, R/CCalculation.h:29-38    -> slx_get_output / slx_get_depth
  *   cv::FileStorage (calibration) R/CCalculation.cpp:124  -> slx_read_calibration_yaml
- *   cv::imread (CSensor)          R/CSensorV.cpp:111      -> slx_read_bmp_gray (+ slx::CSensor, csrc/sensor.hpp)
+ *   cv::imread (CSensor)          R/CSensorV.cpp:111      -> slx_read_bmp_gray / slx_read_pgm_gray (+ slx::CSensor, csrc/sensor.hpp)
+ *   CSensor::GetCamPicture loop   R/CSensorV.cpp:171      -> slx_pipe_* (pinned host slots, copy/decode overlap)
  *   CCalculation::Result          R/CCalculation.cpp:323  -> slx_get_point_cloud (+ slx::CCalculation::Result text writer)
  *   CCalculation::CalculateOther  R/CCalculation.cpp:208  -> slx_track_begin / slx_track_next (+ slx::CCalculation::CalculateOther)
  *   ~CCalculation / ReleaseSpace  R/CCalculation.cpp:30   -> slx_destroy
@@ -191,11 +192,43 @@ int slx_debug_stamps(slx_ctx *ctx, unsigned long long *device_words, size_t n_wo
 /* Selects the kernel variant (0 = default); tuning / A-B benchmarking only. */
 int slx_set_variant(slx_ctx *ctx, int variant);
 
+/* ---- frame ingest pipeline: the live loop around the path -------------------------------------
+ * Role of CSensor::GetCamPicture -> CDecode*::SetMat -> Decode in a capture loop (R/CSensorV.cpp:171-179,
+ * R/CCalculation.cpp:171-205), for frame-sets that arrive in HOST memory: `slots` pinned host buffers, each holding
+ * `sets_per_slot` frame-sets, move through copy-in -> decode -> copy-out on three HIP streams, so the PCIe transfers of
+ * one slot overlap the decode of another.  Layout of a slot's input: [set][plane][height][pitch] bytes, planes in the
+ * order phase f*N+k, then Gray 2b (pattern), 2b+1 (inverse); pitch = width rounded up to 4.  The result is the mode's
+ * primary output (depth; pix for PHASE_ONLY; gray for GRAY_ONLY), [set][height][width] doubles.
+ * Slot life cycle: acquire (host fills the pinned input) -> submit -> collect (oldest submitted first; the host reads
+ * the pinned result) -> the slot is free again at its next acquire.  acquire fails with SLX_ERR_NOT_CONFIGURED when every
+ * slot is submitted or collected-but-not-yet-reused in an order that leaves none free (collect first).
+ * One pipe per context; the context's own frames / outputs (slx_set_frame, slx_decode) are not touched. */
+typedef struct slx_pipe slx_pipe;
+typedef struct {
+    int slots;            /* >= 2 */
+    int sets_per_slot;    /* >= 1 frame-sets decoded by one launch */
+    int host_result;      /* 1: copy the result back into pinned host memory; 0: leave it on the device */
+} slx_pipe_config;
+int slx_pipe_create(slx_ctx *ctx, const slx_pipe_config *cfg, slx_pipe **out);
+void slx_pipe_destroy(slx_pipe *pipe);
+/* Geometry of a slot: planes per frame-set, bytes between rows, planes and frame-sets of the input. */
+int slx_pipe_layout(const slx_pipe *pipe, int *n_planes, size_t *pitch, size_t *plane_bytes, size_t *set_bytes);
+/* Pinned input buffer of the next free slot. */
+int slx_pipe_acquire(slx_pipe *pipe, uint8_t **host_in);
+/* Hands the acquired slot to the GPU; returns at once.  n_sets <= sets_per_slot frame-sets are valid in it. */
+int slx_pipe_submit(slx_pipe *pipe, int n_sets);
+/* Waits for the oldest submitted slot.  host_result (pinned, NULL when host_result == 0), device_result and n_sets may be
+ * NULL when not wanted.  The pointers stay valid until that slot is acquired again. */
+int slx_pipe_collect(slx_pipe *pipe, const double **host_result, const double **device_result, int *n_sets);
+const char *slx_pipe_last_error(const slx_pipe *pipe);
+
 /* ---- file formats of a DynaFrame data directory (host only, no GPU needed) ----
  * 8-bit grey pixels of an uncompressed BMP (8-bit paletted or 24/32-bit colour, converted like
  * imread(..., CV_LOAD_IMAGE_GRAYSCALE), R/CSensorV.cpp:111-114), top-down, dense.  pixels == NULL: only the size.
  * SLX_ERR_UNAVAILABLE: missing or unsupported file. */
 int slx_read_bmp_gray(const char *path, uint8_t *pixels, size_t capacity, int *rows, int *cols);
+/* Same contract for a binary PGM (P5, maxval <= 255), the other 8-bit format cv::imread takes. */
+int slx_read_pgm_gray(const char *path, uint8_t *pixels, size_t capacity, int *rows, int *cols);
 /* CamMat, ProMat, R, T of the cv::FileStorage YAML Init reads (R/CCalculation.cpp:124-132; format of R/Result.yml). */
 int slx_read_calibration_yaml(const char *path, double cam[9], double pro[9], double rot[9], double trans[3]);
 

@@ -30,7 +30,8 @@ SYMBOLS = [
     "slx_validate_config", "slx_create", "slx_destroy", "slx_last_error", "slx_set_gray_lut",
     "slx_set_frame", "slx_decode", "slx_decode_batch", "slx_synchronize", "slx_get_output",
     "slx_get_depth", "slx_get_point_cloud", "slx_track_begin", "slx_track_next", "slx_output_device_ptr", "slx_get_calibration", "slx_enable_timing",
-    "slx_last_decode_ms", "slx_debug_stamps", "slx_set_variant", "slx_read_bmp_gray", "slx_read_calibration_yaml", "slx_version",
+    "slx_last_decode_ms", "slx_debug_stamps", "slx_set_variant", "slx_read_bmp_gray", "slx_read_pgm_gray", "slx_read_calibration_yaml", "slx_version",
+    "slx_pipe_create", "slx_pipe_destroy", "slx_pipe_layout", "slx_pipe_acquire", "slx_pipe_submit", "slx_pipe_collect", "slx_pipe_last_error",
 ]
 
 
@@ -44,6 +45,10 @@ class SlxConfig(C.Structure):
         ("cam", C.c_double * 9), ("pro", C.c_double * 9), ("rot", C.c_double * 9), ("trans", C.c_double * 3),
         ("device", C.c_int), ("aux_outputs", C.c_uint),
     ]
+
+
+class SlxPipeConfig(C.Structure):
+    _fields_ = [("slots", C.c_int), ("sets_per_slot", C.c_int), ("host_result", C.c_int)]
 
 
 class SlxError(RuntimeError):
@@ -87,9 +92,19 @@ def lib():
         L.slx_set_variant.argtypes = [vp, C.c_int]
         L.slx_debug_stamps.argtypes = [vp, vp, sz]
         L.slx_read_bmp_gray.argtypes = [C.c_char_p, vp, sz, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.slx_read_pgm_gray.argtypes = [C.c_char_p, vp, sz, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.slx_read_calibration_yaml.argtypes = [C.c_char_p] + [C.POINTER(C.c_double)] * 4
+        L.slx_pipe_create.argtypes = [vp, C.POINTER(SlxPipeConfig), C.POINTER(vp)]
+        L.slx_pipe_destroy.argtypes = [vp]
+        L.slx_pipe_destroy.restype = None
+        L.slx_pipe_layout.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(sz), C.POINTER(sz), C.POINTER(sz)]
+        L.slx_pipe_acquire.argtypes = [vp, C.POINTER(vp)]
+        L.slx_pipe_submit.argtypes = [vp, C.c_int]
+        L.slx_pipe_collect.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_int)]
+        L.slx_pipe_last_error.argtypes = [vp]
+        L.slx_pipe_last_error.restype = C.c_char_p
         for name in SYMBOLS:
-            if name not in ("slx_destroy", "slx_last_error"):
+            if name not in ("slx_destroy", "slx_last_error", "slx_pipe_destroy", "slx_pipe_last_error"):
                 getattr(L, name).restype = C.c_int
         _lib = L
     return _lib
@@ -296,17 +311,83 @@ class Context:
 VARIANT_AUTO, VARIANT_GENERIC, VARIANT_STRIP, VARIANT_GENERIC_FAST = range(4)
 
 
-def read_bmp_gray(path):
-    """uint8 [rows, cols] of an uncompressed BMP, converted like imread(..., CV_LOAD_IMAGE_GRAYSCALE)."""
+class Pipe:
+    """Frame ingest pipeline over a Context (slx_pipe_*): pinned host slots, copy-in / decode / copy-out overlapped.
+
+        pipe = Pipe(ctx, slots=3, sets_per_slot=8)
+        buf = pipe.acquire()          # uint8 [sets_per_slot, planes, H, pitch], pinned: write the frames here
+        pipe.submit(n_sets)
+        z = pipe.collect()            # float64 [n_sets, H, W] view of the pinned result, valid until the slot is reused
+    """
+
+    def __init__(self, ctx, slots=2, sets_per_slot=1, host_result=True):
+        self._ctx = ctx
+        self._h = C.c_void_p()
+        cfg = SlxPipeConfig(slots, sets_per_slot, 1 if host_result else 0)
+        rc = lib().slx_pipe_create(ctx._h, C.byref(cfg), C.byref(self._h))
+        if rc != OK:
+            self._h = C.c_void_p()
+            raise SlxError(rc, ctx.last_error())
+        n, pitch, plane, sset = C.c_int(), C.c_size_t(), C.c_size_t(), C.c_size_t()
+        lib().slx_pipe_layout(self._h, C.byref(n), C.byref(pitch), C.byref(plane), C.byref(sset))
+        self.n_planes, self.pitch, self.plane_bytes, self.set_bytes = n.value, pitch.value, plane.value, sset.value
+        self.sets_per_slot, self.host_result = sets_per_slot, bool(host_result)
+        self.height, self.width = ctx.spec["height"], ctx.spec["width"]
+
+    def close(self):
+        if self._h:
+            lib().slx_pipe_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != OK:
+            raise SlxError(rc, lib().slx_pipe_last_error(self._h).decode())
+
+    def acquire(self):
+        p = C.c_void_p()
+        self._check(lib().slx_pipe_acquire(self._h, C.byref(p)))
+        buf = (C.c_uint8 * (self.set_bytes * self.sets_per_slot)).from_address(p.value)
+        return np.frombuffer(buf, dtype=np.uint8).reshape(self.sets_per_slot, self.n_planes, self.height, self.pitch)
+
+    def submit(self, n_sets=None):
+        self._check(lib().slx_pipe_submit(self._h, self.sets_per_slot if n_sets is None else int(n_sets)))
+
+    def collect(self, device=False):
+        """float64 [n_sets, H, W] view of the pinned result (or, device=True, the device address and n_sets)."""
+        h, d, n = C.c_void_p(), C.c_void_p(), C.c_int()
+        self._check(lib().slx_pipe_collect(self._h, C.byref(h), C.byref(d), C.byref(n)))
+        if device or not self.host_result:
+            return d.value, n.value
+        buf = (C.c_double * (n.value * self.height * self.width)).from_address(h.value)
+        return np.frombuffer(buf, dtype=np.float64).reshape(n.value, self.height, self.width)
+
+
+def _read_gray_file(fn, path):
     r, c = C.c_int(), C.c_int()
-    rc = lib().slx_read_bmp_gray(path.encode(), None, 0, C.byref(r), C.byref(c))
+    rc = fn(path.encode(), None, 0, C.byref(r), C.byref(c))
     if rc != OK:
         raise SlxError(rc, "cannot read %s" % path)
     a = np.empty((r.value, c.value), dtype=np.uint8)
-    rc = lib().slx_read_bmp_gray(path.encode(), a.ctypes.data, a.size, C.byref(r), C.byref(c))
+    rc = fn(path.encode(), a.ctypes.data, a.size, C.byref(r), C.byref(c))
     if rc != OK:
         raise SlxError(rc, "cannot read %s" % path)
     return a
+
+
+def read_bmp_gray(path):
+    """uint8 [rows, cols] of an uncompressed BMP, converted like imread(..., CV_LOAD_IMAGE_GRAYSCALE)."""
+    return _read_gray_file(lib().slx_read_bmp_gray, path)
+
+
+def read_pgm_gray(path):
+    """uint8 [rows, cols] of a binary PGM (P5, maxval <= 255)."""
+    return _read_gray_file(lib().slx_read_pgm_gray, path)
 
 
 def read_calibration_yaml(path):

@@ -163,7 +163,10 @@ bool CSensor::LoadDatas(int groupNum)
     for (int i = 0; i < n; i++) {
         std::ostringstream name;
         name << filePath << fileName << i << m_dataFileSuffix;
-        if (!ReadBmpGray(name.str(), m_dataMats[(size_t)i], m_rows[(size_t)i], m_cols[(size_t)i])) {
+        std::ostringstream pgm;                                   // same name as a PGM: data sets converted from the BMPs
+        pgm << filePath << fileName << i << ".pgm";
+        if (!ReadBmpGray(name.str(), m_dataMats[(size_t)i], m_rows[(size_t)i], m_cols[(size_t)i]) &&
+            !ReadPgmGray(pgm.str(), m_dataMats[(size_t)i], m_rows[(size_t)i], m_cols[(size_t)i])) {
             // the reference reports and carries on with an empty Mat (R/CSensorV.cpp:122-129); here the load fails
             m_err = "CSensor::LoadPatterns::<Read>, imread error: " + name.str();
             ok = false;
@@ -213,9 +216,50 @@ int CCalculation::CalculateOther(CSensor &sensor, const std::string &pointCloudP
     return done;
 }
 
+// Binary PGM: "P5" <width> <height> <maxval> <one whitespace byte> <rows top-down>; '#' starts a comment in the header.
+bool ReadPgmGray(const std::string &path, std::vector<uint8_t> &pixels, int &rows, int &cols)
+{
+    std::ifstream f(path.c_str(), std::ios::in | std::ios::binary);
+    if (!f) return false;
+    std::vector<unsigned char> buf((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+    if (buf.size() < 7 || buf[0] != 'P' || buf[1] != '5') return false;
+    size_t pos = 2;
+    long val[3] = {0, 0, 0};
+    for (int k = 0; k < 3; k++) {
+        for (;;) {                                               // whitespace and comments before the number
+            if (pos >= buf.size()) return false;
+            const unsigned char ch = buf[pos];
+            if (ch == '#') {
+                while (pos < buf.size() && buf[pos] != '\n') pos++;
+            } else if (ch == ' ' || ch == '\t' || ch == '\r' || ch == '\n') {
+                pos++;
+            } else {
+                break;
+            }
+        }
+        if (buf[pos] < '0' || buf[pos] > '9') return false;
+        long v = 0;
+        while (pos < buf.size() && buf[pos] >= '0' && buf[pos] <= '9') {
+            v = v * 10 + (buf[pos] - '0');
+            if (v > (1l << 30)) return false;
+            pos++;
+        }
+        val[k] = v;
+    }
+    if (pos >= buf.size()) return false;
+    pos++;                                                       // the single whitespace byte after maxval
+    const long w = val[0], h = val[1], maxval = val[2];
+    if (w <= 0 || h <= 0 || maxval <= 0 || maxval > 255) return false;   // 16-bit PGMs are not 8-bit fringe images
+    if (pos + (size_t)w * (size_t)h > buf.size()) return false;
+    rows = (int)h;
+    cols = (int)w;
+    pixels.assign(buf.begin() + (long)pos, buf.begin() + (long)pos + w * h);
+    return true;
+}
+
 }  // namespace slx
 
-// ---- plain-C access to the two file readers (declared in include/slx.h) ----
+// ---- plain-C access to the file readers (declared in include/slx.h) ----
 extern "C" {
 
 int slx_read_bmp_gray(const char *path, uint8_t *pixels, size_t capacity, int *rows, int *cols)
@@ -224,6 +268,20 @@ int slx_read_bmp_gray(const char *path, uint8_t *pixels, size_t capacity, int *r
     std::vector<uint8_t> px;
     int r = 0, c = 0;
     if (!slx::ReadBmpGray(path, px, r, c)) return SLX_ERR_UNAVAILABLE;
+    *rows = r;
+    *cols = c;
+    if (!pixels) return SLX_OK;                                   // size query
+    if (capacity < px.size()) return SLX_ERR_INVALID_ARG;
+    std::memcpy(pixels, px.data(), px.size());
+    return SLX_OK;
+}
+
+int slx_read_pgm_gray(const char *path, uint8_t *pixels, size_t capacity, int *rows, int *cols)
+{
+    if (!path || !rows || !cols) return SLX_ERR_INVALID_ARG;
+    std::vector<uint8_t> px;
+    int r = 0, c = 0;
+    if (!slx::ReadPgmGray(path, px, r, c)) return SLX_ERR_UNAVAILABLE;
     *rows = r;
     *cols = c;
     if (!pixels) return SLX_OK;                                   // size query

@@ -21,6 +21,9 @@ namespace slx {
 // Rows come out top-down, densely packed.  Returns false on a missing / unsupported file.
 bool ReadBmpGray(const std::string &path, std::vector<uint8_t> &pixels, int &rows, int &cols);
 
+// 8-bit binary PGM ("P5", maxval <= 255), the other grey format cv::imread accepts.
+bool ReadPgmGray(const std::string &path, std::vector<uint8_t> &pixels, int &rows, int &cols);
+
 // The calibration file Init reads: YAML 1.0 with !!opencv-matrix blocks named CamMat, ProMat, R, T.
 bool ReadCalibrationYaml(const std::string &path, Calibration &calib);
 

@@ -638,6 +638,200 @@ int slx_track_next(slx_ctx *ctx, const uint8_t *image, size_t stride_bytes, int 
     return SLX_OK;
 }
 
+// ---- frame ingest pipeline ---------------------------------------------------------
+// Three streams, one event per stage and slot:
+//   copy-in  (h2d stream):    hipMemcpyAsync pinned -> device input               -> ev_in
+//   decode   (compute stream): waits ev_in, slx_decode_batch on the slot's buffers  -> ev_dec
+//   copy-out (d2h stream):    waits ev_dec, hipMemcpyAsync device result -> pinned  -> ev_out
+// A slot's buffers are touched again only after slx_pipe_collect has waited for its last event, so consecutive slots
+// overlap freely: while slot k decodes, slot k+1 copies in and slot k-1 copies out (PCIe is full duplex).
+struct slx_pipe {
+    enum State { FREE, ACQUIRED, SUBMITTED, COLLECTED };
+    struct Slot {
+        uint8_t *h_in = nullptr, *d_in = nullptr;
+        double *h_out = nullptr, *d_out = nullptr;
+        hipEvent_t ev_in = nullptr, ev_dec = nullptr, ev_out = nullptr;
+        State state = FREE;
+        int n_sets = 0;
+        unsigned long long ticket = 0;                             // submit order
+    };
+    slx_ctx *ctx = nullptr;
+    slx_pipe_config cfg{};
+    std::vector<Slot> slot;
+    hipStream_t s_in = nullptr, s_dec = nullptr, s_out = nullptr;
+    int n_phase = 0, n_gray = 0;
+    size_t pitch = 0, plane_bytes = 0, set_bytes = 0, out_set_bytes = 0;
+    int acquired = -1;
+    unsigned long long next_ticket = 1;
+    std::string err;
+};
+
+namespace {
+
+int pipe_fail(slx_pipe *p, int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (p) p->err = buf;
+    else g_create_error = buf;
+    return code;
+}
+
+#define SLX_PIPE_HIP(p, call)                                                                                   \
+    do {                                                                                                        \
+        hipError_t e_ = (call);                                                                                 \
+        if (e_ != hipSuccess)                                                                                   \
+            return pipe_fail(p, e_ == hipErrorOutOfMemory ? SLX_ERR_OUT_OF_MEMORY : SLX_ERR_HIP, "%s: %s", #call, hipGetErrorString(e_)); \
+    } while (0)
+
+}  // namespace
+
+void slx_pipe_destroy(slx_pipe *p)
+{
+    if (!p) return;
+    (void)hipSetDevice(p->ctx->device);
+    for (hipStream_t s : {p->s_in, p->s_dec, p->s_out})
+        if (s) (void)hipStreamSynchronize(s);
+    for (auto &sl : p->slot) {
+        if (sl.h_in) (void)hipHostFree(sl.h_in);
+        if (sl.h_out) (void)hipHostFree(sl.h_out);
+        if (sl.d_in) (void)hipFree(sl.d_in);
+        if (sl.d_out) (void)hipFree(sl.d_out);
+        for (hipEvent_t e : {sl.ev_in, sl.ev_dec, sl.ev_out})
+            if (e) (void)hipEventDestroy(e);
+    }
+    for (hipStream_t s : {p->s_in, p->s_dec, p->s_out})
+        if (s) (void)hipStreamDestroy(s);
+    delete p;
+}
+
+int slx_pipe_create(slx_ctx *ctx, const slx_pipe_config *cfg, slx_pipe **out)
+{
+    if (!ctx || !cfg || !out) return SLX_ERR_INVALID_ARG;
+    *out = nullptr;
+    if (cfg->slots < 2 || cfg->slots > 64) return fail(ctx, SLX_ERR_INVALID_ARG, "a pipe needs 2..64 slots (got %d)", cfg->slots);
+    if (cfg->sets_per_slot < 1 || cfg->sets_per_slot > 4096) return fail(ctx, SLX_ERR_INVALID_ARG, "sets_per_slot must be in [1,4096] (got %d)", cfg->sets_per_slot);
+    slx_pipe *p = new slx_pipe;
+    p->ctx = ctx;
+    p->cfg = *cfg;
+    p->n_phase = (int)ctx->phase.size();
+    p->n_gray = (int)ctx->gray.size();
+    p->pitch = ctx->staging_pitch;
+    p->plane_bytes = p->pitch * (size_t)ctx->cfg.height;
+    p->set_bytes = p->plane_bytes * (size_t)(p->n_phase + p->n_gray);
+    p->out_set_bytes = (size_t)ctx->cfg.width * (size_t)ctx->cfg.height * sizeof(double);
+    p->slot.resize((size_t)cfg->slots);
+    auto bail = [&](int rc) {
+        ctx->err = p->err;
+        slx_pipe_destroy(p);
+        return rc;
+    };
+#define SLX_PIPE_TRY(call)                                                                           \
+    do {                                                                                             \
+        hipError_t e_ = (call);                                                                      \
+        if (e_ != hipSuccess) {                                                                      \
+            pipe_fail(p, 0, "%s: %s", #call, hipGetErrorString(e_));                                 \
+            return bail(e_ == hipErrorOutOfMemory ? SLX_ERR_OUT_OF_MEMORY : SLX_ERR_HIP);            \
+        }                                                                                            \
+    } while (0)
+    SLX_PIPE_TRY(hipSetDevice(ctx->device));
+    SLX_PIPE_TRY(hipStreamCreateWithFlags(&p->s_in, hipStreamNonBlocking));
+    SLX_PIPE_TRY(hipStreamCreateWithFlags(&p->s_dec, hipStreamNonBlocking));
+    SLX_PIPE_TRY(hipStreamCreateWithFlags(&p->s_out, hipStreamNonBlocking));
+    const size_t in_bytes = p->set_bytes * (size_t)cfg->sets_per_slot, out_bytes = p->out_set_bytes * (size_t)cfg->sets_per_slot;
+    for (auto &sl : p->slot) {
+        SLX_PIPE_TRY(hipHostMalloc((void **)&sl.h_in, in_bytes, hipHostMallocDefault));
+        SLX_PIPE_TRY(hipMalloc((void **)&sl.d_in, in_bytes));
+        SLX_PIPE_TRY(hipMalloc((void **)&sl.d_out, out_bytes));
+        if (cfg->host_result) SLX_PIPE_TRY(hipHostMalloc((void **)&sl.h_out, out_bytes, hipHostMallocDefault));
+        SLX_PIPE_TRY(hipEventCreateWithFlags(&sl.ev_in, hipEventDisableTiming));
+        SLX_PIPE_TRY(hipEventCreateWithFlags(&sl.ev_dec, hipEventDisableTiming));
+        SLX_PIPE_TRY(hipEventCreateWithFlags(&sl.ev_out, hipEventDisableTiming));
+    }
+#undef SLX_PIPE_TRY
+    *out = p;
+    return SLX_OK;
+}
+
+const char *slx_pipe_last_error(const slx_pipe *p) { return p ? p->err.c_str() : g_create_error.c_str(); }
+
+int slx_pipe_layout(const slx_pipe *p, int *n_planes, size_t *pitch, size_t *plane_bytes, size_t *set_bytes)
+{
+    if (!p) return SLX_ERR_INVALID_ARG;
+    if (n_planes) *n_planes = p->n_phase + p->n_gray;
+    if (pitch) *pitch = p->pitch;
+    if (plane_bytes) *plane_bytes = p->plane_bytes;
+    if (set_bytes) *set_bytes = p->set_bytes;
+    return SLX_OK;
+}
+
+int slx_pipe_acquire(slx_pipe *p, uint8_t **host_in)
+{
+    if (!p || !host_in) return SLX_ERR_INVALID_ARG;
+    if (p->acquired >= 0) return pipe_fail(p, SLX_ERR_INVALID_ARG, "slot %d is already acquired: submit it first", p->acquired);
+    // a free slot, else the collected slot whose result is the oldest (its reader has had it the longest)
+    int pick = -1;
+    for (size_t i = 0; i < p->slot.size(); i++)
+        if (p->slot[i].state == slx_pipe::FREE) { pick = (int)i; break; }
+    if (pick < 0) {
+        for (size_t i = 0; i < p->slot.size(); i++)
+            if (p->slot[i].state == slx_pipe::COLLECTED && (pick < 0 || p->slot[i].ticket < p->slot[(size_t)pick].ticket)) pick = (int)i;
+    }
+    if (pick < 0) return pipe_fail(p, SLX_ERR_NOT_CONFIGURED, "all %zu slots are in flight: collect one first", p->slot.size());
+    p->slot[(size_t)pick].state = slx_pipe::ACQUIRED;
+    p->acquired = pick;
+    *host_in = p->slot[(size_t)pick].h_in;
+    return SLX_OK;
+}
+
+int slx_pipe_submit(slx_pipe *p, int n_sets)
+{
+    if (!p) return SLX_ERR_INVALID_ARG;
+    if (p->acquired < 0) return pipe_fail(p, SLX_ERR_INVALID_ARG, "no slot is acquired");
+    if (n_sets < 1 || n_sets > p->cfg.sets_per_slot) return pipe_fail(p, SLX_ERR_INVALID_ARG, "n_sets must be in [1,%d] (got %d)", p->cfg.sets_per_slot, n_sets);
+    slx_pipe::Slot &sl = p->slot[(size_t)p->acquired];
+    slx_ctx *ctx = p->ctx;
+    SLX_PIPE_HIP(p, hipSetDevice(ctx->device));
+    SLX_PIPE_HIP(p, hipMemcpyAsync(sl.d_in, sl.h_in, p->set_bytes * (size_t)n_sets, hipMemcpyHostToDevice, p->s_in));
+    SLX_PIPE_HIP(p, hipEventRecord(sl.ev_in, p->s_in));
+    SLX_PIPE_HIP(p, hipStreamWaitEvent(p->s_dec, sl.ev_in, 0));
+    const uint8_t *phase_base = p->n_phase ? sl.d_in : nullptr;
+    const uint8_t *gray_base = p->n_gray ? sl.d_in + (size_t)p->n_phase * p->plane_bytes : nullptr;
+    const int rc = slx_decode_batch(ctx, n_sets, phase_base, p->set_bytes, gray_base, p->set_bytes, p->pitch, sl.d_out, p->s_dec);
+    if (rc != SLX_OK) return pipe_fail(p, rc, "decode: %s", ctx->err.c_str());
+    SLX_PIPE_HIP(p, hipEventRecord(sl.ev_dec, p->s_dec));
+    if (sl.h_out) {
+        SLX_PIPE_HIP(p, hipStreamWaitEvent(p->s_out, sl.ev_dec, 0));
+        SLX_PIPE_HIP(p, hipMemcpyAsync(sl.h_out, sl.d_out, p->out_set_bytes * (size_t)n_sets, hipMemcpyDeviceToHost, p->s_out));
+        SLX_PIPE_HIP(p, hipEventRecord(sl.ev_out, p->s_out));
+    }
+    sl.n_sets = n_sets;
+    sl.ticket = p->next_ticket++;
+    sl.state = slx_pipe::SUBMITTED;
+    p->acquired = -1;
+    return SLX_OK;
+}
+
+int slx_pipe_collect(slx_pipe *p, const double **host_result, const double **device_result, int *n_sets)
+{
+    if (!p) return SLX_ERR_INVALID_ARG;
+    int pick = -1;
+    for (size_t i = 0; i < p->slot.size(); i++)
+        if (p->slot[i].state == slx_pipe::SUBMITTED && (pick < 0 || p->slot[i].ticket < p->slot[(size_t)pick].ticket)) pick = (int)i;
+    if (pick < 0) return pipe_fail(p, SLX_ERR_NOT_DECODED, "nothing has been submitted");
+    slx_pipe::Slot &sl = p->slot[(size_t)pick];
+    SLX_PIPE_HIP(p, hipSetDevice(p->ctx->device));
+    SLX_PIPE_HIP(p, hipEventSynchronize(sl.h_out ? sl.ev_out : sl.ev_dec));
+    sl.state = slx_pipe::COLLECTED;
+    if (host_result) *host_result = sl.h_out;
+    if (device_result) *device_result = sl.d_out;
+    if (n_sets) *n_sets = sl.n_sets;
+    return SLX_OK;
+}
+
 int slx_get_calibration(const slx_ctx *ctx, double P[12], double *cA, double *cB)
 {
     if (!ctx) return SLX_ERR_INVALID_ARG;

@@ -568,6 +568,71 @@ def test_full_size_batch_properties(api, oracle, synth, torch_cuda):
         assert torch.equal(torch.nan_to_num(z, nan=-7.0), torch.nan_to_num(first, nan=-7.0))
 
 
+# ------------------------------------------------------------------ frame ingest pipeline (host frames, pinned slots)
+@pytest.mark.parametrize("name,shape", [("C3", (37, 130)), ("C2", (50, 64)), ("C1", (20, 33)), ("C5", (24, 96))])
+def test_ingest_pipe_matches_oracle_in_submit_order(api, oracle, synth, name, shape):
+    """slx_pipe_*: 3 slots x 2 frame-sets, 9 frame-sets pushed with the slots kept full; every result must be the
+    oracle's map of the frame-set submitted in that position (results come back oldest first), bit for bit."""
+    h, w = shape
+    spec = small_spec(synth, name, w, h)
+    primary = "pix" if spec["mode"] == 0 else "z"
+    sets = [synth.random_planes(spec, seed=100 + i) for i in range(9)]
+    want = []
+    for ph, gr in sets:
+        o = oracle.pipeline(spec, ph, gr, want=(primary,))[primary]
+        want.append(o[0] if primary == "pix" else o)
+    with api.Context(spec) as ctx:
+        pipe = api.Pipe(ctx, slots=3, sets_per_slot=2)
+        assert pipe.pitch == (w + 3) // 4 * 4 and pipe.n_planes == sum(x.shape[0] for x in sets[0] if x is not None)
+        groups = [sets[0:2], sets[2:4], sets[4:6], sets[6:8], sets[8:9]]     # the last slot is only half full
+        got, in_flight = [], 0
+        for g in groups:
+            if in_flight == 3:                                                  # all slots busy: take the oldest result
+                got.extend(np.array(m) for m in pipe.collect())
+                in_flight -= 1
+            buf = pipe.acquire()
+            buf[...] = 0xA5                                                     # stale bytes in the padding / unused sets
+            for i, (ph, gr) in enumerate(g):
+                planes = np.concatenate([x for x in (ph, gr) if x is not None])
+                buf[i, :, :, :w] = planes
+            pipe.submit(len(g))
+            in_flight += 1
+        while in_flight:
+            got.extend(np.array(m) for m in pipe.collect())
+            in_flight -= 1
+        with pytest.raises(api.SlxError):
+            pipe.collect()                                                      # nothing left
+        pipe.close()
+    assert len(got) == 9
+    for i in range(9):
+        assert np.array_equal(got[i], want[i], equal_nan=True), i
+
+
+def test_ingest_pipe_slot_rules(api, synth):
+    spec = small_spec(synth, "C2", 32, 8)
+    with api.Context(spec) as ctx:
+        with pytest.raises(api.SlxError):
+            api.Pipe(ctx, slots=1)
+        pipe = api.Pipe(ctx, slots=2, sets_per_slot=1, host_result=False)
+        pipe.acquire()
+        with pytest.raises(api.SlxError):
+            pipe.acquire()                                                      # one acquisition at a time
+        with pytest.raises(api.SlxError):
+            pipe.submit(2)                                                      # more sets than the slot holds
+        pipe.submit(1)
+        pipe.acquire()[...] = 0
+        pipe.submit(1)
+        with pytest.raises(api.SlxError):
+            pipe.acquire()                                                      # both slots in flight
+        dev, n = pipe.collect()
+        assert dev and n == 1
+        pipe.acquire()                                                          # the collected slot is reusable
+        pipe.submit(1)
+        pipe.collect()
+        pipe.collect()
+        pipe.close()
+
+
 # ------------------------------------------------------------------ the C++ mirror of the reference classes
 def test_cpp_host_loop(tmp_path, oracle, synth, golden_dir):
     """tests/cpp/dynaframe_host_loop.cpp drives slx::CDecodeGray / CDecodePhase / CCalculation the way

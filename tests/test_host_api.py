@@ -172,6 +172,23 @@ def test_bmp_reader(api, tmp_path):
         api.read_bmp_gray(str(tmp_path / "junk.bmp"))
 
 
+def test_pgm_reader(api, tmp_path):
+    rng = np.random.default_rng(5)
+    for w, h in ((7, 5), (64, 48), (1, 1)):
+        img = rng.integers(0, 256, size=(h, w), dtype=np.uint8)
+        for header in ("P5\n%d %d\n255\n" % (w, h), "P5 # made by a camera SDK\n# second comment\n%d\t%d\r\n255 " % (w, h)):
+            path = str(tmp_path / "a.pgm")
+            with open(path, "wb") as f:
+                f.write(header.encode() + img.tobytes())
+            assert np.array_equal(api.read_pgm_gray(path), img), (w, h, header)
+    for bad in (b"P2\n2 2\n255\n1 2 3 4", b"P5\n2 2\n65535\n" + b"\0" * 8, b"P5\n4 4\n255\n" + b"\0" * 15, b"P5\n-2 2\n255\n"):
+        (tmp_path / "bad.pgm").write_bytes(bad)
+        with pytest.raises(api.SlxError):
+            api.read_pgm_gray(str(tmp_path / "bad.pgm"))
+    with pytest.raises(api.SlxError):
+        api.read_pgm_gray(str(tmp_path / "missing.pgm"))
+
+
 def test_bmp_colour_to_grey_matches_opencv_formula(api, tmp_path):
     import struct
     rng = np.random.default_rng(4)

@@ -82,6 +82,23 @@ constexpr int ITER = 32768;
 #define I_BFI(k) "v_bfi_b32 %" #k ", %" #k ", %8, %9\n"
 #define I_LSHR(k) "v_lshrrev_b32 %" #k ", 8, %" #k "\n"
 #define I_ANDOR(k) "v_and_or_b32 %" #k ", %" #k ", %8, %9\n"
+#define I_PKMULBC(k) "v_pk_mul_f32 %" #k ", %8, %9\n"
+#define I_SUBSDWABC(k) "v_sub_f32_sdwa %" #k ", %8, %9 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:BYTE_1\n"
+#define I_MULBC(k) "v_mul_f32 %" #k ", %8, %9\n"
+// b, c taken from the kernel argument bit for bit: denormal or normal operands on demand
+#define KERNEL_BC(NAME, TYPE, INS)                                            \
+    __global__ __launch_bounds__(256) void NAME(TYPE *out, TYPE bb, TYPE cc)  \
+    {                                                                         \
+        TYPE a[8], b = bb, c = cc;                                            \
+        for (int k = 0; k < 8; k++) a[k] = (TYPE)(threadIdx.x + k);           \
+        for (int i = 0; i < ITER; i++) { BODY8(INS) }                         \
+        TYPE s = 0;                                                           \
+        for (int k = 0; k < 8; k++) s += a[k];                                \
+        if (s == (TYPE)12345) out[0] = s;                                     \
+    }
+KERNEL_BC(k_pkmul_bc, double, I_PKMULBC)
+KERNEL_BC(k_subsdwa_bc, float, I_SUBSDWABC)
+KERNEL_BC(k_mul_bc, float, I_MULBC)
 KERNEL(k_cndv3, float, I_CNDV3)
 KERNEL(k_cndc, float, I_CNDC)
 KERNEL(k_cndb, float, I_CNDB)
@@ -236,11 +253,46 @@ static int run(const char *name, void (*fn)(T *, S), double &base, int waves_per
     return 0;
 }
 
+template <typename T>
+static int run_bc(const char *name, void (*fn)(T *, T, T), T b, T c, double &base, int waves_per_simd)
+{
+    T *out;
+    CHECK(hipMalloc(&out, 64));
+    const int blocks = 256 * waves_per_simd;
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0));
+    CHECK(hipEventCreate(&e1));
+    for (int w = 0; w < 3; w++) hipLaunchKernelGGL(fn, dim3(blocks), dim3(256), 0, 0, out, b, c);
+    CHECK(hipDeviceSynchronize());
+    float best = 1e30f;
+    for (int rep = 0; rep < 5; rep++) {
+        CHECK(hipEventRecord(e0));
+        hipLaunchKernelGGL(fn, dim3(blocks), dim3(256), 0, 0, out, b, c);
+        CHECK(hipEventRecord(e1));
+        CHECK(hipEventSynchronize(e1));
+        float ms;
+        CHECK(hipEventElapsedTime(&ms, e0, e1));
+        best = ms < best ? ms : best;
+    }
+    const double ns_per_instr = best * 1e6 / ((double)ITER * 8.0 * waves_per_simd);
+    printf("%-12s waves/SIMD %d  %8.3f ms  %6.3f ns per wave-instruction per SIMD  x%.2f\n", name, waves_per_simd, best, ns_per_instr, ns_per_instr / base);
+    CHECK(hipFree(out));
+    return 0;
+}
+
+static float f_bits(uint32_t u) { float f; __builtin_memcpy(&f, &u, 4); return f; }
+static double d_bits(uint32_t lo, uint32_t hi) { uint64_t u = ((uint64_t)hi << 32) | lo; double d; __builtin_memcpy(&d, &u, 8); return d; }
+
 int main()
 {
     for (int w : {4}) {
         double base = 0;
         run("fma_f32", k_fma32, base, w);
+        run_bc("pkmul_norm", k_pkmul_bc, d_bits(0x40400000u, 0x40400000u), d_bits(0x7e800000u, 0x3f000000u), base, w);
+        run_bc("pkmul_denorm", k_pkmul_bc, d_bits(0x00000037u, 0x80000091u), d_bits(0x7e800000u, 0x7e800000u), base, w);
+        run_bc("mul_norm", k_mul_bc, f_bits(0x40400000u), f_bits(0x7e800000u), base, w);
+        run_bc("mul_denorm", k_mul_bc, f_bits(0x00000037u), f_bits(0x7e800000u), base, w);
+        run_bc("subsdwa_bytes", k_subsdwa_bc, f_bits(0x00003700u), f_bits(0x00009100u), base, w);
         run("max_f32", k_max32, base, w);
         run("cnd_e64_vcc", k_cndv3, base, w);
         run("cnd_e32_0", k_cndc, base, w);
