@@ -109,6 +109,8 @@ def main():
     ap.add_argument("--config", default="C4")
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gather", action="store_true",
+                    help="N > 1: skip the second timed region (decode + RCCL gather of the depth maps to rank 0, reported as with_gather)")
     ap.add_argument("--shard", choices=("framesets", "rows"), default="framesets",
                     help="how ranks split the batch: whole frame-sets (default), or a row tile of every frame-set (north_star's wording); "
                          "the per-GPU bytes are the same")
@@ -201,7 +203,7 @@ def main():
     # parity of what was just timed: frame-set 0 of rank 0 against the oracle
     result = {}
     gather = None
-    if world > 1:
+    if world > 1 and not args.no_gather:
         def gather():
             if args.backend == "nccl":
                 return shard.gather_depth(z, dst=0)
