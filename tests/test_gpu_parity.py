@@ -532,6 +532,35 @@ def test_row_tiles_and_frameset_shards_on_gpu(api, oracle, synth, shard):
             assert np.array_equal(np.concatenate([p[w] for p in parts]), full[w], equal_nan=True), (world, w)
 
 
+def test_rccl_backend_single_rank_collectives(tmp_path):
+    """bench.py's multi-rank calls (init with device_id, barrier, all_reduce MAX, gather into views of one buffer,
+    all_gather_into_tensor) on the RCCL backend.  One rank: the box has one GPU; the 2-rank logic runs on gloo in
+    tests/test_shard_gloo.py.  In a child process so that the process group does not leak into this one."""
+    import subprocess
+    import sys
+    code = r'''
+import os, torch, torch.distributed as dist
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+dev = torch.device("cuda", 0); torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+dist.barrier()
+t = torch.tensor([1.5, 2.5], dtype=torch.float64, device=dev); dist.all_reduce(t, op=dist.ReduceOp.MAX)
+assert t.tolist() == [1.5, 2.5]
+local = torch.arange(2 * 3 * 4, dtype=torch.float64, device=dev).reshape(2, 3, 4)
+out = torch.empty((2, 3, 4), dtype=torch.float64, device=dev)
+dist.gather(local, list(out.split(2, dim=0)), dst=0)
+assert torch.equal(out, local)
+out2 = torch.empty_like(out); dist.all_gather_into_tensor(out2, local)
+assert torch.equal(out2, local)
+dist.destroy_process_group()
+print("rccl ok")
+'''
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0 and "rccl ok" in r.stdout, r.stdout + r.stderr
+
+
 # ------------------------------------------------------------------ full batch size, size-independent properties
 def test_full_size_batch_properties(api, oracle, synth, torch_cuda):
     """BASELINE configuration 4's per-GPU share: 32 frame-sets of 1920x1200, 3 x 4-step, in one launch.
