@@ -598,7 +598,7 @@ int slx_track_begin(slx_ctx *ctx, const uint8_t *image, size_t stride_bytes, int
     }
     for (float **q : {&ctx->d_stripW_prev, &ctx->d_stripB_prev, &ctx->d_deltaP_raw})
         if (!*q) SLX_HIP(ctx, hipMalloc((void **)q, hw * sizeof(float)));
-    for (int w : {SLX_OUT_DELTAZ, SLX_OUT_DELTAP, SLX_OUT_STRIPW, SLX_OUT_STRIPB}) SLX_HIP(ctx, hipMemsetAsync(ctx->out[w], 0, ctx->out_bytes[w], ctx->stream));
+    for (int w : {SLX_OUT_DELTAZ, SLX_OUT_DELTAP}) SLX_HIP(ctx, hipMemsetAsync(ctx->out[w], 0, ctx->out_bytes[w], ctx->stream));
     const uint8_t *img;
     size_t istride;
     int rc = track_image(ctx, image, stride_bytes, mem_kind, &img, &istride);
@@ -615,7 +615,6 @@ int slx_track_next(slx_ctx *ctx, const uint8_t *image, size_t stride_bytes, int 
     const slx_config &c = ctx->cfg;
     if (ctx->track_window == 0) return fail(ctx, SLX_ERR_NOT_CONFIGURED, "slx_track_begin has not been called");
     SLX_HIP(ctx, hipSetDevice(ctx->device));
-    const size_t hw = (size_t)c.width * c.height;
     const uint8_t *img;
     size_t istride;
     int rc = track_image(ctx, image, stride_bytes, mem_kind, &img, &istride);
@@ -626,10 +625,9 @@ int slx_track_next(slx_ctx *ctx, const uint8_t *image, size_t stride_bytes, int 
     std::swap(curB, ctx->d_stripB_prev);
     ctx->out[SLX_OUT_STRIPW] = curW;
     ctx->out[SLX_OUT_STRIPB] = curB;
-    SLX_HIP(ctx, hipMemsetAsync(curW, 0, hw * sizeof(float), ctx->stream));
-    SLX_HIP(ctx, hipMemsetAsync(curB, 0, hw * sizeof(float), ctx->stream));
-    int e = slx_launch_strip_regression(img, istride, c.width, c.height, ctx->track_window, curW, curB, ctx->stream);
-    if (e == 0) e = slx_launch_delta_p(ctx->d_stripW_prev, ctx->d_stripB_prev, curW, curB, hw, ctx->d_deltaP_raw, ctx->stream);
+    // (the kernel writes every pixel of both planes, zeros outside the interior)
+    int e = slx_launch_strip_regression(img, istride, c.width, c.height, ctx->track_window, curW, curB, ctx->stream, ctx->d_stripW_prev,
+                                        ctx->d_stripB_prev, ctx->d_deltaP_raw);
     if (e == 0)
         e = slx_launch_track_update(ctx->kp, ctx->d_deltaP_raw, (float *)ctx->out[SLX_OUT_DELTAP], (double *)ctx->out[SLX_OUT_U],
                                     (double *)ctx->out[SLX_OUT_Z], (double *)ctx->out[SLX_OUT_X], (double *)ctx->out[SLX_OUT_Y],

@@ -73,7 +73,10 @@ int slx_launch_cloud_scan(int width, const unsigned *counts, unsigned *offsets, 
 int slx_launch_cloud_write(const SlxKParams &kp, const double *z, const unsigned *offsets, double *xyz, void *stream);
 
 // Dynamic-frame tracker (slx_track.hip).  Device pointers; 0 or a hipError_t.
-int slx_launch_strip_regression(const uint8_t *cam, size_t stride, int W, int H, int win, float *stripW, float *stripB, void *stream);
+// prevW / prevB / raw non-null: also raw = the deltaP selection between the previous frame's strips and the new ones
+// (fused into the strip kernel for the 21-pixel window, a second launch otherwise).
+int slx_launch_strip_regression(const uint8_t *cam, size_t stride, int W, int H, int win, float *stripW, float *stripB, void *stream,
+                                const float *prevW = nullptr, const float *prevB = nullptr, float *raw = nullptr);
 int slx_launch_delta_p(const float *W0, const float *B0, const float *W1, const float *B1, size_t n, float *raw, void *stream);
 int slx_launch_track_update(const SlxKParams &kp, const float *raw, float *deltaP, double *U, double *z, double *x, double *y, double *deltaZ,
                             void *stream);

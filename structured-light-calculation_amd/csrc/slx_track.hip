@@ -15,45 +15,135 @@
 namespace {
 
 constexpr int kTile = 256;            // threads per workgroup = columns per tile, halo included
-constexpr int kRowsPerBand = 64;
+constexpr int kBandRows = 8;          // rows per workgroup: 1920x1200 gives 9 x 150 workgroups, ~5 per CU
 
 // One lane per column keeps the 21-row sliding sum of its column while the workgroup walks down a band of rows;
 // every row's sums go through LDS so that a lane can scan its 20 horizontal neighbours (win/2 to the left,
-// win/2 - 1 to the right, in the reference's order: the centre wins ties, then the leftmost).
+// win/2 - 1 to the right, in the reference's order: the centre wins ties, then the leftmost).  The kernel writes
+// every pixel of the two strip planes -- 0 outside the interior (R/CCalculation.cpp:799-802, :827-828) -- so the
+// planes need no clearing pass.  HWT > 0: the half window as a compile-time constant (the scan unrolls); 0: win / 2.
+template <int HWT>
 __global__ __launch_bounds__(kTile) void slx_strip_regression_kernel(const uint8_t *cam, size_t stride, int W, int H, int win,
                                                                      float *stripW, float *stripB)
 {
     __shared__ float row_sum[2][kTile];
-    const int hw = win / 2;
+    const int hw = HWT > 0 ? HWT : win / 2;
     const int out_cols = kTile - 2 * hw;
     const int tx = threadIdx.x;
-    // lane tx holds column tile_first + tx; lanes hw .. kTile-hw-1 produce output, i.e. a tile yields the out_cols
-    // interior columns from blockIdx.x * out_cols + hw on (halo lanes may be outside the image)
-    const int c = blockIdx.x * out_cols + tx;
-    const bool col_interior = c >= hw && c < W - hw;               // valSum is 0 elsewhere (R/CCalculation.cpp:799-802)
-    const int h0 = hw + blockIdx.y * kRowsPerBand;
-    const int h1 = h0 + kRowsPerBand < H - hw ? h0 + kRowsPerBand : H - hw;
-    if (h0 >= h1) return;
+    // lane tx holds column tile_first - hw + tx; lanes hw .. kTile-hw-1 own the tile's out_cols output columns
+    const int c = (int)blockIdx.x * out_cols + tx - hw;
+    const bool owns = tx >= hw && tx < kTile - hw && c < W;
+    const bool col_interior = c >= hw && c < W - hw;               // valSum is 0 elsewhere
+    const int r0 = (int)blockIdx.y * kBandRows;
+    const int r1 = r0 + kBandRows < H ? r0 + kBandRows : H;
     float sum = 0.f;
-    if (col_interior)
-        for (int r = h0 - hw; r <= h0 + hw; r++) sum += (float)cam[(size_t)r * stride + c];
-    for (int h = h0; h < h1; h++) {
-        float *buf = row_sum[(h - h0) & 1];
+    bool have = false;
+    for (int h = r0; h < r1; h++) {
+        if (h < hw || h >= H - hw) {                               // border row (uniform over the workgroup)
+            if (owns) {
+                stripW[(size_t)h * W + c] = 0.f;
+                stripB[(size_t)h * W + c] = 0.f;
+            }
+            continue;
+        }
+        if (!have) {                                               // first interior row of the band: :814-819
+            if (col_interior)
+                for (int r = h - hw; r <= h + hw; r++) sum += (float)cam[(size_t)r * stride + c];
+            have = true;
+        } else if (col_interior) {                                 // :820-822
+            sum = sum - (float)cam[(size_t)(h - 1 - hw) * stride + c] + (float)cam[(size_t)(h + hw) * stride + c];
+        }
+        float *buf = row_sum[h & 1];
         buf[tx] = col_interior ? sum : 0.f;
         __syncthreads();
-        if (tx >= hw && tx < kTile - hw && col_interior) {
-            float mx = buf[tx], mn = mx, mxi = 0.f, mni = 0.f;
-            for (int i = -hw; i < hw; i++) {                       // :838-851
-                const float v = buf[tx + i];
-                if (v > mx) { mx = v; mxi = (float)i; }
-                if (v < mn) { mn = v; mni = (float)i; }
+        // the other LDS buffer is written next; this one is written again only two rows (one barrier) later
+        if (owns) {
+            float mxi = 0.f, mni = 0.f;
+            if (col_interior) {
+                float mx = buf[tx], mn = mx;
+#pragma unroll
+                for (int i = -hw; i < hw; i++) {                   // :838-851
+                    const float v = buf[tx + i];
+                    if (v > mx) { mx = v; mxi = (float)i; }
+                    if (v < mn) { mn = v; mni = (float)i; }
+                }
             }
             stripB[(size_t)h * W + c] = mni;
             stripW[(size_t)h * W + c] = mxi;
         }
-        if (col_interior && h + 1 < h1)                            // :820-822
-            sum = sum - (float)cam[(size_t)(h - hw) * stride + c] + (float)cam[(size_t)(h + hw + 1) * stride + c];
-        // the other LDS buffer is written next; this one is read again only two rows later
+    }
+}
+
+// The same for a compile-time half window HW (the reference's RECO_WINDOW_SIZE = 21 -> HW = 10), restructured so that
+// nothing in it is serial: a lane loads the kBandRows + 2 HW bytes of its column that the band needs in one go, forms the
+// band's sliding sums from them, and all rows' sums go to LDS behind ONE barrier; then every row is scanned with the
+// neighbour's position folded into the compared key, so that the scan is v_max3_u32 / v_min3_u32 instead of
+// compare + two selects per neighbour and strip:
+//   white strip: key = sum * 32 + priority, priority 2 HW for the centre, HW - 1 - i for neighbour i (leftmost highest)
+//                -> the maximum key is the largest sum, the centre on ties, else the leftmost        (:838-851, `>` replaces)
+//   black strip: key = sum * 32 + rank, rank 0 for the centre, i + HW + 1 for neighbour i -> the minimum key likewise.
+// Sums are at most 21 * 255 < 2^13, so the keys are exact 18-bit integers.
+template <int HW>
+__global__ __launch_bounds__(kTile) void slx_strip_regression_band_kernel(const uint8_t *cam, size_t stride, int W, int H, float *stripW, float *stripB,
+                                                                          const float *prevW, const float *prevB, float *raw)
+{
+    static_assert(2 * HW <= 31, "the neighbour rank must fit 5 bits");
+    __shared__ uint32_t sums[kBandRows][kTile];
+    constexpr int out_cols = kTile - 2 * HW;
+    const int tx = threadIdx.x;
+    const int c = (int)blockIdx.x * out_cols + tx - HW;
+    const bool owns = tx >= HW && tx < kTile - HW && c < W;
+    const bool col_interior = c >= HW && c < W - HW;
+    const int r0 = (int)blockIdx.y * kBandRows;
+    const int r1 = r0 + kBandRows < H ? r0 + kBandRows : H;
+    const int ha = r0 > HW ? r0 : HW, hb = r1 < H - HW ? r1 : H - HW;   // interior rows of the band: [ha, hb)
+    if (ha < hb) {
+        uint32_t b[kBandRows + 2 * HW];
+#pragma unroll
+        for (int k = 0; k < kBandRows + 2 * HW; k++) {
+            const int r = ha - HW + k;
+            b[k] = (col_interior && r < hb + HW) ? cam[(size_t)r * stride + c] : 0u;
+        }
+        uint32_t sum = 0;
+#pragma unroll
+        for (int k = 0; k <= 2 * HW; k++) sum += b[k];
+#pragma unroll
+        for (int j = 0; j < kBandRows; j++) {
+            sums[j][tx] = sum << 5;                                 // 0 outside the interior columns, as valSum is
+            if (j + 1 < kBandRows) sum = sum - b[j] + b[j + 2 * HW + 1];
+        }
+    }
+    __syncthreads();
+    if (!owns) return;
+#pragma unroll
+    for (int j = 0; j < kBandRows; j++) {
+        const int h = r0 + j;
+        if (h >= r1) break;
+        float mxi = 0.f, mni = 0.f;
+        const int jj = h - ha;                                      // row of `sums`
+        if (col_interior && h >= ha && h < hb) {
+            const uint32_t *row = &sums[jj][tx];
+            uint32_t kmax = row[0] | (uint32_t)(2 * HW), kmin = row[0];
+#pragma unroll
+            for (int i = -HW; i < HW; i += 2) {
+                const uint32_t s0 = row[i], s1 = row[i + 1];
+                // neighbour 0 is the centre again with a lower priority / higher rank: harmless
+                const uint32_t w0 = s0 | (uint32_t)(HW - 1 - i), w1 = s1 | (uint32_t)(HW - 2 - i);
+                const uint32_t k0 = s0 | (uint32_t)(i + HW + 1), k1 = s1 | (uint32_t)(i + HW + 2);
+                kmax = max(max(kmax, w0), w1);
+                kmin = min(min(kmin, k0), k1);
+            }
+            const int p = (int)(kmax & 31u), q = (int)(kmin & 31u);
+            mxi = p == 2 * HW ? 0.f : (float)(HW - 1 - p);
+            mni = q == 0 ? 0.f : (float)(q - HW - 1);
+        }
+        const size_t o = (size_t)h * W + c;
+        stripB[o] = mni;
+        stripW[o] = mxi;
+        if (raw) {                                                  // deltaP selection of the next step, R/CCalculation.cpp:602-617
+            const float dB = prevB[o] - mni, dW = prevW[o] - mxi;
+            raw[o] = (__builtin_fabsf(dB) < __builtin_fabsf(dW)) ? dB : dW;
+        }
     }
 }
 
@@ -106,13 +196,35 @@ __global__ __launch_bounds__(256) void slx_track_update_kernel(const float *raw,
 
 }  // namespace
 
-int slx_launch_strip_regression(const uint8_t *cam, size_t stride, int W, int H, int win, float *stripW, float *stripB, void *stream)
+static int slx_launch_strip_regression_only(const uint8_t *cam, size_t stride, int W, int H, int win, float *stripW, float *stripB, void *stream,
+                                            const float *prevW, const float *prevB, float *raw);
+
+int slx_launch_strip_regression(const uint8_t *cam, size_t stride, int W, int H, int win, float *stripW, float *stripB, void *stream,
+                                const float *prevW, const float *prevB, float *raw)
+{
+    const bool fuse = raw && win / 2 == 10 && H > 20 && W > 20;      // the band kernel also forms deltaP's raw selection
+    int e = slx_launch_strip_regression_only(cam, stride, W, H, win, stripW, stripB, stream, fuse ? prevW : nullptr, fuse ? prevB : nullptr,
+                                             fuse ? raw : nullptr);
+    if (e == 0 && raw && !fuse) e = slx_launch_delta_p(prevW, prevB, stripW, stripB, (size_t)W * H, raw, stream);
+    return e;
+}
+
+static int slx_launch_strip_regression_only(const uint8_t *cam, size_t stride, int W, int H, int win, float *stripW, float *stripB, void *stream,
+                                            const float *prevW, const float *prevB, float *raw)
 {
     const int hw = win / 2;
-    if (win < 3 || 2 * hw >= kTile - 1 || H <= 2 * hw || W <= 2 * hw) return 0;     // no interior: the strips stay 0
+    if (win < 3 || 2 * hw >= kTile - 1 || H <= 2 * hw || W <= 2 * hw) {              // no interior: the strips are 0
+        hipError_t e = hipMemsetAsync(stripW, 0, (size_t)W * H * sizeof(float), (hipStream_t)stream);
+        if (e == hipSuccess) e = hipMemsetAsync(stripB, 0, (size_t)W * H * sizeof(float), (hipStream_t)stream);
+        return (int)e;
+    }
     const int out_cols = kTile - 2 * hw;
-    const dim3 grid((unsigned)((W - 2 * hw + out_cols - 1) / out_cols), (unsigned)((H - 2 * hw + kRowsPerBand - 1) / kRowsPerBand));
-    hipLaunchKernelGGL(slx_strip_regression_kernel, grid, dim3(kTile), 0, (hipStream_t)stream, cam, stride, W, H, win, stripW, stripB);
+    const dim3 grid((unsigned)((W + out_cols - 1) / out_cols), (unsigned)((H + kBandRows - 1) / kBandRows));
+    if (hw == 10)                                                                      // RECO_WINDOW_SIZE = 21, R/StaticParameters.cpp
+        hipLaunchKernelGGL(slx_strip_regression_band_kernel<10>, grid, dim3(kTile), 0, (hipStream_t)stream, cam, stride, W, H, stripW, stripB, prevW,
+                           prevB, raw);
+    else
+        hipLaunchKernelGGL(slx_strip_regression_kernel<0>, grid, dim3(kTile), 0, (hipStream_t)stream, cam, stride, W, H, win, stripW, stripB);
     return (int)hipGetLastError();
 }
 

@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""Time of one dynamic frame (slx_track_next: StripRegression + FillOtherDeltaProU + FillCoordinate + deltaZ) on the
+GPU box, camera image resident in HBM.  Usage: tools/track_bench.py [--size 1920x1200] [--frames 60]"""
+import argparse
+import importlib
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+
+synth = importlib.import_module("structured-light-calculation_amd.synth")
+api = importlib.import_module("structured-light-calculation_amd.api")
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--size", default="1920x1200")
+ap.add_argument("--frames", type=int, default=60)
+ap.add_argument("--window", type=int, default=21)
+a = ap.parse_args()
+W, H = (int(v) for v in a.size.split("x"))
+spec = dict(synth.make_spec("REF"))
+spec["width"], spec["height"] = W, H
+spec["calib"] = synth.scaled_calibration(W, H, spec["proj_width"])
+ph, gr, _ = synth.render(spec, "sphere", seed=9, noise_sigma=1.0)
+imgs = [torch.randint(0, 256, (H, W), dtype=torch.uint8, device="cuda") for _ in range(4)]
+with api.Context(spec, aux=("U", "x", "y")) as ctx:
+    ctx.set_frames(phase=ph, gray=gr)
+    ctx.decode()
+    ctx.synchronize()
+    ctx.track_begin(imgs[0], window=a.window)
+    for i in range(10):
+        ctx.track_next(imgs[i % 4])
+    ctx.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    import time
+    t0 = time.perf_counter()
+    for i in range(a.frames):
+        ctx.track_next(imgs[i % 4])
+    ctx.synchronize()
+    dt = (time.perf_counter() - t0) / a.frames
+# algorithmic bytes per pixel of one frame: image 1; strips W,B written 8; previous strips read 8, raw deltaP written 4;
+# update: raw deltaP 4, U 8 read + 8 written, deltaP 4 written, z 8 read, z/x/y 24 written, deltaZ 8 written
+bytes_px = 1 + 8 + 8 + 4 + 4 + 8 + 8 + 4 + 8 + 24 + 8
+print(json.dumps({"metric": "dynamic frames/s (slx_track_next)", "size": a.size, "window": a.window, "frames": a.frames,
+                  "value": 1.0 / dt, "us_per_frame": dt * 1e6, "algorithmic_bytes_per_pixel": bytes_px,
+                  "achieved_GBps": bytes_px * W * H / dt / 1e9}))
