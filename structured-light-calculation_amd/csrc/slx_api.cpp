@@ -41,7 +41,7 @@ struct slx_ctx {
     std::vector<int16_t> lut;
     int16_t *d_lut = nullptr;
     std::vector<Plane> phase, gray;
-    unsigned *d_cloud_counts = nullptr, *d_cloud_offsets = nullptr;   // width + 1 each, point-cloud compaction
+    unsigned *d_cloud_counts = nullptr, *d_cloud_offsets = nullptr;   // slx_cloud_entries() + 1 each, point-cloud compaction
     double *d_cloud = nullptr;
     size_t cloud_capacity = 0;
     // dynamic-frame tracker: previous frame's strips, unblurred deltaP, staged camera image
@@ -527,34 +527,48 @@ int slx_get_point_cloud(slx_ctx *ctx, double *xyz, size_t capacity_points, size_
     if (mem_kind != SLX_MEM_HOST && mem_kind != SLX_MEM_DEVICE) return fail(ctx, SLX_ERR_INVALID_ARG, "unknown mem_kind %d", mem_kind);
     SLX_HIP(ctx, hipSetDevice(ctx->device));
     SLX_HIP(ctx, hipDeviceSynchronize());   // the decode may have run on a caller stream
-    const size_t w1 = (size_t)c.width + 1;
+    const int entries = slx_cloud_entries(c.width, c.height);
+    const size_t w1 = (size_t)entries + 1;
     if (!ctx->d_cloud_counts) SLX_HIP(ctx, hipMalloc((void **)&ctx->d_cloud_counts, w1 * sizeof(unsigned)));
     if (!ctx->d_cloud_offsets) SLX_HIP(ctx, hipMalloc((void **)&ctx->d_cloud_offsets, w1 * sizeof(unsigned)));
     const double *z = (const double *)ctx->out[SLX_OUT_Z];
     int e = slx_launch_cloud_count(ctx->kp, z, ctx->d_cloud_counts, ctx->stream);
-    if (e == 0) e = slx_launch_cloud_scan(c.width, ctx->d_cloud_counts, ctx->d_cloud_offsets, ctx->stream);
+    if (e == 0) e = slx_launch_cloud_scan(entries, ctx->d_cloud_counts, ctx->d_cloud_offsets, ctx->stream);
     if (e != 0) return hip_fail(ctx, (hipError_t)e, "point-cloud count");
+    // The write kernel can follow at once when its target cannot overflow (a device buffer for every pixel, or the
+    // context's own staging buffer, which is sized for every pixel): one pass over the GPU, one wait.
+    const size_t all = (size_t)c.width * c.height;
+    double *dst = nullptr;
+    if (mem_kind == SLX_MEM_DEVICE && xyz && capacity_points >= all) {
+        dst = xyz;
+    } else if (mem_kind == SLX_MEM_HOST && xyz) {
+        if (ctx->cloud_capacity < all) {
+            if (ctx->d_cloud) (void)hipFree(ctx->d_cloud);
+            ctx->d_cloud = nullptr;
+            ctx->cloud_capacity = 0;
+            SLX_HIP(ctx, hipMalloc((void **)&ctx->d_cloud, all * 3 * sizeof(double)));
+            ctx->cloud_capacity = all;
+        }
+        dst = ctx->d_cloud;
+    }
+    if (dst) {
+        e = slx_launch_cloud_write(ctx->kp, z, ctx->d_cloud_offsets, dst, ctx->stream);
+        if (e != 0) return hip_fail(ctx, (hipError_t)e, "point-cloud write");
+    }
     unsigned total = 0;
-    SLX_HIP(ctx, hipMemcpyAsync(&total, ctx->d_cloud_offsets + c.width, sizeof total, hipMemcpyDeviceToHost, ctx->stream));
+    SLX_HIP(ctx, hipMemcpyAsync(&total, ctx->d_cloud_offsets + entries, sizeof total, hipMemcpyDeviceToHost, ctx->stream));
     SLX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     *n_points = total;
     if (total == 0) return SLX_OK;
     if (!xyz || capacity_points < total) return fail(ctx, SLX_ERR_INVALID_ARG, "the cloud has %u points, the buffer holds %zu", total, capacity_points);
-    double *dst = xyz;
-    if (mem_kind == SLX_MEM_HOST) {
-        if (ctx->cloud_capacity < total) {
-            if (ctx->d_cloud) (void)hipFree(ctx->d_cloud);
-            ctx->d_cloud = nullptr;
-            ctx->cloud_capacity = 0;
-            SLX_HIP(ctx, hipMalloc((void **)&ctx->d_cloud, (size_t)total * 3 * sizeof(double)));
-            ctx->cloud_capacity = total;
-        }
-        dst = ctx->d_cloud;
-    }
-    e = slx_launch_cloud_write(ctx->kp, z, ctx->d_cloud_offsets, dst, ctx->stream);
-    if (e != 0) return hip_fail(ctx, (hipError_t)e, "point-cloud write");
-    if (mem_kind == SLX_MEM_HOST)
+    if (!dst) {                                                     // a device buffer smaller than the frame, now known to be large enough
+        e = slx_launch_cloud_write(ctx->kp, z, ctx->d_cloud_offsets, xyz, ctx->stream);
+        if (e != 0) return hip_fail(ctx, (hipError_t)e, "point-cloud write");
+    } else if (mem_kind == SLX_MEM_HOST) {
         SLX_HIP(ctx, hipMemcpyAsync(xyz, dst, (size_t)total * 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    } else {
+        return SLX_OK;                                              // already written and waited for
+    }
     SLX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return SLX_OK;
 }

@@ -66,10 +66,12 @@ struct SlxKParams {
 // parameters: every period <= 2^14, calibration magnitudes < 2^90.
 bool slx_fast_arith_ok(const SlxKParams &kp);
 
-// Point cloud compaction (R/CCalculation.cpp:323-357 order: column outer, row inner).
-// counts/offsets: device arrays of width+1 unsigned; xyz: device, 3 doubles per point.  Returns 0 or a hipError_t.
+// Point cloud compaction (R/CCalculation.cpp:323-357 order: column outer, row inner) over 64 x 64 tiles.
+// counts/offsets: device arrays of slx_cloud_entries(width, height) + 1 unsigned; xyz: device, 3 doubles per point.
+// offsets[entries] is the number of points.  Returns 0 or a hipError_t.
+int slx_cloud_entries(int width, int height);
 int slx_launch_cloud_count(const SlxKParams &kp, const double *z, unsigned *counts, void *stream);
-int slx_launch_cloud_scan(int width, const unsigned *counts, unsigned *offsets, void *stream);
+int slx_launch_cloud_scan(int n_entries, const unsigned *counts, unsigned *offsets, void *stream);
 int slx_launch_cloud_write(const SlxKParams &kp, const double *z, const unsigned *offsets, double *xyz, void *stream);
 
 // Dynamic-frame tracker (slx_track.hip).  Device pointers; 0 or a hipError_t.

@@ -923,67 +923,101 @@ __global__ __launch_bounds__(256) void slx_strip_kernel(const SlxKParams p)
 
 // ------------------------------------------------------------------------------------------
 // Point cloud (CCalculation::Result, R/CCalculation.cpp:323-357): the reference walks u outer / v inner and
-// writes "x y z" for every depth inside the FOV.  Here: per-column counts, an exclusive scan over the columns,
-// and a per-column write.  One lane per column: a wave reads 64 adjacent doubles of a row at a time.
+// writes "x y z" for every depth inside the FOV.  Here the depth map is cut into 64 x 64 tiles; the cloud's order
+// (column, then row) is the order of the entries (column u, row block rb = v / 64) laid out as u * RB + rb, so:
+//   count:  entry (u, rb) = kept depths of column u in rows [64 rb, 64 rb + 64)       -- rows read coalesced
+//   scan:   exclusive prefix sum over the entries (one workgroup), entry n = the total
+//   write:  the tile goes through LDS (coalesced rows in, columns out); a wave takes a column, lane = row, the
+//           kept lanes' rank (ballot + popcount below the lane) is the point's place after the entry's offset, and a
+//           column's points leave as one contiguous run of 24-byte records.
+constexpr int kCloudTile = 64;
+
 __device__ __forceinline__ bool cloud_keep(double zz, double fov_min, double fov_max)
 {
     return !((zz < fov_min) || (zz > fov_max));                     // the reference's `continue` test, negated
 }
 
-__global__ __launch_bounds__(256) void slx_cloud_count_kernel(const double *z, unsigned *counts, int W, int H, double fov_min, double fov_max)
+__global__ __launch_bounds__(256) void slx_cloud_count_kernel(const double *z, unsigned *counts, int W, int H, int RB, double fov_min, double fov_max)
 {
-    const int u = blockIdx.x * blockDim.x + threadIdx.x;
-    if (u >= W) return;
+    __shared__ unsigned part[4][kCloudTile];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int u = blockIdx.x * kCloudTile + lane, rb = blockIdx.y;
     unsigned n = 0;
-    for (int v = 0; v < H; v++) n += cloud_keep(z[(size_t)v * W + u], fov_min, fov_max) ? 1u : 0u;
-    counts[u] = n;
-}
-
-// offsets[u] = sum of counts[0..u), offsets[W] = total.  One workgroup; W <= a few thousand.
-__global__ __launch_bounds__(1024) void slx_cloud_scan_kernel(const unsigned *counts, unsigned *offsets, int W)
-{
-    __shared__ unsigned part[1024];
-    const unsigned t = threadIdx.x;
-    const int per = (W + 1023) / 1024;
-    unsigned sum = 0;
-    for (int i = 0; i < per; i++) {
-        const int u = (int)t * per + i;
-        if (u < W) sum += counts[u];
-    }
-    part[t] = sum;
-    __syncthreads();
-    for (unsigned d = 1; d < 1024; d <<= 1) {                       // Hillis-Steele inclusive scan of the partials
-        const unsigned v = t >= d ? part[t - d] : 0u;
-        __syncthreads();
-        part[t] += v;
-        __syncthreads();
-    }
-    unsigned run = t ? part[t - 1] : 0u;
-    for (int i = 0; i < per; i++) {
-        const int u = (int)t * per + i;
-        if (u < W) {
-            offsets[u] = run;
-            run += counts[u];
+    if (u < W) {
+#pragma unroll 4
+        for (int k = 0; k < 16; k++) {
+            const int v = rb * kCloudTile + wave * 16 + k;
+            if (v < H) n += cloud_keep(z[(size_t)v * W + u], fov_min, fov_max) ? 1u : 0u;
         }
     }
-    if (t == 1023) offsets[W] = part[1023];
+    part[wave][lane] = n;
+    __syncthreads();
+    if (wave == 0 && u < W) counts[(size_t)u * RB + rb] = part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane];
 }
 
-__global__ __launch_bounds__(256) void slx_cloud_write_kernel(const double *z, const unsigned *offsets, double *xyz, int W, int H, int row_offset,
+// offsets[i] = sum of counts[0..i), offsets[n] = total.  One workgroup of 16 waves; n is a few tens of thousands.
+// Each wave owns a contiguous chunk: a first pass sums it (coalesced), the 16 chunk sums give every wave its base,
+// and a second pass scans the chunk 64 entries at a time with wave shuffles.
+__global__ __launch_bounds__(1024) void slx_cloud_scan_kernel(const unsigned *counts, unsigned *offsets, int n)
+{
+    __shared__ unsigned wave_total[16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int chunk = ((n + 15) / 16 + 63) & ~63;                   // entries per wave, a multiple of 64
+    const int lo = wave * chunk, hi = lo + chunk < n ? lo + chunk : n;
+    unsigned sum = 0;
+    for (int i = lo + lane; i < hi; i += 64) sum += counts[i];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) sum += __shfl_xor(sum, d);
+    if (lane == 0) wave_total[wave] = sum;
+    __syncthreads();
+    unsigned run = 0;
+    for (int w = 0; w < wave; w++) run += wave_total[w];
+    for (int i0 = lo; i0 < hi; i0 += 64) {
+        const int i = i0 + lane;
+        const unsigned v = i < hi ? counts[i] : 0u;
+        unsigned incl = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const unsigned t = __shfl_up(incl, d);
+            if (lane >= d) incl += t;
+        }
+        if (i < hi) offsets[i] = run + incl - v;
+        run += __shfl(incl, 63);
+    }
+    if (threadIdx.x == 1023) {
+        unsigned total = 0;
+        for (int w = 0; w < 16; w++) total += wave_total[w];
+        offsets[n] = total;
+    }
+}
+
+__global__ __launch_bounds__(256) void slx_cloud_write_kernel(const double *z, const unsigned *offsets, double *xyz, int W, int H, int RB, int row_offset,
                                                              double fov_min, double fov_max, double cx, double cy, double fu, double fv)
 {
-    const int u = blockIdx.x * blockDim.x + threadIdx.x;
-    if (u >= W) return;
-    size_t o = (size_t)offsets[u] * 3;
-    const double uc = (double)u - cx;                                // R/CCalculation.cpp:762
-    for (int v = 0; v < H; v++) {
-        const double zz = z[(size_t)v * W + u];
-        if (!cloud_keep(zz, fov_min, fov_max)) continue;
-        const double vc = (double)(v + row_offset) - cy;            // :763
-        xyz[o + 0] = zz * uc / fu;                                   // :766
-        xyz[o + 1] = zz * vc / fv;                                   // :767
-        xyz[o + 2] = zz;
-        o += 3;
+    __shared__ double tile[kCloudTile][kCloudTile + 1];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int u0 = blockIdx.x * kCloudTile, rb = blockIdx.y, v0 = rb * kCloudTile;
+    for (int k = 0; k < 16; k++) {                                  // rows in, 512 contiguous bytes per wave
+        const int r = wave * 16 + k, v = v0 + r, u = u0 + lane;
+        tile[r][lane] = (v < H && u < W) ? z[(size_t)v * W + u] : __builtin_nan("");   // NaN passes the reference's test: masked by v < H below
+    }
+    __syncthreads();
+    const int v = v0 + lane;
+    const double vc = (double)(v + row_offset) - cy;                // R/CCalculation.cpp:763
+    for (int k = 0; k < 16; k++) {
+        const int c = wave * 16 + k, u = u0 + c;
+        if (u >= W) break;                                          // uniform over the wave
+        const double zz = tile[lane][c];
+        const bool keep = v < H && cloud_keep(zz, fov_min, fov_max);
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(keep);
+        if (keep) {
+            const unsigned rank = (unsigned)__builtin_popcountll(m & ((1ull << lane) - 1ull));
+            const size_t o = ((size_t)offsets[(size_t)u * RB + rb] + rank) * 3;
+            const double uc = (double)u - cx;                       // :762
+            xyz[o + 0] = zz * uc / fu;                              // :766
+            xyz[o + 1] = zz * vc / fv;                              // :767
+            xyz[o + 2] = zz;
+        }
     }
 }
 
@@ -1036,23 +1070,27 @@ kernel_fn pick_strip(int F)
 
 int slx_num_variants(void) { return 4; }
 
+int slx_cloud_entries(int width, int height) { return width * ((height + kCloudTile - 1) / kCloudTile); }
+
 int slx_launch_cloud_count(const SlxKParams &kp, const double *z, unsigned *counts, void *stream)
 {
-    hipLaunchKernelGGL(slx_cloud_count_kernel, dim3((kp.width + 255) / 256), dim3(256), 0, (hipStream_t)stream, z, counts, kp.width, kp.height,
-                       kp.fov_min, kp.fov_max);
+    const int RB = (kp.height + kCloudTile - 1) / kCloudTile;
+    hipLaunchKernelGGL(slx_cloud_count_kernel, dim3((kp.width + kCloudTile - 1) / kCloudTile, RB), dim3(256), 0, (hipStream_t)stream, z, counts, kp.width,
+                       kp.height, RB, kp.fov_min, kp.fov_max);
     return (int)hipGetLastError();
 }
 
-int slx_launch_cloud_scan(int width, const unsigned *counts, unsigned *offsets, void *stream)
+int slx_launch_cloud_scan(int n_entries, const unsigned *counts, unsigned *offsets, void *stream)
 {
-    hipLaunchKernelGGL(slx_cloud_scan_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, counts, offsets, width);
+    hipLaunchKernelGGL(slx_cloud_scan_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, counts, offsets, n_entries);
     return (int)hipGetLastError();
 }
 
 int slx_launch_cloud_write(const SlxKParams &kp, const double *z, const unsigned *offsets, double *xyz, void *stream)
 {
-    hipLaunchKernelGGL(slx_cloud_write_kernel, dim3((kp.width + 255) / 256), dim3(256), 0, (hipStream_t)stream, z, offsets, xyz, kp.width, kp.height,
-                       kp.row_offset, kp.fov_min, kp.fov_max, kp.cx, kp.cy, kp.fu, kp.fv);
+    const int RB = (kp.height + kCloudTile - 1) / kCloudTile;
+    hipLaunchKernelGGL(slx_cloud_write_kernel, dim3((kp.width + kCloudTile - 1) / kCloudTile, RB), dim3(256), 0, (hipStream_t)stream, z, offsets, xyz,
+                       kp.width, kp.height, RB, kp.row_offset, kp.fov_min, kp.fov_max, kp.cx, kp.cy, kp.fu, kp.fv);
     return (int)hipGetLastError();
 }
 

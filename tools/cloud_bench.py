@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""Time of the point-cloud compaction (slx_get_point_cloud into device memory: count, scan, write + the 4-byte
+point count read back) on the GPU box.  Usage: tools/cloud_bench.py [--config C4] [--reps 50]"""
+import argparse
+import ctypes as C
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+
+synth = importlib.import_module("structured-light-calculation_amd.synth")
+api = importlib.import_module("structured-light-calculation_amd.api")
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--config", default="C4")
+ap.add_argument("--reps", type=int, default=50)
+a = ap.parse_args()
+spec = synth.make_spec(a.config)
+H, W = spec["height"], spec["width"]
+ph, gr, _ = synth.render(spec, "sphere", seed=9, noise_sigma=1.0)
+xyz = torch.empty((H * W, 3), dtype=torch.float64, device="cuda")
+with api.Context(spec) as ctx:
+    ctx.set_frames(phase=ph, gray=gr)
+    ctx.decode()
+    ctx.synchronize()
+    n = C.c_size_t(0)
+    L = api.lib()
+    for _ in range(5):
+        rc = L.slx_get_point_cloud(ctx._h, xyz.data_ptr(), H * W, C.byref(n), api.MEM_DEVICE)
+        assert rc == 0, ctx.last_error()
+    t0 = time.perf_counter()
+    for _ in range(a.reps):
+        L.slx_get_point_cloud(ctx._h, xyz.data_ptr(), H * W, C.byref(n), api.MEM_DEVICE)
+    dt = (time.perf_counter() - t0) / a.reps
+# depth read twice (count, write) + 24 B per kept point written
+bytes_ = 2 * 8 * H * W + 24 * n.value
+print(json.dumps({"metric": "point clouds/s (device to device)", "config": a.config, "points": n.value, "pixels": H * W,
+                  "us_per_cloud": dt * 1e6, "value": 1 / dt, "achieved_GBps": bytes_ / dt / 1e9}))
