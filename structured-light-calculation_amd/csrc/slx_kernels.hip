@@ -16,6 +16,8 @@
 // R/ = DynaFrame/DynaFrame/ of the reference repository.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include <cstdlib>
 
 #include "slx_kernels.h"
@@ -621,10 +623,14 @@ __global__ __launch_bounds__(256) void slx_strip_kernel(const SlxKParams p)
     constexpr bool HAS_GRAY = MODE == SLX_MODE_GRAY_PHASE || MASKED;
     // The ring moves CHUNKS: with 4 steps a chunk is a whole row of the fringe stack, with 8 steps it is one
     // frequency of a row (8 planes), so that the ring stays 4 KiB per wave and 4 waves per SIMD still fit.
-    constexpr int CPR = NS == 4 ? 1 : F;          // chunks per row
-    constexpr int NPH = NS == 4 ? F * 4 : 8;      // phase planes in a chunk
-    constexpr int NP = NPH + 2 * GB;              // planes in a chunk
-    constexpr unsigned ROW_DW = NP * 64;          // one chunk in LDS, dwords per wave
+    // Gray planes that ride the ring are a chunk of their own (the second of the row): the ring is then
+    // max(4 F, 2 GB) planes wide instead of 4 F + 2 GB, which is what lets 4 waves per SIMD fit beside it.
+    constexpr bool GRAY_CHUNK = NS == 4 && GB > 0;
+    constexpr int CPR = NS == 4 ? (GRAY_CHUNK ? 2 : 1) : F;   // chunks per row
+    constexpr int NPH = NS == 4 ? F * 4 : 8;      // planes in a phase chunk
+    constexpr int NGR = 2 * GB;                   // planes in the Gray chunk
+    constexpr int NPMAX = NPH > NGR ? NPH : NGR;
+    constexpr unsigned ROW_DW = NPMAX * 64;       // one ring slot in LDS, dwords per wave
     typedef double vec2 __attribute__((ext_vector_type(2)));
     typedef __attribute__((address_space(3))) void lds_void;
     // LDS per wave: [fringe-stack ring: 2 chunks x NP planes x 256 B] [2 KiB depth staging]
@@ -690,12 +696,15 @@ __global__ __launch_bounds__(256) void slx_strip_kernel(const SlxKParams p)
         // every byte is read once: nontemporal loads (+1.6 % on config 4) -- except in the Gray-mask mode, whose halo
         // quads are re-read by the neighbouring wave out of L2 (-10 % with nt there)
         constexpr int AUX = MASKED ? 0 : 2;
+        if (GRAY_CHUNK && cc == 1) {
 #pragma unroll
-        for (int k = 0; k < NPH; k++)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void *)(dst + k * 64), 4, voff, p.phase_rel[cc * NPH + k], 0, AUX);
+            for (int k = 0; k < NGR; k++)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void *)(dst + k * 64), 4, voff, gray_soff[k], 0, AUX);
+        } else {
 #pragma unroll
-        for (int k = 0; k < 2 * GB; k++)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void *)(dst + (NPH + k) * 64), 4, voff, gray_soff[k], 0, AUX);
+            for (int k = 0; k < NPH; k++)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void *)(dst + k * 64), 4, voff, p.phase_rel[(NS == 4 ? 0 : cc * NPH) + k], 0, AUX);
+        }
     };
     // Depth stores: buffer stores against a descriptor of this frame-set's depth map -- one 32-bit byte offset per store
     // slot that advances by a constant per row, and the hardware's range check drops the rows past the tile (and the
@@ -739,9 +748,10 @@ __global__ __launch_bounds__(256) void slx_strip_kernel(const SlxKParams p)
         for (int c = 0; c < CPR; c++) {
             const unsigned g = i * CPR + c;
             const unsigned slot = g & 1u;
-            // vmcnt retires in issue order: "all but the NP youngest" = everything up to this chunk's DMA
-            if (g + 1 < total_chunks) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // vmcnt retires in issue order: "all but the youngest chunk's loads" = everything up to this chunk's DMA
+            if (g + 1 >= total_chunks) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if (GRAY_CHUNK && c == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NGR) : "memory");   // the Gray chunk is the younger one
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPH) : "memory");
             if (c == 0 && i > 0) flush_row(i - 1);                      // last row's stores, one step late
             if (row < H) {
                 const uint32_t *src = ring + slot * ROW_DW + lane;
@@ -769,7 +779,7 @@ __global__ __launch_bounds__(256) void slx_strip_kernel(const SlxKParams p)
                     pix[c][3] = p23.y;
                 }
 #pragma unroll
-                for (int f = 0; f < (NS == 4 ? F : 0); f++) {
+                for (int f = 0; f < ((NS == 4 && c == 0) ? F : 0); f++) {
                     const uint32_t w0 = src[(f * 4 + 0) * 64], w1 = src[(f * 4 + 1) * 64];
                     const uint32_t w2 = src[(f * 4 + 2) * 64], w3 = src[(f * 4 + 3) * 64];
                     // differences as denormals (x 2^-149), rescaled to x 2^-23 by one packed multiply per pair
@@ -783,8 +793,10 @@ __global__ __launch_bounds__(256) void slx_strip_kernel(const SlxKParams p)
                     pix[f][2] = p23.x;
                     pix[f][3] = p23.y;
                 }
+                if (GRAY_CHUNK && c == 1) {
 #pragma unroll
-                for (int k = 0; k < 2 * GB; k++) gw[k] = src[(NPH + k) * 64];
+                    for (int k = 0; k < NGR; k++) gw[k] = src[k * 64];
+                }
                 // the slot is free once it has been read: chunk g+2 goes into it
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             }
@@ -1223,13 +1235,14 @@ int slx_launch_fused(const SlxKParams &kp_in, int mode, bool aux, int n_sets, in
             kp.gray_set_delta = delta;
         }
     }
-    // LDS per wave: 2 ring chunks ((4 n_freq + 2 gb) planes with 4 steps, 8 planes with 8 steps, 256 B each) + 2 KiB of depth staging
+    // LDS per wave: 2 ring slots (max(4 n_freq, 2 gb) planes with 4 steps, 8 planes with 8 steps, 256 B each) + 2 KiB of depth staging
     unsigned waves_per_wg = 4u;
     if (const char *e = getenv("SLX_STRIP_WAVES")) {               // tuning hook
         const int v = atoi(e);
         if (v >= 1 && v <= 4) waves_per_wg = (unsigned)v;
     }
-    const unsigned lds_wave = 2u * ((kp.n_steps == 4 ? (unsigned)kp.n_freq * 4u : 8u) + 2u * (unsigned)gb) * 256u + 2048u;
+    const unsigned ring_planes = kp.n_steps == 4 ? std::max((unsigned)kp.n_freq * 4u, 2u * (unsigned)gb) : 8u;
+    const unsigned lds_wave = 2u * ring_planes * 256u + 2048u;
     if (lds_wave * waves_per_wg > 32u * 1024u) waves_per_wg = 2u;       // keep >= 5 workgroups per CU
     const unsigned threads = waves_per_wg * 64u;
     const unsigned long long need_wgs = (kp.total_items + waves_per_wg - 1) / waves_per_wg;
