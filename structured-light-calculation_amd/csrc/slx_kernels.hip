@@ -968,32 +968,52 @@ __global__ __launch_bounds__(256) void slx_cloud_count_kernel(const double *z, u
 }
 
 // offsets[i] = sum of counts[0..i), offsets[n] = total.  One workgroup of 16 waves; n is a few tens of thousands.
-// Each wave owns a contiguous chunk: a first pass sums it (coalesced), the 16 chunk sums give every wave its base,
-// and a second pass scans the chunk 64 entries at a time with wave shuffles.
+// Each wave owns a contiguous chunk: a first pass sums it, the 16 chunk sums give every wave its base, and a second
+// pass scans the chunk 256 entries at a time -- four consecutive entries per lane, wave shuffles across the lanes.
 __global__ __launch_bounds__(1024) void slx_cloud_scan_kernel(const unsigned *counts, unsigned *offsets, int n)
 {
     __shared__ unsigned wave_total[16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int chunk = ((n + 15) / 16 + 63) & ~63;                   // entries per wave, a multiple of 64
+    const int chunk = ((n + 15) / 16 + 255) & ~255;                 // entries per wave, a multiple of 256
     const int lo = wave * chunk, hi = lo + chunk < n ? lo + chunk : n;
+    auto load4 = [&](int i, unsigned v[4]) {                        // entries i .. i+3, zeros past the chunk
+        if (i + 3 < hi) {
+            const uint4 q = *reinterpret_cast<const uint4 *>(counts + i);   // i is a multiple of 4, hipMalloc aligns the base
+            v[0] = q.x, v[1] = q.y, v[2] = q.z, v[3] = q.w;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; j++) v[j] = i + j < hi ? counts[i + j] : 0u;
+        }
+    };
     unsigned sum = 0;
-    for (int i = lo + lane; i < hi; i += 64) sum += counts[i];
+    for (int i = lo + 4 * lane; i < hi; i += 256) {
+        unsigned v[4];
+        load4(i, v);
+        sum += (v[0] + v[1]) + (v[2] + v[3]);
+    }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) sum += __shfl_xor(sum, d);
     if (lane == 0) wave_total[wave] = sum;
     __syncthreads();
     unsigned run = 0;
     for (int w = 0; w < wave; w++) run += wave_total[w];
-    for (int i0 = lo; i0 < hi; i0 += 64) {
-        const int i = i0 + lane;
-        const unsigned v = i < hi ? counts[i] : 0u;
-        unsigned incl = v;
+    for (int i0 = lo; i0 < hi; i0 += 256) {
+        const int i = i0 + 4 * lane;
+        unsigned v[4];
+        load4(i, v);
+        const unsigned mine = (v[0] + v[1]) + (v[2] + v[3]);
+        unsigned incl = mine;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
             const unsigned t = __shfl_up(incl, d);
             if (lane >= d) incl += t;
         }
-        if (i < hi) offsets[i] = run + incl - v;
+        unsigned o = run + incl - mine;                             // exclusive offset of this lane's first entry
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            if (i + j < hi) offsets[i + j] = o;
+            o += v[j];
+        }
         run += __shfl(incl, 63);
     }
     if (threadIdx.x == 1023) {
