@@ -185,8 +185,8 @@ int slx_get_calibration(const slx_ctx *ctx, double P[12], double *cA, double *cB
 int slx_enable_timing(slx_ctx *ctx, int on);
 int slx_last_decode_ms(slx_ctx *ctx, float *ms);
 
-/* Diagnostics: when set (device buffer of >= 32768 u64 words, or NULL to stop), every wave of the
- * fast kernel records s_memtime / s_memrealtime at entry and exit into words [4*(16*wg+wave) .. +3]. */
+/* Diagnostics: when set (device buffer of >= 32768 u64 words, or NULL to stop), the first n_words / 4 work items
+ * (waves) of the fast kernel record s_memtime / s_memrealtime at entry and exit into words [4*item .. 4*item+3]. */
 int slx_debug_stamps(slx_ctx *ctx, unsigned long long *device_words, size_t n_words);
 
 /* Selects the kernel variant (0 = default); tuning / A-B benchmarking only. */

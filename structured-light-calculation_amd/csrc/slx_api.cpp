@@ -876,6 +876,7 @@ int slx_debug_stamps(slx_ctx *ctx, unsigned long long *device_words, size_t n_wo
     if (!ctx) return SLX_ERR_INVALID_ARG;
     if (device_words && n_words < 4 * 8192) return fail(ctx, SLX_ERR_INVALID_ARG, "stamp buffer needs at least 32768 words");
     ctx->kp.stamps = device_words;
+    ctx->kp.stamp_items = device_words ? n_words / 4 : 0;
     return SLX_OK;
 }
 

@@ -48,10 +48,14 @@ struct SlxKParams {
     unsigned chunks_per_group;                  // interleave * quads_per_row / 64 (64-quad chunks of a row group)
     unsigned rows_per_lane;                     // rows one lane walks per work item (even)
     unsigned items_per_set;                     // ceil(H / (interleave * rows_per_lane)) * chunks_per_group
-    unsigned long long total_items;             // items_per_set * n_sets
+    unsigned long long total_items;             // all items of the launch
+    unsigned long long items_head;              // items [0, items_head) are the long ones: items_per_set per frame-set, rows_per_lane rows each
+    unsigned rows_per_lane_tail;                // items [items_head, total_items): the rows from tail_row0 on, in items of this many rows
+    unsigned items_per_set_tail, tail_row0;
     int fast_arith;                             // generic kernel: use the bit-identical cheap unwrap / in-range division (host-checked)
     int dbg;                                    // experiments only (SLX_DBG): 1 = skip stores, 2 = skip compute
-    unsigned long long *stamps;                 // diagnostics: 4 words per workgroup (s_memtime / s_memrealtime at start, end) or null
+    unsigned long long *stamps;                 // diagnostics: 4 words per work item (s_memtime / s_memrealtime at start, end) or null
+    unsigned long long stamp_items;             // items the stamp buffer has room for
 };
 
 // Kernel variants (slx_set_variant): 0 = automatic (strip kernel when eligible, else the generic kernel with

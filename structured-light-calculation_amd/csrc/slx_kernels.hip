@@ -582,16 +582,17 @@ struct StripPos {
 // either side (lanes 0 and 63), so the 3-tap horizontal AND of x3 never leaves the wave; chunks then
 // advance by 62 quads and the run a wave stores is the 62 inner quads.
 template <bool HALO>
-__device__ __forceinline__ StripPos strip_locate(const SlxKParams &p, unsigned item, bool &lane_valid)
+__device__ __forceinline__ StripPos strip_locate(const SlxKParams &p, unsigned item, unsigned items_per_set, unsigned rows_per_lane, unsigned row0,
+                                                 bool &lane_valid)
 {
     constexpr unsigned SPAN = HALO ? 62u : 64u;
     StripPos s;
     const unsigned lane = threadIdx.x & 63u;
-    s.set = item / p.items_per_set;
-    const unsigned rem = item - s.set * p.items_per_set;
+    s.set = item / items_per_set;
+    const unsigned rem = item - s.set * items_per_set;
     const unsigned g = rem / p.chunks_per_group;
     const unsigned c = rem - g * p.chunks_per_group;
-    const unsigned row_base = g * p.rows_per_lane * p.interleave;
+    const unsigned row_base = row0 + g * rows_per_lane * p.interleave;
     const unsigned total = p.interleave * p.quads_per_row;           // quads of one row group, rows laid end to end
     const int idx_raw = (int)(c * SPAN + lane) - (HALO ? 1 : 0);
     lane_valid = idx_raw >= 0 && (unsigned)idx_raw < total;
@@ -646,20 +647,32 @@ __global__ __launch_bounds__(256) void slx_strip_kernel(const SlxKParams p)
     // an L2), so consecutive items go to ONE XCD: neighbouring chunks of the Gray-mask mode overlap by a halo quad
     // and start at 248-byte multiples, and their shared 128-byte lines are then fetched from HBM once, not twice.
     // Placement only affects speed; any dispatch order gives the same result.
+    // The other modes have no reuse and run in plain order, which is what lets the LAST items be the small ones (below).
     unsigned wg = blockIdx.x;
-    if (p.dbg != 4) {                                               // SLX_DBG=4: plain order, for A/B measurements
+    if (MASKED && p.dbg != 4) {                                     // SLX_DBG=4: plain order, for A/B measurements
         const unsigned nb = gridDim.x, q = nb >> 3, r = nb & 7u, x = wg & 7u, within = wg >> 3;
         wg = x * q + (x < r ? x : r) + within;
     }
-    const unsigned item = wg * (blockDim.x >> 6) + wave_in_wg;
+    unsigned item = wg * (blockDim.x >> 6) + wave_in_wg;
     if (item >= p.total_items) return;
-    if (p.stamps && lane == 0 && item < 8192) {   // diagnostics only (slx_debug_stamps)
-        p.stamps[4 * item + 0] = __builtin_amdgcn_s_memtime();
-        p.stamps[4 * item + 2] = __builtin_amdgcn_s_memrealtime();
+    // Two regions of items: the head of every frame-set in items of rows_per_lane rows, then the last rows of every
+    // frame-set in short items (rows_per_lane_tail).  Long items amortise the item start-up; the short ones run last and
+    // cut the end of the launch, where the chip drains for about one item's lifetime, to a quarter.
+    unsigned RB = p.rows_per_lane, items_per_set = p.items_per_set, region_row0 = 0;
+    const unsigned item_id = item;
+    if (item >= p.items_head) {
+        item -= (unsigned)p.items_head;
+        RB = p.rows_per_lane_tail;
+        items_per_set = p.items_per_set_tail;
+        region_row0 = p.tail_row0;
+    }
+    if (p.stamps && lane == 0 && item_id < p.stamp_items) {   // diagnostics only (slx_debug_stamps)
+        p.stamps[4 * item_id + 0] = __builtin_amdgcn_s_memtime();
+        p.stamps[4 * item_id + 2] = __builtin_amdgcn_s_memrealtime();
     }
     const unsigned W = (unsigned)p.width, H = (unsigned)p.height;
     const unsigned row_stride = (unsigned)p.row_stride;
-    const unsigned RB = p.rows_per_lane, step_rows = p.interleave;
+    const unsigned step_rows = p.interleave;
     const unsigned last_row = H - 1u;
     float Tf[F];
 #pragma unroll
@@ -674,7 +687,7 @@ __global__ __launch_bounds__(256) void slx_strip_kernel(const SlxKParams p)
     }
 
     bool lane_valid;
-    const StripPos pos = strip_locate<MASKED>(p, item, lane_valid);
+    const StripPos pos = strip_locate<MASKED>(p, item, items_per_set, RB, region_row0, lane_valid);
     const size_t pset = (size_t)pos.set * p.phase_set_stride;
     const size_t gset = (size_t)pos.set * p.gray_set_stride;
     double *zset = p.z + (size_t)pos.set * p.out_set_stride;
@@ -927,9 +940,9 @@ __global__ __launch_bounds__(256) void slx_strip_kernel(const SlxKParams p)
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     flush_row(RB - 1);
-    if (p.stamps && lane == 0 && item < 8192) {
-        p.stamps[4 * item + 1] = __builtin_amdgcn_s_memtime();
-        p.stamps[4 * item + 3] = __builtin_amdgcn_s_memrealtime();
+    if (p.stamps && lane == 0 && item_id < p.stamp_items) {
+        p.stamps[4 * item_id + 1] = __builtin_amdgcn_s_memtime();
+        p.stamps[4 * item_id + 3] = __builtin_amdgcn_s_memrealtime();
     }
 }
 
@@ -1232,6 +1245,29 @@ int slx_launch_fused(const SlxKParams &kp_in, int mode, bool aux, int n_sets, in
     const unsigned groups = ((unsigned)kp.height + rows_group - 1) / rows_group;
     kp.items_per_set = groups * kp.chunks_per_group;
     kp.total_items = (unsigned long long)kp.items_per_set * (unsigned)n_sets;
+    kp.items_head = kp.total_items;
+    kp.rows_per_lane_tail = rb;
+    kp.items_per_set_tail = 0;
+    kp.tail_row0 = 0;
+    // Short items at the end of the launch (plain-order modes, launches of many long items): the last ~20 % of every
+    // frame-set's rows go in items a quarter as long, dispatched after all the long ones.
+    unsigned tail_pct = 20, tail_rb = rb / 4;
+    if (const char *e = getenv("SLX_TAIL_PCT")) tail_pct = (unsigned)atoi(e);          // tuning hooks
+    if (const char *e = getenv("SLX_TAIL_ROWS")) tail_rb = (unsigned)atoi(e);
+    if (mode != SLX_MODE_MULTIFREQ_GRAYMASK && rb >= 8 && tail_rb >= 1 && tail_rb < rb && tail_pct > 0 && tail_pct < 100 && groups >= 4) {
+        unsigned head_groups = (unsigned)((unsigned long long)groups * (100u - tail_pct) / 100u);
+        if (head_groups >= 1 && head_groups < groups) {
+            const unsigned head_rows = head_groups * rows_group;                     // < height
+            const unsigned tail_group_rows = kp.interleave * tail_rb;
+            const unsigned tail_groups = ((unsigned)kp.height - head_rows + tail_group_rows - 1) / tail_group_rows;
+            kp.items_per_set = head_groups * kp.chunks_per_group;
+            kp.items_per_set_tail = tail_groups * kp.chunks_per_group;
+            kp.rows_per_lane_tail = tail_rb;
+            kp.tail_row0 = head_rows;
+            kp.items_head = (unsigned long long)kp.items_per_set * (unsigned)n_sets;
+            kp.total_items = kp.items_head + (unsigned long long)kp.items_per_set_tail * (unsigned)n_sets;
+        }
+    }
     // Gray planes ride the DMA ring when there are 6 bits of them (the reference's and config 3's count) and every
     // plane, in every frame-set of the launch, sits within 2 GiB above the lowest plane; otherwise the kernel reads
     // them with ordinary loads

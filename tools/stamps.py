@@ -26,7 +26,7 @@ print("data mode", mode)
 z = torch.empty((n_sets, H, W), dtype=torch.float64, device="cuda")
 ctx = api.Context(spec)
 ctx.set_variant(variant)
-st = torch.zeros(32768, dtype=torch.int64, device="cuda")
+st = torch.zeros(4 * 65536, dtype=torch.int64, device="cuda")
 s = torch.cuda.Stream(); torch.cuda.set_stream(s)
 for _ in range(300):       # ~2 s of back-to-back launches so the clock settles
     ctx.decode_batch(n_sets, phase, None, z, stream=s.cuda_stream)
@@ -50,3 +50,12 @@ print("waves", len(w), "kernel span %.1f us" % ((t1 - t0) / 100.0))
 print("per-wave duration us: min %.1f median %.1f max %.1f" % (real.min() * 1e6, sorted(real)[len(real) // 2] * 1e6, real.max() * 1e6))
 print("in-kernel clock GHz: median %.3f" % (sorted(cyc / real)[len(cyc) // 2] / 1e9))
 print("start skew us: %.1f" % ((w[:, 2].max() - t0) / 100.0))
+
+# how many waves are alive over the kernel's span: the ramp at the start and the tail at the end
+import numpy as np
+ts = np.linspace(t0, t1, 60)
+alive = [(int(((w[:, 2] <= t) & (w[:, 3] > t)).sum())) for t in ts]
+print("alive waves over the span (60 samples):", alive)
+peak = max(alive)
+full = [t for t, a in zip(ts, alive) if a >= 0.9 * peak]
+print("span with >= 90 %% of the peak wave count: %.1f us of %.1f us" % ((full[-1] - full[0]) / 100.0, (t1 - t0) / 100.0))
