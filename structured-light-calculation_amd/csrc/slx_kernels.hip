@@ -101,27 +101,7 @@ __device__ __forceinline__ int byte_diff(uint32_t a, uint32_t b)
 //  * RN(x/360) by the same residual correction with r = RN(1/360);
 //  * (float)((double)q * (double)T) == q*T in f32 (the double product is exact), and
 //    (float)((double)pix + 0.5) == pix + 0.5f (the double sum is exact for pix = 0 or >= 2^-11).
-__device__ __forceinline__ float wrapped_pix_from_diffs(float s2, float c2, float Tf)
-{
-    const float as = __builtin_fabsf(s2), ac = __builtin_fabsf(c2);
-    const float mx = __builtin_fmaxf(__builtin_fmaxf(as, ac), 1.0f);
-    const float mn = __builtin_fminf(as, ac);
-    const float r = __builtin_amdgcn_rcpf(mx);
-    const float q0 = mn * r;
-    const float c = __builtin_fmaf(__builtin_fmaf(-mx, q0, mn), r, q0);
-    const float cc = c * c;
-    float a = (((kP7 * cc + kP5) * cc + kP3) * cc + kP1) * c;
-    a = (as > ac) ? 90.f - a : a;
-    a = (c2 < 0.f) ? 180.f - a : a;
-    a = (s2 < 0.f) ? 360.f - a : a;
-    const float d0 = a * kInv360;
-    const float d = __builtin_fmaf(__builtin_fmaf(-360.f, d0, a), kInv360, d0);
-    float pix = d * Tf;
-    pix = pix + 0.5f;
-    pix = (pix > Tf) ? pix - Tf : pix;
-    return pix;
-}
-
+// wrapped_pix_from_diffs2 evaluates two pixels per instruction (f32x2 operands -> v_pk_*_f32).
 // SCALED: s2, c2 carry the integer differences times 2^-23 (byte_diff_scaled below).  Every use of them is invariant
 // under a power-of-two scale that stays inside the normal range -- max/min/compare, v_rcp_f32 (a function of the
 // mantissa), the quotient and its residual, the sign tests -- so the result is the same bit for bit; only the
@@ -157,11 +137,6 @@ __device__ __forceinline__ f32x2 wrapped_pix_from_diffs2(f32x2 s2, f32x2 c2, flo
     pix = pix + 0.5f;
     const f32x2 mw = pk_mul_sat(pix - Tf, f32x2{0x1p60f, 0x1p60f});
     return __builtin_elementwise_fma(f32x2{-Tf, -Tf}, mw, pix);
-}
-
-__device__ __forceinline__ float wrapped_pix_4step(float g0, float g1, float g2, float g3, float Tf)
-{
-    return wrapped_pix_from_diffs(g0 - g2, g1 - g3, Tf);
 }
 
 // a2 literally (any float inputs): used by the x1 path, N != 4.
@@ -366,9 +341,16 @@ __global__ __launch_bounds__(256) void slx_fused_kernel(const SlxKParams p)
                 const uint32_t w2 = load_quad(p.phase[f * 4 + 2], set_off, aligned, npx);
                 const uint32_t w3 = load_quad(p.phase[f * 4 + 3], set_off, aligned, npx);
                 const float Tf = (float)p.period[f];
-#pragma unroll
-                for (int j = 0; j < SLX_QUAD; j++)
-                    pix[f][j] = wrapped_pix_4step(ubyte(w0, j), ubyte(w1, j), ubyte(w2, j), ubyte(w3, j), Tf);
+                // two pixels per instruction, byte differences as rescaled denormals: see wrapped_pix_from_diffs2
+                const f32x2 kUp = {0x1p126f, 0x1p126f};
+                const f32x2 p01 = wrapped_pix_from_diffs2<true>(f32x2{byte_diff_denorm<0>(w0, w2), byte_diff_denorm<1>(w0, w2)} * kUp,
+                                                                f32x2{byte_diff_denorm<0>(w1, w3), byte_diff_denorm<1>(w1, w3)} * kUp, Tf);
+                const f32x2 p23 = wrapped_pix_from_diffs2<true>(f32x2{byte_diff_denorm<2>(w0, w2), byte_diff_denorm<3>(w0, w2)} * kUp,
+                                                                f32x2{byte_diff_denorm<2>(w1, w3), byte_diff_denorm<3>(w1, w3)} * kUp, Tf);
+                pix[f][0] = p01.x;
+                pix[f][1] = p01.y;
+                pix[f][2] = p23.x;
+                pix[f][3] = p23.y;
             } else {
                 float sy[SLX_QUAD] = {0.f, 0.f, 0.f, 0.f}, sx[SLX_QUAD] = {0.f, 0.f, 0.f, 0.f};
                 const int N = p.n_steps;
