@@ -139,6 +139,82 @@ __device__ __forceinline__ f32x2 wrapped_pix_from_diffs2(f32x2 s2, f32x2 c2, flo
     return __builtin_elementwise_fma(f32x2{-Tf, -Tf}, mw, pix);
 }
 
+// The same on two pixel pairs in lockstep: every statement is issued for pair A, then for pair B, so that dependent
+// packed operations (which need a wait state between them: hipcc pads with s_nop, and an s_nop costs the wave an issue
+// turn just like a real instruction) have an independent operation of the other pair between them.
+template <bool SCALED>
+__device__ __forceinline__ void wrapped_pix_from_diffs2x2(f32x2 sA, f32x2 cA, f32x2 sB, f32x2 cB, float Tf, f32x2 &outA, f32x2 &outB)
+{
+    constexpr float kGuard = SCALED ? 0x1p-23f : 1.0f;
+    const f32x2 asA = {__builtin_fabsf(sA.x), __builtin_fabsf(sA.y)}, acA = {__builtin_fabsf(cA.x), __builtin_fabsf(cA.y)};
+    const f32x2 asB = {__builtin_fabsf(sB.x), __builtin_fabsf(sB.y)}, acB = {__builtin_fabsf(cB.x), __builtin_fabsf(cB.y)};
+    const f32x2 mxA = {__builtin_fmaxf(__builtin_fmaxf(asA.x, acA.x), kGuard), __builtin_fmaxf(__builtin_fmaxf(asA.y, acA.y), kGuard)};
+    const f32x2 mxB = {__builtin_fmaxf(__builtin_fmaxf(asB.x, acB.x), kGuard), __builtin_fmaxf(__builtin_fmaxf(asB.y, acB.y), kGuard)};
+    const f32x2 mnA = {__builtin_fminf(asA.x, acA.x), __builtin_fminf(asA.y, acA.y)};
+    const f32x2 mnB = {__builtin_fminf(asB.x, acB.x), __builtin_fminf(asB.y, acB.y)};
+    const f32x2 rA = {__builtin_amdgcn_rcpf(mxA.x), __builtin_amdgcn_rcpf(mxA.y)};
+    const f32x2 rB = {__builtin_amdgcn_rcpf(mxB.x), __builtin_amdgcn_rcpf(mxB.y)};
+    const f32x2 q0A = mnA * rA;
+    const f32x2 q0B = mnB * rB;
+    const f32x2 eA = __builtin_elementwise_fma(-mxA, q0A, mnA);
+    const f32x2 eB = __builtin_elementwise_fma(-mxB, q0B, mnB);
+    const f32x2 qA = __builtin_elementwise_fma(eA, rA, q0A);
+    const f32x2 qB = __builtin_elementwise_fma(eB, rB, q0B);
+    const f32x2 ccA = qA * qA;
+    const f32x2 ccB = qB * qB;
+    f32x2 tA = kP7 * ccA;
+    f32x2 tB = kP7 * ccB;
+    tA = tA + kP5;
+    tB = tB + kP5;
+    tA = tA * ccA;
+    tB = tB * ccB;
+    tA = tA + kP3;
+    tB = tB + kP3;
+    tA = tA * ccA;
+    tB = tB * ccB;
+    tA = tA + kP1;
+    tB = tB + kP1;
+    f32x2 aA = tA * qA;
+    f32x2 aB = tB * qB;
+    const f32x2 a90A = 90.f - aA;
+    const f32x2 a90B = 90.f - aB;
+    aA = f32x2{asA.x > acA.x ? a90A.x : aA.x, asA.y > acA.y ? a90A.y : aA.y};
+    aB = f32x2{asB.x > acB.x ? a90B.x : aB.x, asB.y > acB.y ? a90B.y : aB.y};
+    const f32x2 one = {1.f, 1.f}, mtwo = {-2.f, -2.f}, big = {-0x1p60f, -0x1p60f};
+    const f32x2 mcA = SCALED ? pk_mul_sat(cA, big) : pk_neg_sat(cA);
+    const f32x2 mcB = SCALED ? pk_mul_sat(cB, big) : pk_neg_sat(cB);
+    const f32x2 scA = __builtin_elementwise_fma(mtwo, mcA, one);
+    const f32x2 scB = __builtin_elementwise_fma(mtwo, mcB, one);
+    const f32x2 kcA = mcA * 180.f;
+    const f32x2 kcB = mcB * 180.f;
+    aA = __builtin_elementwise_fma(scA, aA, kcA);
+    aB = __builtin_elementwise_fma(scB, aB, kcB);
+    const f32x2 msA = SCALED ? pk_mul_sat(sA, big) : pk_neg_sat(sA);
+    const f32x2 msB = SCALED ? pk_mul_sat(sB, big) : pk_neg_sat(sB);
+    const f32x2 ssA = __builtin_elementwise_fma(mtwo, msA, one);
+    const f32x2 ssB = __builtin_elementwise_fma(mtwo, msB, one);
+    const f32x2 ksA = msA * 360.f;
+    const f32x2 ksB = msB * 360.f;
+    aA = __builtin_elementwise_fma(ssA, aA, ksA);
+    aB = __builtin_elementwise_fma(ssB, aB, ksB);
+    const f32x2 k360 = {kInv360, kInv360}, m360 = {-360.f, -360.f};
+    const f32x2 d0A = aA * kInv360;
+    const f32x2 d0B = aB * kInv360;
+    const f32x2 fA = __builtin_elementwise_fma(m360, d0A, aA);
+    const f32x2 fB = __builtin_elementwise_fma(m360, d0B, aB);
+    const f32x2 dA = __builtin_elementwise_fma(fA, k360, d0A);
+    const f32x2 dB = __builtin_elementwise_fma(fB, k360, d0B);
+    f32x2 pA = dA * Tf;
+    f32x2 pB = dB * Tf;
+    pA = pA + 0.5f;
+    pB = pB + 0.5f;
+    const f32x2 up = {0x1p60f, 0x1p60f}, mT = {-Tf, -Tf};
+    const f32x2 wA = pk_mul_sat(pA - Tf, up);
+    const f32x2 wB = pk_mul_sat(pB - Tf, up);
+    outA = __builtin_elementwise_fma(mT, wA, pA);
+    outB = __builtin_elementwise_fma(mT, wB, pB);
+}
+
 // a2 literally (any float inputs): used by the x1 path, N != 4.
 __device__ __forceinline__ float fast_atan2_deg(float y, float x)
 {
@@ -779,10 +855,11 @@ __global__ __launch_bounds__(256) void slx_strip_kernel(const SlxKParams p)
                     const uint32_t w2 = src[(f * 4 + 2) * 64], w3 = src[(f * 4 + 3) * 64];
                     // differences as denormals (x 2^-149), rescaled to x 2^-23 by one packed multiply per pair
                     const f32x2 kUp = {0x1p126f, 0x1p126f};
-                    const f32x2 p01 = wrapped_pix_from_diffs2<true>(f32x2{byte_diff_denorm<0>(w0, w2), byte_diff_denorm<1>(w0, w2)} * kUp,
-                                                                    f32x2{byte_diff_denorm<0>(w1, w3), byte_diff_denorm<1>(w1, w3)} * kUp, Tf[f]);
-                    const f32x2 p23 = wrapped_pix_from_diffs2<true>(f32x2{byte_diff_denorm<2>(w0, w2), byte_diff_denorm<3>(w0, w2)} * kUp,
-                                                                    f32x2{byte_diff_denorm<2>(w1, w3), byte_diff_denorm<3>(w1, w3)} * kUp, Tf[f]);
+                    f32x2 p01, p23;
+                    wrapped_pix_from_diffs2x2<true>(f32x2{byte_diff_denorm<0>(w0, w2), byte_diff_denorm<1>(w0, w2)} * kUp,
+                                                    f32x2{byte_diff_denorm<0>(w1, w3), byte_diff_denorm<1>(w1, w3)} * kUp,
+                                                    f32x2{byte_diff_denorm<2>(w0, w2), byte_diff_denorm<3>(w0, w2)} * kUp,
+                                                    f32x2{byte_diff_denorm<2>(w1, w3), byte_diff_denorm<3>(w1, w3)} * kUp, Tf[f], p01, p23);
                     pix[f][0] = p01.x;
                     pix[f][1] = p01.y;
                     pix[f][2] = p23.x;
