@@ -101,118 +101,93 @@ __device__ __forceinline__ int byte_diff(uint32_t a, uint32_t b)
 //  * RN(x/360) by the same residual correction with r = RN(1/360);
 //  * (float)((double)q * (double)T) == q*T in f32 (the double product is exact), and
 //    (float)((double)pix + 0.5) == pix + 0.5f (the double sum is exact for pix = 0 or >= 2^-11).
-// wrapped_pix_from_diffs2 evaluates two pixels per instruction (f32x2 operands -> v_pk_*_f32).
-// SCALED: s2, c2 carry the integer differences times 2^-23 (byte_diff_scaled below).  Every use of them is invariant
+// ---- the phase arithmetic on vectors of pixels ---------------------------------------------------------------------
+// f32x2 operands make every multiply / add / fma a packed instruction (two pixels per issue slot).  F32x2x2 is two such
+// pairs evaluated in LOCKSTEP: every operation is issued for pair a, then for pair b.  Dependent packed operations need a
+// wait state between them -- hipcc pads with s_nop, and an s_nop costs the wave an issue turn like a real instruction
+// (122 per row before, 14 after) -- and the other pair's independent operation fills it.
+struct F32x2x2 {
+    f32x2 a, b;
+};
+__device__ __forceinline__ F32x2x2 operator+(F32x2x2 x, float y) { return {x.a + y, x.b + y}; }
+__device__ __forceinline__ F32x2x2 operator-(F32x2x2 x, float y) { return {x.a - y, x.b - y}; }
+__device__ __forceinline__ F32x2x2 operator-(float x, F32x2x2 y) { return {x - y.a, x - y.b}; }
+__device__ __forceinline__ F32x2x2 operator-(F32x2x2 x) { return {-x.a, -x.b}; }
+__device__ __forceinline__ F32x2x2 operator*(F32x2x2 x, F32x2x2 y) { return {x.a * y.a, x.b * y.b}; }
+__device__ __forceinline__ F32x2x2 operator*(F32x2x2 x, float y) { return {x.a * y, x.b * y}; }
+__device__ __forceinline__ F32x2x2 operator*(float x, F32x2x2 y) { return {x * y.a, x * y.b}; }
+
+__device__ __forceinline__ f32x2 v_fma(f32x2 x, f32x2 y, f32x2 z) { return __builtin_elementwise_fma(x, y, z); }
+__device__ __forceinline__ f32x2 v_fma(float x, f32x2 y, float z) { return __builtin_elementwise_fma(f32x2{x, x}, y, f32x2{z, z}); }
+__device__ __forceinline__ f32x2 v_fma(float x, f32x2 y, f32x2 z) { return __builtin_elementwise_fma(f32x2{x, x}, y, z); }
+__device__ __forceinline__ f32x2 v_fma(f32x2 x, float y, f32x2 z) { return __builtin_elementwise_fma(x, f32x2{y, y}, z); }
+__device__ __forceinline__ f32x2 v_fma(f32x2 x, f32x2 y, float z) { return __builtin_elementwise_fma(x, y, f32x2{z, z}); }
+__device__ __forceinline__ f32x2 v_abs(f32x2 x) { return {__builtin_fabsf(x.x), __builtin_fabsf(x.y)}; }
+__device__ __forceinline__ f32x2 v_max(f32x2 x, f32x2 y) { return {__builtin_fmaxf(x.x, y.x), __builtin_fmaxf(x.y, y.y)}; }
+__device__ __forceinline__ f32x2 v_max3(f32x2 x, f32x2 y, float z) { return {__builtin_fmaxf(__builtin_fmaxf(x.x, y.x), z), __builtin_fmaxf(__builtin_fmaxf(x.y, y.y), z)}; }
+__device__ __forceinline__ f32x2 v_min(f32x2 x, f32x2 y) { return {__builtin_fminf(x.x, y.x), __builtin_fminf(x.y, y.y)}; }
+__device__ __forceinline__ f32x2 v_rcp(f32x2 x) { return {__builtin_amdgcn_rcpf(x.x), __builtin_amdgcn_rcpf(x.y)}; }
+// per component: p > q ? x : y
+__device__ __forceinline__ f32x2 v_sel_gt(f32x2 p, f32x2 q, f32x2 x, f32x2 y) { return {p.x > q.x ? x.x : y.x, p.y > q.y ? x.y : y.y}; }
+__device__ __forceinline__ f32x2 v_mul_sat(f32x2 x, float s) { return pk_mul_sat(x, f32x2{s, s}); }
+__device__ __forceinline__ f32x2 v_neg_sat(f32x2 x) { return pk_neg_sat(x); }
+
+#define SLX_LOCKSTEP1(NAME) __device__ __forceinline__ F32x2x2 NAME(F32x2x2 x) { return {NAME(x.a), NAME(x.b)}; }
+SLX_LOCKSTEP1(v_abs)
+SLX_LOCKSTEP1(v_rcp)
+SLX_LOCKSTEP1(v_neg_sat)
+#undef SLX_LOCKSTEP1
+__device__ __forceinline__ F32x2x2 v_fma(F32x2x2 x, F32x2x2 y, F32x2x2 z) { return {v_fma(x.a, y.a, z.a), v_fma(x.b, y.b, z.b)}; }
+__device__ __forceinline__ F32x2x2 v_fma(float x, F32x2x2 y, float z) { return {v_fma(x, y.a, z), v_fma(x, y.b, z)}; }
+__device__ __forceinline__ F32x2x2 v_fma(float x, F32x2x2 y, F32x2x2 z) { return {v_fma(x, y.a, z.a), v_fma(x, y.b, z.b)}; }
+__device__ __forceinline__ F32x2x2 v_fma(F32x2x2 x, float y, F32x2x2 z) { return {v_fma(x.a, y, z.a), v_fma(x.b, y, z.b)}; }
+__device__ __forceinline__ F32x2x2 v_fma(F32x2x2 x, F32x2x2 y, float z) { return {v_fma(x.a, y.a, z), v_fma(x.b, y.b, z)}; }
+__device__ __forceinline__ F32x2x2 v_max(F32x2x2 x, F32x2x2 y) { return {v_max(x.a, y.a), v_max(x.b, y.b)}; }
+__device__ __forceinline__ F32x2x2 v_max3(F32x2x2 x, F32x2x2 y, float z) { return {v_max3(x.a, y.a, z), v_max3(x.b, y.b, z)}; }
+__device__ __forceinline__ F32x2x2 v_min(F32x2x2 x, F32x2x2 y) { return {v_min(x.a, y.a), v_min(x.b, y.b)}; }
+__device__ __forceinline__ F32x2x2 v_sel_gt(F32x2x2 p, F32x2x2 q, F32x2x2 x, F32x2x2 y) { return {v_sel_gt(p.a, q.a, x.a, y.a), v_sel_gt(p.b, q.b, x.b, y.b)}; }
+__device__ __forceinline__ F32x2x2 v_mul_sat(F32x2x2 x, float s) { return {v_mul_sat(x.a, s), v_mul_sat(x.b, s)}; }
+
+// From the angle's first-octant value to pix: the 90 / 180 / 360 degree fix-ups, RN(a / 360) * T + 0.5 and the wrap.
+// The sign fix-ups and the final wrap are selects; compares and v_cndmask do not pack, but a saturating packed multiply
+// does (VOP3P clamp, which hipcc does not emit for f32 pairs): m = sat(-2^60 x) is 1 where x < 0 and 0 elsewhere (|x| is 0
+// or far above 2^-60), and fma(1 - 2m, a, 180 m) is a where m = 0 and RN(180 - a) where m = 1 -- the same single rounding as
+// the subtraction.  Likewise m = sat((pix - T) * 2^60) is 1 exactly where pix > T (the smallest positive difference is
+// an ulp) and fma(-T, m, pix) is RN(pix - T) or pix.  mc, ms: 1 where the cosine / sine term is negative.
+template <typename V>
+__device__ __forceinline__ V pix_from_octant_angle(V a, V mc, V ms, float Tf)
+{
+    a = v_fma(v_fma(-2.f, mc, 1.f), a, mc * 180.f);
+    a = v_fma(v_fma(-2.f, ms, 1.f), a, ms * 360.f);
+    const V d0 = a * kInv360;
+    const V d = v_fma(v_fma(-360.f, d0, a), kInv360, d0);          // RN(a / 360), see the identities above
+    V pix = d * Tf;
+    pix = pix + 0.5f;
+    const V mw = v_mul_sat(pix - Tf, 0x1p60f);
+    return v_fma(-Tf, mw, pix);
+}
+
+// a1 for 4 steps from the two differences (sine term s2 = g0 - g2, cosine term c2 = g1 - g3).
+// SCALED: s2, c2 carry the integer differences times 2^-23 (byte_diff_denorm below).  Every use of them is invariant
 // under a power-of-two scale that stays inside the normal range -- max/min/compare, v_rcp_f32 (a function of the
 // mantissa), the quotient and its residual, the sign tests -- so the result is the same bit for bit; only the
 // 0/0 guard and the saturation factor of the sign tests move with the scale.
-template <bool SCALED = false>
-__device__ __forceinline__ f32x2 wrapped_pix_from_diffs2(f32x2 s2, f32x2 c2, float Tf)
+template <bool SCALED, typename V>
+__device__ __forceinline__ V wrapped_pix_from_diffs(V s2, V c2, float Tf)
 {
     constexpr float kGuard = SCALED ? 0x1p-23f : 1.0f;
-    const f32x2 as = {__builtin_fabsf(s2.x), __builtin_fabsf(s2.y)}, ac = {__builtin_fabsf(c2.x), __builtin_fabsf(c2.y)};
-    const f32x2 mx = {__builtin_fmaxf(__builtin_fmaxf(as.x, ac.x), kGuard), __builtin_fmaxf(__builtin_fmaxf(as.y, ac.y), kGuard)};
-    const f32x2 mn = {__builtin_fminf(as.x, ac.x), __builtin_fminf(as.y, ac.y)};
-    const f32x2 r = {__builtin_amdgcn_rcpf(mx.x), __builtin_amdgcn_rcpf(mx.y)};
-    const f32x2 q0 = mn * r;
-    const f32x2 c = __builtin_elementwise_fma(__builtin_elementwise_fma(-mx, q0, mn), r, q0);
-    const f32x2 cc = c * c;
-    f32x2 a = (((kP7 * cc + kP5) * cc + kP3) * cc + kP1) * c;
-    const f32x2 a90 = 90.f - a;
-    a = f32x2{as.x > ac.x ? a90.x : a.x, as.y > ac.y ? a90.y : a.y};
-    // The two sign fix-ups and the final wrap are selects; compares and v_cndmask do not pack, but a saturating
-    // packed multiply does (VOP3P clamp, which hipcc does not emit for f32 pairs): for the integer-valued c2,
-    // m = sat(-c2) is 1 where c2 < 0 and 0 elsewhere, and fma(1 - 2m, a, 180 m) is a where m = 0 and RN(180 - a)
-    // where m = 1 -- the same single rounding as the subtraction.  Likewise m = sat((pix - T) * 2^60) is 1 exactly
-    // where pix > T (the smallest positive difference is an ulp, far above 2^-60) and fma(-T, m, pix) is RN(pix - T) or pix.
-    const f32x2 one = {1.f, 1.f}, mtwo = {-2.f, -2.f};
-    const f32x2 mc = SCALED ? pk_mul_sat(c2, f32x2{-0x1p60f, -0x1p60f}) : pk_neg_sat(c2);
-    a = __builtin_elementwise_fma(__builtin_elementwise_fma(mtwo, mc, one), a, mc * 180.f);
-    const f32x2 ms = SCALED ? pk_mul_sat(s2, f32x2{-0x1p60f, -0x1p60f}) : pk_neg_sat(s2);
-    a = __builtin_elementwise_fma(__builtin_elementwise_fma(mtwo, ms, one), a, ms * 360.f);
-    const f32x2 d0 = a * kInv360;
-    const f32x2 k360 = {kInv360, kInv360}, m360 = {-360.f, -360.f};
-    const f32x2 d = __builtin_elementwise_fma(__builtin_elementwise_fma(m360, d0, a), k360, d0);
-    f32x2 pix = d * Tf;
-    pix = pix + 0.5f;
-    const f32x2 mw = pk_mul_sat(pix - Tf, f32x2{0x1p60f, 0x1p60f});
-    return __builtin_elementwise_fma(f32x2{-Tf, -Tf}, mw, pix);
-}
-
-// The same on two pixel pairs in lockstep: every statement is issued for pair A, then for pair B, so that dependent
-// packed operations (which need a wait state between them: hipcc pads with s_nop, and an s_nop costs the wave an issue
-// turn just like a real instruction) have an independent operation of the other pair between them.
-template <bool SCALED>
-__device__ __forceinline__ void wrapped_pix_from_diffs2x2(f32x2 sA, f32x2 cA, f32x2 sB, f32x2 cB, float Tf, f32x2 &outA, f32x2 &outB)
-{
-    constexpr float kGuard = SCALED ? 0x1p-23f : 1.0f;
-    const f32x2 asA = {__builtin_fabsf(sA.x), __builtin_fabsf(sA.y)}, acA = {__builtin_fabsf(cA.x), __builtin_fabsf(cA.y)};
-    const f32x2 asB = {__builtin_fabsf(sB.x), __builtin_fabsf(sB.y)}, acB = {__builtin_fabsf(cB.x), __builtin_fabsf(cB.y)};
-    const f32x2 mxA = {__builtin_fmaxf(__builtin_fmaxf(asA.x, acA.x), kGuard), __builtin_fmaxf(__builtin_fmaxf(asA.y, acA.y), kGuard)};
-    const f32x2 mxB = {__builtin_fmaxf(__builtin_fmaxf(asB.x, acB.x), kGuard), __builtin_fmaxf(__builtin_fmaxf(asB.y, acB.y), kGuard)};
-    const f32x2 mnA = {__builtin_fminf(asA.x, acA.x), __builtin_fminf(asA.y, acA.y)};
-    const f32x2 mnB = {__builtin_fminf(asB.x, acB.x), __builtin_fminf(asB.y, acB.y)};
-    const f32x2 rA = {__builtin_amdgcn_rcpf(mxA.x), __builtin_amdgcn_rcpf(mxA.y)};
-    const f32x2 rB = {__builtin_amdgcn_rcpf(mxB.x), __builtin_amdgcn_rcpf(mxB.y)};
-    const f32x2 q0A = mnA * rA;
-    const f32x2 q0B = mnB * rB;
-    const f32x2 eA = __builtin_elementwise_fma(-mxA, q0A, mnA);
-    const f32x2 eB = __builtin_elementwise_fma(-mxB, q0B, mnB);
-    const f32x2 qA = __builtin_elementwise_fma(eA, rA, q0A);
-    const f32x2 qB = __builtin_elementwise_fma(eB, rB, q0B);
-    const f32x2 ccA = qA * qA;
-    const f32x2 ccB = qB * qB;
-    f32x2 tA = kP7 * ccA;
-    f32x2 tB = kP7 * ccB;
-    tA = tA + kP5;
-    tB = tB + kP5;
-    tA = tA * ccA;
-    tB = tB * ccB;
-    tA = tA + kP3;
-    tB = tB + kP3;
-    tA = tA * ccA;
-    tB = tB * ccB;
-    tA = tA + kP1;
-    tB = tB + kP1;
-    f32x2 aA = tA * qA;
-    f32x2 aB = tB * qB;
-    const f32x2 a90A = 90.f - aA;
-    const f32x2 a90B = 90.f - aB;
-    aA = f32x2{asA.x > acA.x ? a90A.x : aA.x, asA.y > acA.y ? a90A.y : aA.y};
-    aB = f32x2{asB.x > acB.x ? a90B.x : aB.x, asB.y > acB.y ? a90B.y : aB.y};
-    const f32x2 one = {1.f, 1.f}, mtwo = {-2.f, -2.f}, big = {-0x1p60f, -0x1p60f};
-    const f32x2 mcA = SCALED ? pk_mul_sat(cA, big) : pk_neg_sat(cA);
-    const f32x2 mcB = SCALED ? pk_mul_sat(cB, big) : pk_neg_sat(cB);
-    const f32x2 scA = __builtin_elementwise_fma(mtwo, mcA, one);
-    const f32x2 scB = __builtin_elementwise_fma(mtwo, mcB, one);
-    const f32x2 kcA = mcA * 180.f;
-    const f32x2 kcB = mcB * 180.f;
-    aA = __builtin_elementwise_fma(scA, aA, kcA);
-    aB = __builtin_elementwise_fma(scB, aB, kcB);
-    const f32x2 msA = SCALED ? pk_mul_sat(sA, big) : pk_neg_sat(sA);
-    const f32x2 msB = SCALED ? pk_mul_sat(sB, big) : pk_neg_sat(sB);
-    const f32x2 ssA = __builtin_elementwise_fma(mtwo, msA, one);
-    const f32x2 ssB = __builtin_elementwise_fma(mtwo, msB, one);
-    const f32x2 ksA = msA * 360.f;
-    const f32x2 ksB = msB * 360.f;
-    aA = __builtin_elementwise_fma(ssA, aA, ksA);
-    aB = __builtin_elementwise_fma(ssB, aB, ksB);
-    const f32x2 k360 = {kInv360, kInv360}, m360 = {-360.f, -360.f};
-    const f32x2 d0A = aA * kInv360;
-    const f32x2 d0B = aB * kInv360;
-    const f32x2 fA = __builtin_elementwise_fma(m360, d0A, aA);
-    const f32x2 fB = __builtin_elementwise_fma(m360, d0B, aB);
-    const f32x2 dA = __builtin_elementwise_fma(fA, k360, d0A);
-    const f32x2 dB = __builtin_elementwise_fma(fB, k360, d0B);
-    f32x2 pA = dA * Tf;
-    f32x2 pB = dB * Tf;
-    pA = pA + 0.5f;
-    pB = pB + 0.5f;
-    const f32x2 up = {0x1p60f, 0x1p60f}, mT = {-Tf, -Tf};
-    const f32x2 wA = pk_mul_sat(pA - Tf, up);
-    const f32x2 wB = pk_mul_sat(pB - Tf, up);
-    outA = __builtin_elementwise_fma(mT, wA, pA);
-    outB = __builtin_elementwise_fma(mT, wB, pB);
+    const V as = v_abs(s2), ac = v_abs(c2);
+    const V mx = v_max3(as, ac, kGuard);
+    const V mn = v_min(as, ac);
+    const V r = v_rcp(mx);
+    const V q0 = mn * r;
+    const V c = v_fma(v_fma(-mx, q0, mn), r, q0);                   // RN(mn / mx)
+    const V cc = c * c;
+    V a = (((kP7 * cc + kP5) * cc + kP3) * cc + kP1) * c;
+    a = v_sel_gt(as, ac, 90.f - a, a);
+    const V mc = SCALED ? v_mul_sat(c2, -0x1p60f) : v_neg_sat(c2);
+    const V ms = SCALED ? v_mul_sat(s2, -0x1p60f) : v_neg_sat(s2);
+    return pix_from_octant_angle(a, mc, ms, Tf);
 }
 
 // a2 literally (any float inputs): used by the x1 path, N != 4.
@@ -244,42 +219,6 @@ __device__ __forceinline__ float pix_tail_literal(float sinValue, float cosValue
     return pix;
 }
 
-// R/CDecodePhase.cpp:67-75 for arbitrary float sums (x1, N = 8), all in f32, two pixels at a time.
-//  * the angle's division n/d (0 <= n <= d, d in [2^-53, 2^12]) is hipcc's f32 sequence (v_rcp_f32, one Newton step,
-//    two residual corrections) without its range scaling and special-case fix-up, which are no-ops in this range;
-//  * the casts through double are exact or round identically (the double product of a float and an integer < 2^24
-//    is exact; the double sum with 0.5 is either exact or rounds to the float the f32 add gives), and RN(x/360)
-//    comes from one residual correction (x/360 is never within 1/90 ulp of a rounding tie);
-//  * every mul/add/fma is packed; the sign fix-ups and the wrap are saturating multiplies (see
-//    wrapped_pix_from_diffs2; |x|, |y| are 0 or >= 2^-6 here, far above the 2^-60 the saturation needs).
-__device__ __forceinline__ f32x2 pix_tail_f32x2(f32x2 y, f32x2 x, float Tf)
-{
-    const f32x2 ax = {__builtin_fabsf(x.x), __builtin_fabsf(x.y)}, ay = {__builtin_fabsf(y.x), __builtin_fabsf(y.y)};
-    const f32x2 mx = {__builtin_fmaxf(ax.x, ay.x), __builtin_fmaxf(ax.y, ay.y)}, mn = {__builtin_fminf(ax.x, ay.x), __builtin_fminf(ax.y, ay.y)};
-    const f32x2 dd = mx + kEps;
-    f32x2 r = {__builtin_amdgcn_rcpf(dd.x), __builtin_amdgcn_rcpf(dd.y)};
-    const f32x2 one = {1.f, 1.f}, mtwo = {-2.f, -2.f};
-    r = __builtin_elementwise_fma(__builtin_elementwise_fma(-dd, r, one), r, r);
-    f32x2 q = mn * r;
-    q = __builtin_elementwise_fma(__builtin_elementwise_fma(-dd, q, mn), r, q);
-    const f32x2 c = __builtin_elementwise_fma(__builtin_elementwise_fma(-dd, q, mn), r, q);
-    const f32x2 cc = c * c;
-    f32x2 a = (((kP7 * cc + kP5) * cc + kP3) * cc + kP1) * c;
-    const f32x2 a90 = 90.f - a;
-    a = f32x2{ay.x > ax.x ? a90.x : a.x, ay.y > ax.y ? a90.y : a.y};
-    const f32x2 nbig = {-0x1p60f, -0x1p60f};
-    const f32x2 mxn = pk_mul_sat(x, nbig);                          // 1 where x < 0
-    a = __builtin_elementwise_fma(__builtin_elementwise_fma(mtwo, mxn, one), a, mxn * 180.f);
-    const f32x2 myn = pk_mul_sat(y, nbig);                          // 1 where y < 0
-    a = __builtin_elementwise_fma(__builtin_elementwise_fma(mtwo, myn, one), a, myn * 360.f);
-    const f32x2 d0 = a * kInv360;
-    const f32x2 k360 = {kInv360, kInv360}, m360 = {-360.f, -360.f};
-    const f32x2 d = __builtin_elementwise_fma(__builtin_elementwise_fma(m360, d0, a), k360, d0);
-    f32x2 pix = d * Tf;
-    pix = pix + 0.5f;
-    const f32x2 mw = pk_mul_sat(pix - Tf, f32x2{0x1p60f, 0x1p60f});
-    return __builtin_elementwise_fma(f32x2{-Tf, -Tf}, mw, pix);
-}
 
 // IEEE-754 correctly rounded num/den without the range scaling and special-case fix-up of the
 // general f64 division: the same v_rcp_f64 + two Newton steps + residual correction hipcc emits,
@@ -417,16 +356,15 @@ __global__ __launch_bounds__(256) void slx_fused_kernel(const SlxKParams p)
                 const uint32_t w2 = load_quad(p.phase[f * 4 + 2], set_off, aligned, npx);
                 const uint32_t w3 = load_quad(p.phase[f * 4 + 3], set_off, aligned, npx);
                 const float Tf = (float)p.period[f];
-                // two pixels per instruction, byte differences as rescaled denormals: see wrapped_pix_from_diffs2
+                // byte differences as rescaled denormals, the quad's two pixel pairs in lockstep: see wrapped_pix_from_diffs
                 const f32x2 kUp = {0x1p126f, 0x1p126f};
-                const f32x2 p01 = wrapped_pix_from_diffs2<true>(f32x2{byte_diff_denorm<0>(w0, w2), byte_diff_denorm<1>(w0, w2)} * kUp,
-                                                                f32x2{byte_diff_denorm<0>(w1, w3), byte_diff_denorm<1>(w1, w3)} * kUp, Tf);
-                const f32x2 p23 = wrapped_pix_from_diffs2<true>(f32x2{byte_diff_denorm<2>(w0, w2), byte_diff_denorm<3>(w0, w2)} * kUp,
-                                                                f32x2{byte_diff_denorm<2>(w1, w3), byte_diff_denorm<3>(w1, w3)} * kUp, Tf);
-                pix[f][0] = p01.x;
-                pix[f][1] = p01.y;
-                pix[f][2] = p23.x;
-                pix[f][3] = p23.y;
+                const F32x2x2 px = wrapped_pix_from_diffs<true>(
+                    F32x2x2{f32x2{byte_diff_denorm<0>(w0, w2), byte_diff_denorm<1>(w0, w2)} * kUp, f32x2{byte_diff_denorm<2>(w0, w2), byte_diff_denorm<3>(w0, w2)} * kUp},
+                    F32x2x2{f32x2{byte_diff_denorm<0>(w1, w3), byte_diff_denorm<1>(w1, w3)} * kUp, f32x2{byte_diff_denorm<2>(w1, w3), byte_diff_denorm<3>(w1, w3)} * kUp}, Tf);
+                pix[f][0] = px.a.x;
+                pix[f][1] = px.a.y;
+                pix[f][2] = px.b.x;
+                pix[f][3] = px.b.y;
             } else {
                 float sy[SLX_QUAD] = {0.f, 0.f, 0.f, 0.f}, sx[SLX_QUAD] = {0.f, 0.f, 0.f, 0.f};
                 const int N = p.n_steps;
@@ -609,6 +547,30 @@ __global__ __launch_bounds__(256) void slx_fused_kernel(const SlxKParams p)
     }
 }
 
+
+// R/CDecodePhase.cpp:67-75 for arbitrary float sums (x1, N = 8 in the strip kernel), all in f32.
+//  * the angle's division n/d (0 <= n <= d, d in [2^-53, 2^12]) is hipcc's f32 sequence (v_rcp_f32, one Newton step,
+//    two residual corrections) without its range scaling and special-case fix-up, which are no-ops in this range;
+//  * the casts through double are exact or round identically (the double product of a float and an integer < 2^24
+//    is exact; the double sum with 0.5 is either exact or rounds to the float the f32 add gives), and RN(x/360)
+//    comes from one residual correction (x/360 is never within 1/90 ulp of a rounding tie);
+//  * |x|, |y| are 0 or >= 2^-6 here, far above the 2^-60 the saturating sign tests need.
+template <typename V>
+__device__ __forceinline__ V pix_tail_inrange(V y, V x, float Tf)
+{
+    const V ax = v_abs(x), ay = v_abs(y);
+    const V mx = v_max(ax, ay), mn = v_min(ax, ay);
+    const V dd = mx + kEps;
+    V r = v_rcp(dd);
+    r = v_fma(v_fma(-dd, r, 1.f), r, r);
+    V q = mn * r;
+    q = v_fma(v_fma(-dd, q, mn), r, q);
+    const V c = v_fma(v_fma(-dd, q, mn), r, q);
+    const V cc = c * c;
+    V a = (((kP7 * cc + kP5) * cc + kP3) * cc + kP1) * c;
+    a = v_sel_gt(ay, ax, 90.f - a, a);
+    return pix_from_octant_angle(a, v_mul_sat(x, -0x1p60f), v_mul_sat(y, -0x1p60f), Tf);
+}
 
 // ------------------------------------------------------------------------------------------
 // Fast path: waves walking column strips, fringe stack staged through LDS.
@@ -842,12 +804,12 @@ __global__ __launch_bounds__(256) void slx_strip_kernel(const SlxKParams p)
                         sy[j] = ((((ubyte(w[0], j) + m1) - m3) - ubyte(w[4], j)) - m5) + m7;
                         sx[j] = ((((m1 + ubyte(w[2], j)) + m3) - m5) - ubyte(w[6], j)) - m7;
                     }
-                    const f32x2 p01 = pix_tail_f32x2(f32x2{sy[0], sy[1]} * p.wscale, f32x2{sx[0], sx[1]} * p.wscale, Tf[c]);
-                    const f32x2 p23 = pix_tail_f32x2(f32x2{sy[2], sy[3]} * p.wscale, f32x2{sx[2], sx[3]} * p.wscale, Tf[c]);
-                    pix[c][0] = p01.x;
-                    pix[c][1] = p01.y;
-                    pix[c][2] = p23.x;
-                    pix[c][3] = p23.y;
+                    const F32x2x2 px = pix_tail_inrange(F32x2x2{f32x2{sy[0], sy[1]} * p.wscale, f32x2{sy[2], sy[3]} * p.wscale},
+                                                        F32x2x2{f32x2{sx[0], sx[1]} * p.wscale, f32x2{sx[2], sx[3]} * p.wscale}, Tf[c]);
+                    pix[c][0] = px.a.x;
+                    pix[c][1] = px.a.y;
+                    pix[c][2] = px.b.x;
+                    pix[c][3] = px.b.y;
                 }
 #pragma unroll
                 for (int f = 0; f < ((NS == 4 && c == 0) ? F : 0); f++) {
@@ -855,15 +817,13 @@ __global__ __launch_bounds__(256) void slx_strip_kernel(const SlxKParams p)
                     const uint32_t w2 = src[(f * 4 + 2) * 64], w3 = src[(f * 4 + 3) * 64];
                     // differences as denormals (x 2^-149), rescaled to x 2^-23 by one packed multiply per pair
                     const f32x2 kUp = {0x1p126f, 0x1p126f};
-                    f32x2 p01, p23;
-                    wrapped_pix_from_diffs2x2<true>(f32x2{byte_diff_denorm<0>(w0, w2), byte_diff_denorm<1>(w0, w2)} * kUp,
-                                                    f32x2{byte_diff_denorm<0>(w1, w3), byte_diff_denorm<1>(w1, w3)} * kUp,
-                                                    f32x2{byte_diff_denorm<2>(w0, w2), byte_diff_denorm<3>(w0, w2)} * kUp,
-                                                    f32x2{byte_diff_denorm<2>(w1, w3), byte_diff_denorm<3>(w1, w3)} * kUp, Tf[f], p01, p23);
-                    pix[f][0] = p01.x;
-                    pix[f][1] = p01.y;
-                    pix[f][2] = p23.x;
-                    pix[f][3] = p23.y;
+                    const F32x2x2 px = wrapped_pix_from_diffs<true>(
+                        F32x2x2{f32x2{byte_diff_denorm<0>(w0, w2), byte_diff_denorm<1>(w0, w2)} * kUp, f32x2{byte_diff_denorm<2>(w0, w2), byte_diff_denorm<3>(w0, w2)} * kUp},
+                        F32x2x2{f32x2{byte_diff_denorm<0>(w1, w3), byte_diff_denorm<1>(w1, w3)} * kUp, f32x2{byte_diff_denorm<2>(w1, w3), byte_diff_denorm<3>(w1, w3)} * kUp}, Tf[f]);
+                    pix[f][0] = px.a.x;
+                    pix[f][1] = px.a.y;
+                    pix[f][2] = px.b.x;
+                    pix[f][3] = px.b.y;
                 }
                 if (GRAY_CHUNK && c == 1) {
 #pragma unroll
