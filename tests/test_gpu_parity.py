@@ -453,7 +453,11 @@ def dyna_images(h, w, n, seed):
 
 
 @pytest.mark.parametrize("shape,window", [((96, 160), 21), ((40, 300), 21), ((25, 23), 21), ((64, 64), 5), ((20, 64), 21),
-                                          ((130, 256), 21), ((30, 257), 21), ((70, 492), 21), ((24, 1000), 9)])
+                                          ((130, 256), 21), ((30, 257), 21), ((70, 492), 21), ((24, 1000), 9),
+                                          # band / tile edges of the 21-pixel kernel: a single interior pixel, one interior row,
+                                          # bands of 8 rows starting exactly at / next to the interior, exactly one and two tiles
+                                          ((21, 21), 21), ((21, 80), 21), ((22, 45), 21), ((29, 64), 21), ((37, 256), 21), ((34, 472), 21),
+                                          ((27, 473), 21)])
 def test_dynamic_frames(api, oracle, synth, shape, window):
     h, w = shape
     spec = small_spec(synth, "C1x4", w, h)
