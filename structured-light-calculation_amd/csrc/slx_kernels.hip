@@ -864,33 +864,33 @@ __global__ __launch_bounds__(256) void slx_strip_kernel(const SlxKParams p)
                             code[j] = code[j] + code[j] + (ibyte(wa, j) > ibyte(wb, j) ? 1u : 0u);
                     }
                 }
+                if (p.std_gray) {                                       // inverse reflected Gray code: prefix xor (one uniform branch)
 #pragma unroll
-                for (int j = 0; j < SLX_QUAD; j++) {
-                    if (p.std_gray) {                                   // inverse reflected Gray code: prefix xor
+                    for (int j = 0; j < SLX_QUAD; j++) {
                         unsigned g = code[j];
                         g ^= g >> 1;
                         g ^= g >> 2;
                         g ^= g >> 4;
                         g ^= g >> 8;
                         bin[j] = (int)g;
-                    } else {
-                        bin[j] = (int)p.lut[code[j]];
                     }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < SLX_QUAD; j++) bin[j] = (int)p.lut[code[j]];
                 }
             }
             if constexpr (MODE == SLX_MODE_GRAY_PHASE) {
                 const double Td = (double)p.period[0], Sd = (double)p.gray_stripe;
 #pragma unroll
                 for (int j = 0; j < SLX_QUAD; j++) {
+                    // a5 without divergent branches: even stripe: phase > 3T/4 ? phase - T : phase;
+                    // odd stripe: (phase < T/4 ? phase + T : phase) - T/2.  Same operations, same roundings, as selects.
                     const double grayv = (double)bin[j] * Sd;
                     const double phaseVal = (double)pix[0][j];
-                    double ph = phaseVal;
-                    if ((bin[j] & 1) == 0) {
-                        if (phaseVal > Td * 0.75) ph = phaseVal - Td;
-                    } else {
-                        if (phaseVal < Td * 0.25) ph = phaseVal + Td;
-                        ph = ph - 0.5 * Td;
-                    }
+                    const bool odd = (bin[j] & 1) != 0;
+                    const bool shift = odd ? (phaseVal < Td * 0.25) : (phaseVal > Td * 0.75);
+                    const double t = shift ? phaseVal + (odd ? Td : -Td) : phaseVal;
+                    const double ph = odd ? t - 0.5 * Td : t;
                     U[j] = grayv + ph;
                 }
             } else {
