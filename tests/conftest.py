@@ -25,8 +25,20 @@ def synth():
     return pkg("synth")
 
 
+def _ensure_built():
+    """The library and the C++ test programs are build products (git-ignored).  A tree that has not been through
+    __graft_entry__.build() yet -- e.g. a fresh checkout on the GPU box -- is built here once; hipcc and gcc are on the image."""
+    need = [os.path.join(ROOT, PKG, "libslx.so"), os.path.join(ROOT, "tests", "cpp", "dynaframe_host_loop"),
+            os.path.join(ROOT, "tests", "cpp", "dynaframe_data_dir")]
+    if all(os.path.exists(f) for f in need):
+        return
+    import __graft_entry__
+    __graft_entry__.build()
+
+
 @pytest.fixture(scope="session")
 def api():
+    _ensure_built()
     return pkg("api")
 
 
