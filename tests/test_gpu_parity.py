@@ -673,6 +673,8 @@ def test_cpp_host_loop(tmp_path, oracle, synth, golden_dir):
     import subprocess
     from conftest import ROOT
     exe = os.path.join(ROOT, "tests", "cpp", "dynaframe_host_loop")
+    from conftest import _ensure_built
+    _ensure_built()
     assert os.path.exists(exe), "run __graft_entry__.build() first"
     W, H, PW = 320, 200, 1280
     spec = small_spec(synth, "C1x4", W, H)
@@ -701,6 +703,8 @@ def test_cpp_data_directory(tmp_path, oracle, synth, golden_dir):
     from conftest import ROOT
     from dynaframe_files import write_bmp, write_calibration_yaml
     exe = os.path.join(ROOT, "tests", "cpp", "dynaframe_data_dir")
+    from conftest import _ensure_built
+    _ensure_built()
     assert os.path.exists(exe), "run __graft_entry__.build() first"
     W, H, PW = 256, 130, 1280
     spec = small_spec(synth, "C1x4", W, H)
