@@ -143,7 +143,12 @@ def main():
     synth = importlib.import_module(PKG + ".synth")
     api = importlib.import_module(PKG + ".api")
     shard = importlib.import_module(PKG + ".shard")
-    api.lib()   # raises if the HIP library is missing
+    if not os.path.exists(api.LIB_PATH) and int(os.environ.get("LOCAL_RANK", "0")) == 0:
+        import __graft_entry__      # an unbuilt tree (fresh checkout): compile the HIP library once, in-tree
+        __graft_entry__.build()
+    if world > 1:
+        dist.barrier()
+    api.lib()   # raises if the HIP library is missing: there is no other implementation
 
     spec = synth.make_spec(args.config)
     full_h = spec["height"]
