@@ -277,6 +277,34 @@ def test_strip_kernel_geometries(api, oracle, synth, variant, shape):
         assert_same(got, ref, ("z",))
 
 
+@pytest.mark.parametrize("rows,tail_pct,tail_rows", [(8, 20, 2), (16, 30, 4), (8, 50, 1), (12, 10, 3)])
+@pytest.mark.parametrize("shape", [(67, 256), (130, 1000), (200, 64), (97, 1920)])
+def test_strip_kernel_long_and_short_items(api, oracle, synth, shape, rows, tail_pct, tail_rows, monkeypatch):
+    """The two-region item layout (long items first, the last rows of every frame-set in short items) is chosen
+    automatically only for large launches; the tuning hooks force it here on small, ragged tiles, for a batch of 3
+    frame-sets, in the plain-order modes (the Gray-mask mode keeps one region)."""
+    import torch
+    h, w = shape
+    monkeypatch.setenv("SLX_STRIP_ROWS", str(rows))
+    monkeypatch.setenv("SLX_TAIL_PCT", str(tail_pct))
+    monkeypatch.setenv("SLX_TAIL_ROWS", str(tail_rows))
+    for name in ("C1x4", "C4", "C5"):
+        spec = small_spec(synth, name, w, h)
+        sets = [synth.random_planes(spec, seed=7 * h + w + i) for i in range(3)]
+        want = [oracle.pipeline(spec, ph, gr, want=("z",))["z"] for ph, gr in sets]
+        phase = torch.from_numpy(np.stack([ph for ph, _ in sets])).cuda()
+        gray = torch.from_numpy(np.stack([gr for _, gr in sets])).cuda() if sets[0][1] is not None else None
+        z = torch.full((3, h, w), -1.0, dtype=torch.float64, device="cuda")
+        torch.cuda.synchronize()
+        with api.Context(spec) as ctx:
+            ctx.set_variant(2)
+            ctx.decode_batch(3, phase, gray, z)
+            ctx.synchronize()
+        got = z.cpu().numpy()
+        for i in range(3):
+            assert np.array_equal(got[i], want[i], equal_nan=True), (name, i)
+
+
 def test_strip_variant_refuses_ineligible_operands(api, synth):
     spec = small_spec(synth, "C2", 63, 8)                   # width not a multiple of 4
     ph, _ = synth.random_planes(spec, seed=1)
