@@ -192,6 +192,21 @@ int slx_debug_stamps(slx_ctx *ctx, unsigned long long *device_words, size_t n_wo
 /* Selects the kernel variant (0 = default); tuning / A-B benchmarking only. */
 int slx_set_variant(slx_ctx *ctx, int variant);
 
+/* Launch-geometry overrides of the fast kernel, for tuning / A-B benchmarking and for tests that force the rarely taken
+ * item layouts on small tiles.  value 0 restores the automatic choice.  They change how the work is cut into items, never a
+ * result.  This entry is the ONLY way to set them: the library does not read the process environment. */
+enum slx_tuning_key {
+    SLX_TUNE_STRIP_ROWS = 0,   /* rows per work item, 1..32                                             */
+    SLX_TUNE_TAIL_PCT = 1,     /* percent of every frame-set's rows cut into short items, 1..99; -1 none */
+    SLX_TUNE_TAIL_ROWS = 2,    /* rows per short item, 1..32                                            */
+    SLX_TUNE_GRAY_PLAIN = 3,   /* 1: Gray planes by ordinary loads instead of the LDS-DMA ring          */
+    SLX_TUNE_STRIP_WAVES = 4,  /* waves per workgroup, 1..4                                             */
+    SLX_TUNE_LDS_PAD_KIB = 5,  /* extra LDS per workgroup in KiB (lowers the occupancy), 1..128         */
+    SLX_TUNE_PLAIN_ORDER = 6,  /* 1: Gray-mask work items in plain order instead of XCD-grouped         */
+    SLX_TUNE_COUNT = 7
+};
+int slx_set_tuning(slx_ctx *ctx, int key, int value);
+
 /* ---- frame ingest pipeline: the live loop around the path -------------------------------------
  * Role of CSensor::GetCamPicture -> CDecode*::SetMat -> Decode in a capture loop (R/CSensorV.cpp:171-179,
  * R/CCalculation.cpp:171-205), for frame-sets that arrive in HOST memory: `slots` pinned host buffers, each holding

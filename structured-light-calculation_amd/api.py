@@ -30,7 +30,7 @@ SYMBOLS = [
     "slx_validate_config", "slx_create", "slx_destroy", "slx_last_error", "slx_set_gray_lut",
     "slx_set_frame", "slx_decode", "slx_decode_batch", "slx_synchronize", "slx_get_output",
     "slx_get_depth", "slx_get_point_cloud", "slx_track_begin", "slx_track_next", "slx_output_device_ptr", "slx_get_calibration", "slx_enable_timing",
-    "slx_last_decode_ms", "slx_debug_stamps", "slx_set_variant", "slx_read_bmp_gray", "slx_read_pgm_gray", "slx_read_calibration_yaml", "slx_version",
+    "slx_last_decode_ms", "slx_debug_stamps", "slx_set_variant", "slx_set_tuning", "slx_read_bmp_gray", "slx_read_pgm_gray", "slx_read_calibration_yaml", "slx_version",
     "slx_pipe_create", "slx_pipe_destroy", "slx_pipe_layout", "slx_pipe_acquire", "slx_pipe_submit", "slx_pipe_collect", "slx_pipe_last_error",
 ]
 
@@ -90,6 +90,7 @@ def lib():
         L.slx_enable_timing.argtypes = [vp, C.c_int]
         L.slx_last_decode_ms.argtypes = [vp, C.POINTER(C.c_float)]
         L.slx_set_variant.argtypes = [vp, C.c_int]
+        L.slx_set_tuning.argtypes = [vp, C.c_int, C.c_int]
         L.slx_debug_stamps.argtypes = [vp, vp, sz]
         L.slx_read_bmp_gray.argtypes = [C.c_char_p, vp, sz, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.slx_read_pgm_gray.argtypes = [C.c_char_p, vp, sz, C.POINTER(C.c_int), C.POINTER(C.c_int)]
@@ -307,8 +308,15 @@ class Context:
     def set_variant(self, v):
         self._check(lib().slx_set_variant(self._h, int(v)))
 
+    def set_tuning(self, **kv):
+        """Launch-geometry overrides of the fast kernel (slx_set_tuning): strip_rows, tail_pct, tail_rows, gray_plain,
+        strip_waves, lds_pad_kib, plain_order; 0 = automatic."""
+        for k, v in kv.items():
+            self._check(lib().slx_set_tuning(self._h, TUNE_KEYS[k], int(v)))
+
 
 VARIANT_AUTO, VARIANT_GENERIC, VARIANT_STRIP, VARIANT_GENERIC_FAST = range(4)
+TUNE_KEYS = {"strip_rows": 0, "tail_pct": 1, "tail_rows": 2, "gray_plain": 3, "strip_waves": 4, "lds_pad_kib": 5, "plain_order": 6}
 
 
 class Pipe:

@@ -55,6 +55,7 @@ struct slx_ctx {
     bool aux = false;
     bool decoded = false;
     int variant = 0;
+    SlxTuning tune{};
     std::string err;
 };
 
@@ -420,7 +421,7 @@ static int launch(slx_ctx *ctx, SlxKParams &kp, int n_sets, bool aux, void *stre
     if (ctx->variant == SLX_VARIANT_GENERIC_FAST && !(mode_has_depth(c.mode) && slx_fast_arith_ok(kp)))
         return fail(ctx, SLX_ERR_UNAVAILABLE, "variant %d (cheap exact arithmetic) needs a depth mode, periods <= 2^14 and moderate calibration magnitudes", ctx->variant);
     if (ctx->timed) SLX_HIP(ctx, hipEventRecord(ctx->ev0, s));
-    int e = slx_launch_fused(kp, c.mode, aux, n_sets, ctx->variant, s);
+    int e = slx_launch_fused(kp, c.mode, aux, n_sets, ctx->variant, s, &ctx->tune);
     if (e != 0) return hip_fail(ctx, (hipError_t)e, "kernel launch");
     if (ctx->timed) SLX_HIP(ctx, hipEventRecord(ctx->ev1, s));
     return SLX_OK;
@@ -885,6 +886,19 @@ int slx_set_variant(slx_ctx *ctx, int variant)
     if (!ctx) return SLX_ERR_INVALID_ARG;
     if (variant < 0 || variant >= slx_num_variants()) return fail(ctx, SLX_ERR_INVALID_ARG, "variant %d outside [0,%d)", variant, slx_num_variants());
     ctx->variant = variant;
+    return SLX_OK;
+}
+
+int slx_set_tuning(slx_ctx *ctx, int key, int value)
+{
+    if (!ctx) return SLX_ERR_INVALID_ARG;
+    struct Range { int *field; int lo, hi; };
+    SlxTuning &t = ctx->tune;
+    const Range r[SLX_TUNE_COUNT] = {{&t.strip_rows, 0, 32}, {&t.tail_pct, -1, 99}, {&t.tail_rows, 0, 32}, {&t.gray_plain, 0, 1},
+                                     {&t.strip_waves, 0, 4}, {&t.lds_pad_kib, 0, 128}, {&t.plain_order, 0, 1}};
+    if (key < 0 || key >= SLX_TUNE_COUNT) return fail(ctx, SLX_ERR_INVALID_ARG, "unknown tuning key %d", key);
+    if (value < r[key].lo || value > r[key].hi) return fail(ctx, SLX_ERR_INVALID_ARG, "tuning key %d takes values in [%d,%d] (got %d)", key, r[key].lo, r[key].hi, value);
+    *r[key].field = value;
     return SLX_OK;
 }
 

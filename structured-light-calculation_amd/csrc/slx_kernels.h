@@ -53,7 +53,7 @@ struct SlxKParams {
     unsigned rows_per_lane_tail;                // items [items_head, total_items): the rows from tail_row0 on, in items of this many rows
     unsigned items_per_set_tail, tail_row0;
     int fast_arith;                             // generic kernel: use the bit-identical cheap unwrap / in-range division (host-checked)
-    int dbg;                                    // experiments only (SLX_DBG): 1 = skip stores, 2 = skip compute
+    int plain_order;                            // Gray-mask strip kernel: items in plain order instead of XCD-grouped (slx_set_tuning, A/B only)
     unsigned long long *stamps;                 // diagnostics: 4 words per work item (s_memtime / s_memrealtime at start, end) or null
     unsigned long long stamp_items;             // items the stamp buffer has room for
 };
@@ -90,9 +90,21 @@ int slx_launch_track_update(const SlxKParams &kp, const float *raw, float *delta
 // True when the strip kernel can run this configuration / these operands.
 bool slx_strip_eligible(const SlxKParams &kp, int mode, bool aux);
 
+// Launch-geometry overrides of the strip kernel (slx_set_tuning).  0 = the automatic choice.  They change how the
+// work is cut into items, never a result; the process environment is not consulted anywhere.
+struct SlxTuning {
+    int strip_rows;      // rows per work item, 1..32
+    int tail_pct;        // share of every frame-set's rows that goes into short items, 1..99 (-1: none)
+    int tail_rows;       // rows per short item
+    int gray_plain;      // 1: Gray planes by ordinary loads instead of the DMA ring
+    int strip_waves;     // waves per workgroup, 1..4
+    int lds_pad_kib;     // extra LDS per workgroup (lowers the occupancy), 0..128
+    int plain_order;     // 1: Gray-mask items in plain order instead of XCD-grouped
+};
+
 // Launches the fused kernel for `n_sets` frame-sets on `stream` (hipStream_t).
-// Returns 0, or a hipError_t value.  `variant` selects a tuning variant.
-int slx_launch_fused(const SlxKParams &kp, int mode, bool aux, int n_sets, int variant, void *stream);
+// Returns 0, or a hipError_t value.  `variant` selects a kernel variant, `tune` (may be null) the item geometry.
+int slx_launch_fused(const SlxKParams &kp, int mode, bool aux, int n_sets, int variant, void *stream, const SlxTuning *tune = nullptr);
 
 // Number of distinct variants slx_launch_fused understands.
 int slx_num_variants(void);

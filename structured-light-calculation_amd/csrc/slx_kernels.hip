@@ -18,8 +18,6 @@
 
 #include <algorithm>
 
-#include <cstdlib>
-
 #include "slx_kernels.h"
 
 #pragma clang fp contract(off)
@@ -669,7 +667,7 @@ __global__ __launch_bounds__(256) void slx_strip_kernel(const SlxKParams p)
     // Placement only affects speed; any dispatch order gives the same result.
     // The other modes have no reuse and run in plain order, which is what lets the LAST items be the small ones (below).
     unsigned wg = blockIdx.x;
-    if (MASKED && p.dbg != 4) {                                     // SLX_DBG=4: plain order, for A/B measurements
+    if (MASKED && !p.plain_order) {                                 // plain order: A/B measurements only (slx_set_tuning)
         const unsigned nb = gridDim.x, q = nb >> 3, r = nb & 7u, x = wg & 7u, within = wg >> 3;
         wg = x * q + (x < r ? x : r) + within;
     }
@@ -747,7 +745,7 @@ __global__ __launch_bounds__(256) void slx_strip_kernel(const SlxKParams p)
     unsigned out_boff[2], out_bstep[2];
 #pragma unroll
     for (int k = 0; k < 2; k++) {
-        const bool ok = pos.out_row[k] != 0xFFFFFFFFu && p.dbg != 1;
+        const bool ok = pos.out_row[k] != 0xFFFFFFFFu;
         out_boff[k] = ok ? pos.out_off[k] * 8u : 0xFFFFFFF0u;
         out_bstep[k] = ok ? step_rows * W * 8u : 0u;
     }
@@ -914,10 +912,7 @@ __global__ __launch_bounds__(256) void slx_strip_kernel(const SlxKParams p)
                 }
             }
 
-            if (p.dbg == 2) {                                           // experiment: memory traffic only
-#pragma unroll
-                for (int j = 0; j < SLX_QUAD; j++) z[j] = (double)pix[0][j];
-            } else {
+            {
                 const double vc = (double)((int)row + p.row_offset) - p.cy;
                 const double vf = vc * p.fu;
                 const double tvC = vf * p.P01, tvD = vf * p.P21;
@@ -1218,8 +1213,10 @@ static int launch_generic(const SlxKParams &kp, int mode, bool aux, int n_sets, 
     return (int)hipGetLastError();
 }
 
-int slx_launch_fused(const SlxKParams &kp_in, int mode, bool aux, int n_sets, int variant, void *stream)
+int slx_launch_fused(const SlxKParams &kp_in, int mode, bool aux, int n_sets, int variant, void *stream, const SlxTuning *tune)
 {
+    const SlxTuning none{};
+    const SlxTuning &tn = tune ? *tune : none;
     const bool can_strip = slx_strip_eligible(kp_in, mode, aux);
     if (variant == SLX_VARIANT_GENERIC || variant == SLX_VARIANT_GENERIC_FAST || !can_strip) {
         if (variant == SLX_VARIANT_STRIP) return (int)hipErrorInvalidValue;
@@ -1254,11 +1251,9 @@ int slx_launch_fused(const SlxKParams &kp_in, int mode, bool aux, int n_sets, in
         };
         while (rb > 1 && waves_at(rb) < want_waves) rb /= 2;
     }
-    if (const char *e = getenv("SLX_DBG")) kp.dbg = atoi(e);
-    if (const char *e = getenv("SLX_STRIP_ROWS")) {                  // tuning hook
-        const int v = atoi(e);
-        if (v >= 1 && v <= 256) rb = (unsigned)v;
-    }
+    kp.plain_order = tn.plain_order ? 1 : 0;
+    // <= 32 rows: slx_strip_eligible bounds the 32-bit output offsets for interleave (<= 64) x 32 rows past the tile
+    if (tn.strip_rows >= 1 && tn.strip_rows <= 32) rb = (unsigned)tn.strip_rows;
     kp.rows_per_lane = rb;
     const unsigned rows_group = kp.interleave * rb;
     const unsigned groups = ((unsigned)kp.height + rows_group - 1) / rows_group;
@@ -1271,8 +1266,8 @@ int slx_launch_fused(const SlxKParams &kp_in, int mode, bool aux, int n_sets, in
     // Short items at the end of the launch (plain-order modes, launches of many long items): the last ~20 % of every
     // frame-set's rows go in items a quarter as long, dispatched after all the long ones.
     unsigned tail_pct = 20, tail_rb = rb / 4;
-    if (const char *e = getenv("SLX_TAIL_PCT")) tail_pct = (unsigned)atoi(e);          // tuning hooks
-    if (const char *e = getenv("SLX_TAIL_ROWS")) tail_rb = (unsigned)atoi(e);
+    if (tn.tail_pct != 0) tail_pct = tn.tail_pct < 0 ? 0u : (unsigned)tn.tail_pct;
+    if (tn.tail_rows > 0) tail_rb = (unsigned)tn.tail_rows;
     if (mode != SLX_MODE_MULTIFREQ_GRAYMASK && rb >= 8 && tail_rb >= 1 && tail_rb < rb && tail_pct > 0 && tail_pct < 100 && groups >= 4) {
         unsigned head_groups = (unsigned)((unsigned long long)groups * (100u - tail_pct) / 100u);
         if (head_groups >= 1 && head_groups < groups) {
@@ -1291,7 +1286,7 @@ int slx_launch_fused(const SlxKParams &kp_in, int mode, bool aux, int n_sets, in
     // plane, in every frame-set of the launch, sits within 2 GiB above the lowest plane; otherwise the kernel reads
     // them with ordinary loads
     int gb = 0;
-    if (mode != SLX_MODE_MULTIFREQ && kp.gray_bits == 6 && !getenv("SLX_GRAY_PLAIN")) {
+    if (mode != SLX_MODE_MULTIFREQ && kp.gray_bits == 6 && !tn.gray_plain) {
         gb = 6;
         const uint8_t *lo = kp.phase_base;
         for (int k = 0; k < 12; k++) lo = kp.gray[k] < lo ? kp.gray[k] : lo;
@@ -1312,10 +1307,7 @@ int slx_launch_fused(const SlxKParams &kp_in, int mode, bool aux, int n_sets, in
     }
     // LDS per wave: 2 ring slots (max(4 n_freq, 2 gb) planes with 4 steps, 8 planes with 8 steps, 256 B each) + 2 KiB of depth staging
     unsigned waves_per_wg = 4u;
-    if (const char *e = getenv("SLX_STRIP_WAVES")) {               // tuning hook
-        const int v = atoi(e);
-        if (v >= 1 && v <= 4) waves_per_wg = (unsigned)v;
-    }
+    if (tn.strip_waves >= 1 && tn.strip_waves <= 4) waves_per_wg = (unsigned)tn.strip_waves;
     const unsigned ring_planes = kp.n_steps == 4 ? std::max((unsigned)kp.n_freq * 4u, 2u * (unsigned)gb) : 8u;
     const unsigned lds_wave = 2u * ring_planes * 256u + 2048u;
     if (lds_wave * waves_per_wg > 32u * 1024u) waves_per_wg = 2u;       // keep >= 5 workgroups per CU
@@ -1328,7 +1320,8 @@ int slx_launch_fused(const SlxKParams &kp_in, int mode, bool aux, int n_sets, in
                        : (gb ? pick_strip<SLX_MODE_GRAY_PHASE, 6>(1) : pick_strip<SLX_MODE_GRAY_PHASE, 0>(1));
     if (!fn) return (int)hipErrorInvalidValue;
     size_t lds = (size_t)waves_per_wg * lds_wave;
-    if (const char *e = getenv("SLX_LDS_PAD")) lds += (size_t)atoi(e) * 1024u;   // experiments: lower the occupancy
+    if (tn.lds_pad_kib > 0 && tn.lds_pad_kib <= 128) lds += (size_t)tn.lds_pad_kib * 1024u;   // experiments: lower the occupancy
+    if (lds > 160u * 1024u) return (int)hipErrorInvalidValue;
     // operand shapes were validated by the caller (slx_api.cpp: check_launch_shapes) and slx_strip_eligible
     hipLaunchKernelGGL(fn, dim3((unsigned)need_wgs, 1, 1), dim3(threads, 1, 1), lds, (hipStream_t)stream, kp);
     return (int)hipGetLastError();

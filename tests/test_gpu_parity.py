@@ -279,15 +279,12 @@ def test_strip_kernel_geometries(api, oracle, synth, variant, shape):
 
 @pytest.mark.parametrize("rows,tail_pct,tail_rows", [(8, 20, 2), (16, 30, 4), (8, 50, 1), (12, 10, 3)])
 @pytest.mark.parametrize("shape", [(67, 256), (130, 1000), (200, 64), (97, 1920)])
-def test_strip_kernel_long_and_short_items(api, oracle, synth, shape, rows, tail_pct, tail_rows, monkeypatch):
+def test_strip_kernel_long_and_short_items(api, oracle, synth, shape, rows, tail_pct, tail_rows):
     """The two-region item layout (long items first, the last rows of every frame-set in short items) is chosen
-    automatically only for large launches; the tuning hooks force it here on small, ragged tiles, for a batch of 3
+    automatically only for large launches; slx_set_tuning forces it here on small, ragged tiles, for a batch of 3
     frame-sets, in the plain-order modes (the Gray-mask mode keeps one region)."""
     import torch
     h, w = shape
-    monkeypatch.setenv("SLX_STRIP_ROWS", str(rows))
-    monkeypatch.setenv("SLX_TAIL_PCT", str(tail_pct))
-    monkeypatch.setenv("SLX_TAIL_ROWS", str(tail_rows))
     for name in ("C1x4", "C4", "C5"):
         spec = small_spec(synth, name, w, h)
         sets = [synth.random_planes(spec, seed=7 * h + w + i) for i in range(3)]
@@ -298,11 +295,45 @@ def test_strip_kernel_long_and_short_items(api, oracle, synth, shape, rows, tail
         torch.cuda.synchronize()
         with api.Context(spec) as ctx:
             ctx.set_variant(2)
+            ctx.set_tuning(strip_rows=rows, tail_pct=tail_pct, tail_rows=tail_rows)
             ctx.decode_batch(3, phase, gray, z)
             ctx.synchronize()
         got = z.cpu().numpy()
         for i in range(3):
             assert np.array_equal(got[i], want[i], equal_nan=True), (name, i)
+
+
+def test_environment_is_ignored(api, oracle, synth, monkeypatch):
+    """The library never reads the process environment: the round-1 debug variables (SLX_DBG=1 used to drop every
+    depth store) change nothing, and out-of-range tuning values are refused."""
+    for k, v in (("SLX_DBG", "1"), ("SLX_STRIP_ROWS", "3"), ("SLX_TAIL_PCT", "50"), ("SLX_TAIL_ROWS", "1"), ("SLX_GRAY_PLAIN", "1"),
+                 ("SLX_STRIP_WAVES", "1"), ("SLX_LDS_PAD", "64")):
+        monkeypatch.setenv(k, v)
+    for name in ("C3", "C4"):
+        spec = small_spec(synth, name, 256, 70)
+        ph, gr = synth.random_planes(spec, seed=31)
+        ref = oracle.pipeline(spec, ph, gr, want=("z",))
+        got = api.decode_frameset(spec, ph, gr, want=("z",), variant=api.VARIANT_STRIP)
+        assert_same(got, ref, ("z",))
+    with api.Context(small_spec(synth, "C4", 64, 8)) as ctx:
+        for bad in (dict(strip_rows=33), dict(strip_rows=-1), dict(tail_pct=100), dict(strip_waves=5), dict(lds_pad_kib=129)):
+            with pytest.raises(api.SlxError) as e:
+                ctx.set_tuning(**bad)
+            assert e.value.code == api.ERR_INVALID_ARG
+
+
+@pytest.mark.parametrize("tune", [dict(gray_plain=1), dict(strip_waves=2), dict(plain_order=1), dict(lds_pad_kib=40), dict(strip_rows=1), dict(tail_pct=-1)])
+def test_tuning_keys_do_not_change_results(api, oracle, synth, tune):
+    spec = small_spec(synth, "C3", 500, 67)
+    ph, gr = synth.random_planes(spec, seed=17)
+    gr[:, :, :250] = np.where(gr[:, :, :250] > 127, 220, 20)
+    ref = oracle.pipeline(spec, ph, gr, want=("z",))["z"]
+    with api.Context(spec) as ctx:
+        ctx.set_variant(api.VARIANT_STRIP)
+        ctx.set_tuning(**tune)
+        ctx.set_frames(ph, gr)
+        ctx.decode()
+        assert np.array_equal(ctx.get_depth(), ref, equal_nan=True)
 
 
 def test_strip_variant_refuses_ineligible_operands(api, synth):

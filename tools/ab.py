@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Interleaved A/B timing of kernel variants / tuning knobs on the bench workload (GPU box).
-Usage: tools/ab.py "1" "2" "2:SLX_STRIP_ROWS=8" ...   (variant[:ENV=VAL[,ENV=VAL]])
+Usage: tools/ab.py "1" "2" "2:strip_rows=8" ...   (variant[:KEY=VAL[,KEY=VAL]], keys of slx_set_tuning; LIB=path picks
+another build of the library for the whole run)
 All arms run in one process on one device, round-robin, and the median over rounds is reported."""
 import importlib, os, sys, statistics
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -11,7 +12,7 @@ api = importlib.import_module("structured-light-calculation_amd.api")
 arms = []
 for a in sys.argv[1:]:
     v, _, envs = a.partition(":")
-    env = dict(e.split("=") for e in envs.split(",") if e)
+    env = {k: int(v_) for k, v_ in (e.split("=") for e in envs.split(",") if e)}
     arms.append((a, int(v), env))
 cfg = os.environ.get("AB_CONFIG", "C4")
 n_sets = int(os.environ.get("AB_SETS", "32"))
@@ -24,11 +25,8 @@ z = torch.empty((n_sets, H, W), dtype=torch.float64, device="cuda")
 s = torch.cuda.Stream(); torch.cuda.set_stream(s)
 ctxs = {}
 for name, v, env in arms:
-    c = api.Context(spec); c.set_variant(v); ctxs[name] = c
+    c = api.Context(spec); c.set_variant(v); c.set_tuning(**env); ctxs[name] = c
 def run(name, v, env, n):
-    for k in list(os.environ):
-        if k.startswith("SLX_"): del os.environ[k]
-    os.environ.update(env)
     c = ctxs[name]
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(s)
