@@ -4,18 +4,26 @@
 Metric (BASELINE.json): depth frames/s and achieved HBM GB/s at 1920x1200, 3-frequency x
 4-step.  One "step" = one pass of the fused decode over this rank's batch of frame-sets
 (32 per GPU: configuration 4's 256 frame-sets over 8 GPUs), inputs already resident in HBM.
-Ranks shard the batch by frame-set with no collective in the data path ("weak" scaling);
-the RCCL depth-map gather of north_star is timed separately and reported as `with_gather`.
+Ranks shard the batch with no collective in the data path ("weak" scaling); the RCCL
+depth-map gather of north_star is timed separately and reported under `with_gather`, for
+both ways of cutting the batch (whole frame-sets per rank; a row tile of every frame-set per
+rank), kernel-only and end-to-end side by side.
 
   python bench.py [--gpus N] [--steps K] [--warmup W]
-  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-         --master-port P bench.py --gpus N --steps K --warmup W
+
+With --gpus N > 1 and no launcher in the environment, this process starts the N ranks itself
+(one child process per GPU, before anything here touches a GPU) and relays rank 0's JSON
+line.  Under a launcher (`python -m torch.distributed.run --nproc-per-node N ... bench.py
+--gpus N ...`) it is one of the ranks.
 """
 import argparse
+import fcntl
 import importlib
 import json
 import math
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -27,6 +35,18 @@ HBM_PEAK_GBPS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 
 
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
+
+
+def ensure_built():
+    """`make` of the HIP library and the oracle under a file lock (a no-op when up to date): one rank builds, the others
+    wait.  Runs before any GPU call of this process."""
+    with open(os.path.join(ROOT, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            import __graft_entry__
+            __graft_entry__.build()
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
 
 
 def make_batch(torch, synth, spec, n_sets, device, seed):
@@ -67,12 +87,16 @@ def make_batch(torch, synth, spec, n_sets, device, seed):
     return out, gray
 
 
-def cpu_baseline(spec, phase_np, gray_np=None, budget_s=12.0):
-    """The oracle (CPU restatement, reference loop order, one thread) timed on whole frame-sets of
-    the same workload until ~budget_s of CPU work; then once more on all host cores."""
+def load_oracle():
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle as O   # checker / CPU baseline only
     O.build()
+    return O
+
+
+def cpu_baseline(O, spec, phase_np, gray_np=None, budget_s=12.0):
+    """The oracle (CPU restatement, reference loop order, one thread) timed on whole frame-sets of
+    the same workload until ~budget_s of CPU work; then once more on all host cores."""
     n = 0
     t0 = time.perf_counter()
     while True:
@@ -95,10 +119,30 @@ def cpu_baseline(spec, phase_np, gray_np=None, budget_s=12.0):
             break
     multi = {"value": m / dt2, "unit": "frames/s", "cores": cores, "kind": "port",
              "sample": "%d frame-sets, row-parallel OpenMP, %.1f s" % (m, dt2)}
-    return single, multi, O
+    return single, multi
 
 
-def main():
+def kernel_name(spec, variant):
+    strip = variant in (0, 2) and ((spec["mode"] == 3 and spec["n_steps"] in (4, 8)) or (spec["mode"] in (2, 4) and spec["n_steps"] == 4))
+    return ("slx_strip_kernel" if strip else "slx_fused_kernel") + "<mode %d, F=%d, N=%d>" % (spec["mode"], spec["n_freq"], spec["n_steps"])
+
+
+def traffic_entry(config, n_sets):
+    """HBM bytes per launch from the committed PMC capture (not measured in this run): value, provenance."""
+    tp = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        ent = json.load(open(tp)).get(config)
+        if ent:
+            return (ent["hbm_bytes_per_launch"] * n_sets / ent["sets_per_launch"],
+                    "profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE, separate passes, captured in round %s "
+                    "on %d frame-sets per launch; replayed here scaled to %d frame-sets, NOT measured in this run"
+                    % (ent.get("round", "1"), ent["sets_per_launch"], n_sets))
+    except Exception:
+        pass
+    return None, "not measured"
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     # the chip needs ~100 launches (~35 ms) of this kernel after an idle spell before its clock settles
@@ -108,62 +152,184 @@ def main():
     ap.add_argument("--sets-per-gpu", type=int, default=32)
     ap.add_argument("--config", default="C4")
     ap.add_argument("--variant", type=int, default=0)
+    ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE", help="slx_set_tuning override (tools only), e.g. --tune strip_rows=8")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true", help="N = 1: skip the short C3 / C5 timings reported under other_configs")
     ap.add_argument("--no-gather", action="store_true",
-                    help="N > 1: skip the second timed region (decode + RCCL gather of the depth maps to rank 0, reported as with_gather)")
+                    help="N > 1: skip the gather timings (decode + RCCL gather of the depth maps to rank 0, reported as with_gather)")
     ap.add_argument("--shard", choices=("framesets", "rows"), default="framesets",
-                    help="how ranks split the batch: whole frame-sets (default), or a row tile of every frame-set (north_star's wording); "
-                         "the per-GPU bytes are the same")
-    ap.add_argument("--backend", default="nccl", help="nccl (= RCCL) on GPUs; gloo only to rehearse the multi-rank path on one GPU")
-    args = ap.parse_args()
+                    help="how ranks split the batch in the headline (decode-only) region: whole frame-sets (default), or a row tile of every "
+                         "frame-set (north_star's wording); the per-GPU bytes are the same.  with_gather always reports both")
+    ap.add_argument("--gather-chunk", type=int, default=8, help="frame-sets per pipelined decode+gather chunk")
+    ap.add_argument("--backend", default=None, help="nccl (= RCCL, default on GPUs) or gloo (one-GPU rehearsal of the multi-rank path)")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="allow --gpus N on a box with fewer GPUs: the ranks share GPU 0 and talk over gloo (RCCL refuses two ranks on one device)")
+    ap.add_argument("--selftest-launcher", nargs="?", const="ok", default=None, metavar="ok|fail",
+                    help="no GPU, no decode: the ranks only rendezvous over gloo, gather a known array with the shard-table gather and report "
+                         "metric launcher_selftest (tests/test_bench_launcher.py); 'fail' makes the last rank exit non-zero")
+    return ap.parse_args(argv)
+
+
+# ---------------------------------------------------------------------------------------------- the parent of N ranks
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(args, argv):
+    """--gpus N > 1 without a launcher: start N child processes of this script, one per GPU, and relay rank 0's JSON line.
+    This process never touches a GPU (device_count() does not initialise the runtime on this image)."""
+    backend = args.backend
+    if args.selftest_launcher:
+        n_dev, backend = args.gpus, "gloo"
+    else:
+        ensure_built()
+        import torch
+        n_dev = torch.cuda.device_count()
+    if args.selftest_launcher:
+        pass
+    elif n_dev < args.gpus:
+        if not args.rehearse_on_one_gpu:
+            log("bench: --gpus %d asked but %d GPU(s) are visible; refusing (use --rehearse-on-one-gpu to share GPU 0 over gloo)" % (args.gpus, n_dev))
+            return 2
+        if n_dev < 1:
+            log("bench: no GPU visible")
+            return 2
+        if args.gpus > 4:
+            log("bench: a one-GPU rehearsal takes at most 4 ranks (the box allows 6 processes on its card)")
+            return 2
+        backend = "gloo"
+    elif backend is None:
+        backend = "nccl"
+    port = free_port()
+    child_argv = [a for a in argv if a != "--rehearse-on-one-gpu"]
+    if "--backend" not in child_argv:
+        child_argv += ["--backend", backend]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), SLX_BENCH_SELF_LAUNCHED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if backend == "gloo" and not args.selftest_launcher:
+            env["SLX_BENCH_SHARED_GPU"] = "1"
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + child_argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr, text=(r == 0)))
+    # rank 0's stdout is collected by a reader thread (so a full pipe can never block it); the loop below only polls exit codes
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    rc = 0
+    try:
+        while True:
+            codes = [p.poll() for p in procs]
+            bad = [c for c in codes if c not in (None, 0)]
+            if bad:
+                rc = bad[0]
+                break
+            if all(c == 0 for c in codes):
+                break
+            time.sleep(0.2)
+    finally:
+        for p in procs:                                       # the exact children started above, nothing else
+            if p.poll() is None and rc:
+                p.kill()
+        for p in procs:
+            try:
+                p.wait(timeout=60)
+            except Exception:
+                p.kill()
+    reader.join(timeout=10)
+    out0 = "".join(c for c in chunks if c)
+    line = None
+    for ln in out0.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+    if rc != 0 or line is None:
+        log("bench: a rank failed (rc %s)%s" % (rc, "" if line else "; no result line from rank 0"))
+        sys.stderr.write(out0)
+        return rc or 1
+    print(line, flush=True)
+    return 0
+
+
+# -------------------------------------------------------------------------------------------------------- one rank
+def run_rank(args):
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    args.gpus = world
+    if not os.environ.get("SLX_BENCH_SELF_LAUNCHED"):
+        ensure_built()                     # before any GPU call; under a launcher every rank passes through the lock
 
     import numpy as np
     import torch
     import torch.distributed as dist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run for --gpus > 1")
-        args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the decode has no CPU fallback")
-    dev_index = local_rank % torch.cuda.device_count()
+    shared_gpu = bool(os.environ.get("SLX_BENCH_SHARED_GPU"))
+    backend = args.backend or ("gloo" if shared_gpu else "nccl")
+    n_dev = torch.cuda.device_count()
+    if world > 1 and backend == "nccl" and n_dev < world:
+        raise SystemExit("bench: %d ranks but %d GPU(s): RCCL needs one GPU per rank" % (world, n_dev))
+    dev_index = 0 if shared_gpu else local_rank % n_dev
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.backend == "nccl":
+        if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
         else:
-            dist.init_process_group(args.backend, rank=rank, world_size=world)
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    coll_dev = device if backend == "nccl" else torch.device("cpu")
 
     synth = importlib.import_module(PKG + ".synth")
     api = importlib.import_module(PKG + ".api")
     shard = importlib.import_module(PKG + ".shard")
-    if not os.path.exists(api.LIB_PATH) and int(os.environ.get("LOCAL_RANK", "0")) == 0:
-        import __graft_entry__      # an unbuilt tree (fresh checkout): compile the HIP library once, in-tree
-        __graft_entry__.build()
-    if world > 1:
-        dist.barrier()
     api.lib()   # raises if the HIP library is missing: there is no other implementation
 
-    spec = synth.make_spec(args.config)
-    full_h = spec["height"]
-    n_sets = args.sets_per_gpu
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def max_over_ranks(values):
+        t = torch.tensor(values, dtype=torch.float64, device=coll_dev)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return [float(v) for v in t]
+
+    tune = {}
+    for kv in args.tune:
+        k, _, v = kv.partition("=")
+        tune[k] = int(v)
+
+    full_spec = synth.make_spec(args.config)
+    full_h = full_spec["height"]
+    spec, n_sets = full_spec, args.sets_per_gpu
     if args.shard == "rows" and world > 1:
         # every rank decodes its row tile of all world * sets_per_gpu frame-sets (row_offset keeps v - cy right)
-        spec, _, _ = shard.row_tile_spec(spec, world, rank)
+        spec, _, _ = shard.row_tile_spec(full_spec, world, rank)
         n_sets = args.sets_per_gpu * world
     H, W = spec["height"], spec["width"]
     n_phase, n_gray = synth.n_planes(spec)
-    bytes_per_set = H * W * synth.algorithmic_bytes_per_pixel(spec)
-    bytes_per_launch = n_sets * bytes_per_set
+    bpp = synth.algorithmic_bytes_per_pixel(spec)
+    bytes_per_launch = n_sets * H * W * bpp
 
     t0 = time.perf_counter()
-    phase, gray = make_batch(torch, synth, spec, n_sets, device, seed=0x5EED + 4 + rank)
+    phase_full, gray_full = make_batch(torch, synth, full_spec, args.sets_per_gpu, device, seed=0x5EED + 4 + rank)
+    if spec is full_spec:
+        phase, gray = phase_full, gray_full
+    else:
+        lo = spec["row_offset"]
+        phase = phase_full[:, :, lo:lo + H].repeat(world, 1, 1, 1).contiguous()
+        gray = None if gray_full is None else gray_full[:, :, lo:lo + H].repeat(world, 1, 1, 1).contiguous()
     z = torch.empty((n_sets, H, W), dtype=torch.float64, device=device)
     torch.cuda.synchronize()
     if rank == 0:
@@ -172,19 +338,25 @@ def main():
 
     ctx = api.Context(spec, device=dev_index)
     ctx.set_variant(args.variant)
+    ctx.set_tuning(**tune)
     stream = torch.cuda.Stream(device=device)      # an explicit stream: the library treats NULL as "my own stream"
     torch.cuda.set_stream(stream)
     sh = stream.cuda_stream
     assert sh != 0
 
+    def timed(fn, n):
+        """n calls of fn bracketed by HIP events on the launch stream: (host seconds, ms per call by the events)."""
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        ev0.record(stream)
+        for _ in range(n):
+            fn()
+        ev1.record(stream)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0, ev0.elapsed_time(ev1) / n
+
     def step():
         ctx.decode_batch(n_sets, phase, gray, z, stream=sh)
-
-    def fence():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
 
     # The chip needs ~100 launches of this kernel after an idle spell before its clock settles (tools/ramp.py).  When the
     # caller asks for fewer warm-up steps than that, the difference runs here, untimed and reported as "settle_launches",
@@ -195,94 +367,228 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record(stream)                    # HIP events on the stream the kernel is launched on
-    for _ in range(args.steps):
-        step()
-    ev1.record(stream)
-    torch.cuda.synchronize()
-    t_local = time.perf_counter() - t0
+    t_local, kernel_ms = timed(step, args.steps)      # HIP events on the stream the kernel is launched on
     fence()
-    kernel_ms = ev0.elapsed_time(ev1) / args.steps          # average launch duration over the timed region
-    coll_dev = device if args.backend == "nccl" else torch.device("cpu")
-    t = torch.tensor([t_local, kernel_ms], dtype=torch.float64, device=coll_dev)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    t_max, kernel_ms_max = float(t[0]), float(t[1])
+    t_max, kernel_ms_max = max_over_ranks([t_local, kernel_ms])
 
-    # parity of what was just timed: frame-set 0 of rank 0 against the oracle
-    result = {}
+    # ------------------------------------------------------------------ N > 1: decode + gather, both ways of cutting the batch
     gather = None
     if world > 1 and not args.no_gather:
-        def gather():
-            if args.backend == "nccl":
-                return shard.gather_depth(z, dst=0)
-            torch.cuda.synchronize()
-            return shard.gather_depth(z.cpu(), dst=0)            # rehearsal only
-        gather_error = None
+        gather = {"rccl_world_size": dist.get_world_size(), "backend": "RCCL (libslx slx_decode_gather: grouped ncclSend/ncclRecv)" if backend == "nccl"
+                  else "%s via torch.distributed (one-GPU rehearsal, depth maps staged through the host)" % backend,
+                  "chunk_sets": args.gather_chunk, "root": 0}
+        comm = None
         try:
-            full = gather()
-            fence()
-            tg = time.perf_counter()
-            reps = max(3, min(20, args.steps // 15))
-            for _ in range(reps):
-                step()
-                full = gather()
-            torch.cuda.synchronize()
-            tg_local = time.perf_counter() - tg
-            fence()
-            tt = torch.tensor([tg_local], dtype=torch.float64, device=coll_dev)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        except Exception as e:      # the decode-only line above must still be reported
-            full, reps, tt = None, 0, None
-            gather_error = "%s: %s" % (type(e).__name__, e)
-        gather = {"error": gather_error} if tt is None else {"value": world * args.sets_per_gpu * reps / float(tt[0]), "unit": "frames/s", "steps": reps,
-                  "collective": "torch.distributed.gather (%s) of f64 depth maps to rank 0" % ("RCCL" if args.backend == "nccl" else args.backend),
-                  "gathered_bytes_per_step": int(world * n_sets * H * W * 8),
-                  "gathered_shape": list(full.shape) if (rank == 0 and full is not None) else None}
+            if backend == "nccl":
+                ids = [api.comm_unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(ids, src=0)
+        except Exception as e:
+            ids = None
+            gather["error"] = "unique id: %s: %s" % (type(e).__name__, e)
+        total = world * args.sets_per_gpu
+        reps = max(3, min(20, args.steps // 15))
+        for split in ("framesets", "rows"):
+            res = {}
+            gctx = None
+            try:
+                if split == "framesets":
+                    gspec = full_spec
+                    table = shard.shards_by_frameset(total, world, full_h)
+                    gphase, ggray = phase_full, gray_full
+                else:
+                    gspec, lo, hi = shard.row_tile_spec(full_spec, world, rank)
+                    table = shard.shards_by_rows(total, world, full_h)
+                    gphase = phase_full[:, :, lo:hi].repeat(world, 1, 1, 1).contiguous()
+                    ggray = None if gray_full is None else gray_full[:, :, lo:hi].repeat(world, 1, 1, 1).contiguous()
+                set0, gn, row0, grows = table[rank]
+                gctx = api.Context(gspec, device=dev_index)
+                gctx.set_variant(args.variant)
+                full = torch.empty((total, full_h, W), dtype=torch.float64, device=device) if rank == 0 else None
+                scratch = None if rank == 0 else torch.empty((gn, grows, W), dtype=torch.float64, device=device)
+                torch.cuda.synchronize()
+                if backend == "nccl":
+                    if ids is None:
+                        raise RuntimeError(gather.get("error", "no unique id"))
+                    comm = api.Comm(gctx, ids[0], world, rank)
+
+                    def decode_only():
+                        gctx.decode_batch_ex(gn, gphase, ggray, z=(full[set0:, row0:] if rank == 0 else scratch),
+                                             plane_stride=(full_h * W if rank == 0 else 0), stream=sh)
+
+                    def decode_and_gather():
+                        comm.decode_gather(table, full_h, args.gather_chunk, gphase, ggray, scratch, full, root=0, stream=sh)
+
+                    def drain():
+                        comm.synchronize()
+                else:
+                    local = torch.empty((gn, grows, W), dtype=torch.float64, device=device)
+                    holder = {}
+
+                    def decode_only():
+                        gctx.decode_batch(gn, gphase, ggray, local, stream=sh)
+
+                    def decode_and_gather():
+                        decode_only()
+                        torch.cuda.synchronize()
+                        holder["full"] = shard.gather_shards(local.cpu(), table, full_h, W, dst=0)
+
+                    def drain():
+                        pass
+                for _ in range(2):
+                    decode_and_gather()
+                drain()
+                fence()
+                tk, _ = timed(decode_only, reps)
+                fence()
+                t0g = time.perf_counter()
+                for _ in range(reps):
+                    decode_and_gather()
+                drain()
+                torch.cuda.synchronize()
+                tg = time.perf_counter() - t0g
+                fence()
+                tk_max, tg_max = max_over_ranks([tk, tg])
+                # the gathered array against what every rank decoded: wrapping int64 sums of the bit patterns, per rank
+                mine = (full[set0:set0 + gn, row0:row0 + grows] if (rank == 0 and backend == "nccl") else
+                        (scratch if backend == "nccl" else local))
+                sums = torch.zeros(world, dtype=torch.int64, device=coll_dev)
+                sums[rank] = mine.contiguous().view(torch.int64).sum().to(coll_dev)
+                dist.all_reduce(sums)
+                ok = None
+                if rank == 0:
+                    got_full = full if backend == "nccl" else holder["full"]
+                    ok = got_full is not None and tuple(got_full.shape) == (total, full_h, W)
+                    for r, (s0, n, r0, rows) in enumerate(table):
+                        if ok and n and rows:
+                            part = got_full[s0:s0 + n, r0:r0 + rows].contiguous().view(torch.int64).sum()
+                            ok = ok and int(part) == int(sums[r])
+                res = {"kernel_only": {"value": total * reps / tk_max, "unit": "frames/s", "ms_per_step": tk_max / reps * 1e3},
+                       "end_to_end": {"value": total * reps / tg_max, "unit": "frames/s", "ms_per_step": tg_max / reps * 1e3},
+                       "steps": reps, "bytes_into_root_per_step": int(((total - gn) * full_h if split == "framesets" else total * (full_h - grows)) * W * 8),
+                       "gathered_shape": [total, full_h, W], "messages_at_root_per_step": (world - 1) * (1 if split == "framesets" else total),
+                       "gathered_equals_local_decodes": ok}
+            except Exception as e:      # the decode-only line above must still be reported
+                res = {"error": "%s: %s" % (type(e).__name__, e)}
+            finally:
+                if comm is not None:
+                    try:
+                        comm.close()
+                    except Exception:
+                        pass
+                    comm = None
+                if gctx is not None:
+                    gctx.close()
+            gather[split] = res
 
     if rank == 0:
         cpu_single = cpu_multi = None
         parity = None
+        other = None
+        if world == 1 and not (args.no_cpu_baseline and args.no_other_configs):
+            O = load_oracle()
         if not args.no_cpu_baseline and world == 1:
             sample = phase[: min(4, n_sets)].cpu().numpy()
             gsample = gray[: min(4, n_sets)].cpu().numpy() if gray is not None else None
-            cpu_single, cpu_multi, O = cpu_baseline(spec, sample, gsample)
+            cpu_single, cpu_multi = cpu_baseline(O, spec, sample, gsample)
             ref = O.pipeline(spec, sample[0], None if gsample is None else gsample[0], want=("z",), threads=min(len(os.sched_getaffinity(0)), 16))["z"]
             got = z[0].cpu().numpy()
             parity = bool(np.array_equal(got, ref, equal_nan=True))
             if not parity:
                 raise SystemExit("bench: frame-set 0 differs from the oracle -- refusing to report a number")
+        if world == 1 and not args.no_other_configs:
+            # the other single-GPU BASELINE configurations, >= 50 launches each after a short settle, so that every one of
+            # them has a number taken by this run's clock; parity of frame-set 0 against the oracle for each
+            other = {}
+            for name, sets in (("C3", 16), ("C5", 4)):
+                if name == args.config:
+                    continue
+                try:
+                    ospec = synth.make_spec(name)
+                    oph, ogr = make_batch(torch, synth, ospec, sets, device, seed=0x5EED + int(name[1]))
+                    oz = torch.empty((sets, ospec["height"], ospec["width"]), dtype=torch.float64, device=device)
+                    torch.cuda.synchronize()
+                    with api.Context(ospec, device=dev_index) as octx:
+                        octx.set_variant(args.variant)
+
+                        def ostep():
+                            octx.decode_batch(sets, oph, ogr, oz, stream=sh)
+                        for _ in range(60):
+                            ostep()
+                        torch.cuda.synchronize()
+                        n_launch = max(50, min(args.steps, 100))
+                        _, oms = timed(ostep, n_launch)
+                    obytes = sets * ospec["height"] * ospec["width"] * synth.algorithmic_bytes_per_pixel(ospec)
+                    oref = O.pipeline(ospec, oph[0].cpu().numpy(), None if ogr is None else ogr[0].cpu().numpy(), want=("z",),
+                                      threads=min(len(os.sched_getaffinity(0)), 16))["z"]
+                    otraffic, osource = traffic_entry(name, sets)
+                    other[name] = {"value": sets / (oms * 1e-3), "unit": "frames/s", "sets_per_launch": sets, "launches": n_launch, "launch_ms": oms,
+                                   "roofline": {"bound": "hbm", "achieved": obytes / (oms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                                "frac": obytes / (oms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "traffic": otraffic, "traffic_source": osource,
+                                                "kernel": kernel_name(ospec, args.variant), "algorithmic_bytes_per_launch": obytes},
+                                   "parity_vs_oracle": bool(np.array_equal(oz[0].cpu().numpy(), oref, equal_nan=True))}
+                    del oph, ogr, oz
+                except Exception as e:
+                    other[name] = {"error": "%s: %s" % (type(e).__name__, e)}
         achieved = bytes_per_launch / (kernel_ms_max * 1e-3) / 1e9
-        traffic = None
-        tp = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tp):
-            try:
-                ent = json.load(open(tp)).get(args.config, {})
-                traffic = ent["hbm_bytes_per_launch"] * n_sets / ent["sets_per_launch"]     # measured per frame-set, scaled to this launch
-            except Exception:
-                traffic = None
+        traffic, traffic_source = traffic_entry(args.config, n_sets)
         result = {
             "metric": "depth_frames_per_sec", "value": world * args.sets_per_gpu * args.steps / t_max, "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": t_max / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32+f64", "data": "synthetic",
             "config": {"workload": "%s: %dx%d, %d-frequency x %d-step temporal unwrap%s + triangulation, %d frame-sets per GPU per step"
-                                   % (args.config, W, H, spec["n_freq"], spec["n_steps"], " + %d-bit Gray mask" % spec["gray_bits"] if n_gray else "", n_sets),
-                       "periods": spec["periods"], "sharding": ("by frame-set" if args.shard == "framesets" or world == 1 else "by row tile (%d rows of %d per GPU)" % (H, full_h)) + ", no data-path collective",
-                       "kernel_variant": args.variant, "settle_launches": settle},
+                                   % (args.config, W, full_h, spec["n_freq"], spec["n_steps"], " + %d-bit Gray mask" % spec["gray_bits"] if n_gray else "", args.sets_per_gpu),
+                       "periods": spec["periods"], "sharding": ("by frame-set" if args.shard == "framesets" or world == 1 else "by row tile (%d rows of %d per GPU, %d frame-sets)" % (H, full_h, n_sets)) + ", no data-path collective",
+                       "kernel_variant": args.variant, "settle_launches": settle, "tuning": tune or None},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "kernel": ("slx_strip_kernel" if (args.variant in (0, 2) and ((spec["mode"] == 3 and spec["n_steps"] in (4, 8)) or (spec["mode"] in (2, 4) and spec["n_steps"] == 4))) else "slx_fused_kernel") + "<mode %d, F=%d, N=%d>" % (spec["mode"], spec["n_freq"], spec["n_steps"]), "launch_ms": kernel_ms_max,
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
+                         "kernel": kernel_name(spec, args.variant), "launch_ms": kernel_ms_max,
                          "algorithmic_bytes_per_launch": bytes_per_launch},
             "achieved_hbm_gbps_per_gpu": achieved,
+            "rccl_world_size": (dist.get_world_size() if world > 1 else 1), "collective_backend": (backend if world > 1 else None),
             "cpu_baseline": cpu_single, "cpu_baseline_all_cores": cpu_multi,
-            "parity_vs_oracle": parity, "with_gather": gather,
+            "parity_vs_oracle": parity, "other_configs": other, "with_gather": gather,
         }
         print(json.dumps(result), flush=True)
     ctx.close()
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
+
+
+def selftest_rank(args):
+    """--selftest-launcher: what a rank does around the decode -- rendezvous, barrier, MAX all-reduce, the shard-table gather of
+    both splits -- on gloo with known arrays, no GPU and no decode."""
+    import torch
+    import torch.distributed as dist
+    world, rank = int(os.environ["WORLD_SIZE"]), int(os.environ["RANK"])
+    shard = importlib.import_module(PKG + ".shard")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.barrier()
+    if args.selftest_launcher == "fail" and rank == world - 1:
+        os._exit(3)
+    t = torch.tensor([float(rank)], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    total, H, W = 2 * world, 13, 8
+    want = torch.arange(total * H * W, dtype=torch.float64).reshape(total, H, W)
+    ok = {}
+    for name, table in (("framesets", shard.shards_by_frameset(total, world, H)), ("rows", shard.shards_by_rows(total, world, H))):
+        s0, n, r0, rows = table[rank]
+        full = shard.gather_shards(want[s0:s0 + n, r0:r0 + rows].contiguous(), table, H, W, dst=0)
+        ok[name] = bool(rank != 0 or torch.equal(full, want))
+    dist.barrier()
+    if rank == 0:
+        print(json.dumps({"metric": "launcher_selftest", "value": float(t[0]), "unit": "max rank", "n_gpus": world,
+                          "rccl_world_size": dist.get_world_size(), "collective_backend": "gloo", "with_gather": ok}), flush=True)
+    dist.destroy_process_group()
+
+
+def main():
+    args = parse_args()
+    if "WORLD_SIZE" not in os.environ and "RANK" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args, sys.argv[1:]))
+    if args.selftest_launcher:
+        return selftest_rank(args)
+    run_rank(args)
 
 
 if __name__ == "__main__":

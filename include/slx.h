@@ -149,6 +149,26 @@ int slx_decode_batch(slx_ctx *ctx, int n_sets,
                      const uint8_t *gray_base, size_t gray_set_stride,
                      size_t row_stride, double *z_out, void *stream);
 
+/* Output planes of slx_decode_batch_ex.  Every plane is device memory.  Plane q of frame-set s of an output with P planes
+ * per set (P = 1; F-1 for k) starts `(s*P + q) * plane_stride` elements after the pointer, and the tile's row 0 at that
+ * address: plane_stride = 0 means dense (height*width).  A larger plane_stride lets a row tile be decoded straight into its
+ * rows of a full-height map (pointer = map + row0*width, plane_stride = full_height*width): the layout the gather below
+ * delivers, with no copy in between.  z is required for the depth modes (for PHASE_ONLY / GRAY_ONLY it receives the mode's
+ * primary output); the others are optional (NULL = not produced) and are what the reference computes beside z for every
+ * frame: x, y (R/CCalculation.cpp:756-771), the projector column U (m_ProjectorU), the fringe orders k of the temporal
+ * unwrap and the validity mask of the BUILD-DEFINED modes. */
+typedef struct slx_batch_out {
+    double *z;
+    double *x, *y, *U;
+    int32_t *k;
+    uint8_t *mask;
+    size_t plane_stride;
+} slx_batch_out;
+int slx_decode_batch_ex(slx_ctx *ctx, int n_sets,
+                        const uint8_t *phase_base, size_t phase_set_stride,
+                        const uint8_t *gray_base, size_t gray_set_stride,
+                        size_t row_stride, const slx_batch_out *out, void *stream);
+
 int slx_synchronize(slx_ctx *ctx);
 
 /* Copies an output of the last slx_decode (waits for it).  dst_bytes must be at least the
@@ -236,6 +256,45 @@ int slx_pipe_submit(slx_pipe *pipe, int n_sets);
  * NULL when not wanted.  The pointers stay valid until that slot is acquired again. */
 int slx_pipe_collect(slx_pipe *pipe, const double **host_result, const double **device_result, int *n_sets);
 const char *slx_pipe_last_error(const slx_pipe *pipe);
+
+/* ---- multi-GPU: one process per GPU, the final depth-map gather over RCCL / xGMI -------------------------------------
+ * The decode is pixel-independent, so ranks exchange nothing while computing; the only
+ * collective is the gather of the finished depth maps.  Rank r holds the rows [row0, row0+rows) of the frame-sets
+ * [set0, set0+n_sets) of a batch whose full result is f64 [total_sets][height][width]: whole frame-sets (rows == height)
+ * or a row tile of every frame-set (the split BASELINE.json's north_star words).  The gather reassembles [set][H][W]
+ * on `root` (or on every rank, root = -1): grouped ncclSend / ncclRecv, one message per (peer, frame-set) landing at
+ * its row offset of that set, so the root's 7 xGMI links carry traffic at once and no staging copy or transpose follows.
+ * The reference has no counterpart (single process); this is the drop-in for a host loop that spreads a batch over a node. */
+typedef struct slx_comm slx_comm;
+typedef struct slx_shard { int set0, n_sets, row0, rows; } slx_shard;
+#define SLX_COMM_ID_BYTES 128
+/* Rank 0 makes an id (ncclGetUniqueId) and hands the 128 bytes to the other ranks by any means (a file, MPI, a socket ...). */
+int slx_comm_unique_id(void *id, size_t id_bytes);
+/* Collective over all `world` ranks: ncclCommInitRank on the context's device.  The comm owns a gather stream. */
+int slx_comm_create(slx_ctx *ctx, const void *id, size_t id_bytes, int world, int rank, slx_comm **out);
+/* Wraps a communicator the host already has (an ncclComm_t whose device is the context's); it is not destroyed with the wrapper. */
+int slx_comm_adopt(slx_ctx *ctx, void *nccl_comm, slx_comm **out);
+void slx_comm_destroy(slx_comm *comm);
+int slx_comm_info(const slx_comm *comm, int *world, int *rank);
+const char *slx_comm_last_error(const slx_comm *comm);   /* comm == NULL: of the last failed create on this thread */
+/* Waits for everything queued on the comm's gather stream. */
+int slx_comm_synchronize(slx_comm *comm);
+/* One gather.  shards[world]: what every rank holds (the same table on every rank).  local: this rank's shard, plane
+ * (s - set0) at local + (s - set0)*local_plane_stride doubles (0 = dense rows*width); it may point into `full`
+ * (local == full + (set0*height + row0)*width, local_plane_stride == height*width: decoded in place, nothing is copied).
+ * full: f64 [total_sets][height][width] on the destination ranks, ignored elsewhere.  Queued on `stream` (NULL: the comm's
+ * gather stream); asynchronous. */
+int slx_gather_depth(slx_comm *comm, const slx_shard *shards, int height, int width,
+                     const double *local, size_t local_plane_stride, double *full, int root, void *stream);
+/* Decode + gather of this rank's shard, pipelined: the shard's frame-sets are decoded `chunk_sets` at a time on `stream`
+ * (NULL: the context's) and every finished chunk is gathered on the comm's stream while the next one decodes.  Inputs as
+ * slx_decode_batch (this rank's shards[rank].n_sets frame-sets, tile height shards[rank].rows = the context's height).
+ * Destination ranks decode in place into `full`; the others into `scratch` (f64 [n_sets][rows][width], may be NULL on
+ * destination ranks).  Every rank must pass the same shards / chunk_sets / root.  Asynchronous: slx_comm_synchronize. */
+int slx_decode_gather(slx_comm *comm, slx_ctx *ctx, const slx_shard *shards, int full_height, int chunk_sets,
+                      const uint8_t *phase_base, size_t phase_set_stride,
+                      const uint8_t *gray_base, size_t gray_set_stride, size_t row_stride,
+                      double *scratch, double *full, int root, void *stream);
 
 /* ---- file formats of a DynaFrame data directory (host only, no GPU needed) ----
  * 8-bit grey pixels of an uncompressed BMP (8-bit paletted or 24/32-bit colour, converted like

@@ -31,6 +31,8 @@ SYMBOLS = [
     "slx_set_frame", "slx_decode", "slx_decode_batch", "slx_synchronize", "slx_get_output",
     "slx_get_depth", "slx_get_point_cloud", "slx_track_begin", "slx_track_next", "slx_output_device_ptr", "slx_get_calibration", "slx_enable_timing",
     "slx_last_decode_ms", "slx_debug_stamps", "slx_set_variant", "slx_set_tuning", "slx_read_bmp_gray", "slx_read_pgm_gray", "slx_read_calibration_yaml", "slx_version",
+    "slx_decode_batch_ex", "slx_comm_unique_id", "slx_comm_create", "slx_comm_adopt", "slx_comm_destroy", "slx_comm_info", "slx_comm_last_error",
+    "slx_comm_synchronize", "slx_gather_depth", "slx_decode_gather",
     "slx_pipe_create", "slx_pipe_destroy", "slx_pipe_layout", "slx_pipe_acquire", "slx_pipe_submit", "slx_pipe_collect", "slx_pipe_last_error",
 ]
 
@@ -45,6 +47,18 @@ class SlxConfig(C.Structure):
         ("cam", C.c_double * 9), ("pro", C.c_double * 9), ("rot", C.c_double * 9), ("trans", C.c_double * 3),
         ("device", C.c_int), ("aux_outputs", C.c_uint),
     ]
+
+
+class SlxBatchOut(C.Structure):
+    _fields_ = [("z", C.c_void_p), ("x", C.c_void_p), ("y", C.c_void_p), ("U", C.c_void_p), ("k", C.c_void_p), ("mask", C.c_void_p),
+                ("plane_stride", C.c_size_t)]
+
+
+class SlxShard(C.Structure):
+    _fields_ = [("set0", C.c_int), ("n_sets", C.c_int), ("row0", C.c_int), ("rows", C.c_int)]
+
+
+COMM_ID_BYTES = 128
 
 
 class SlxPipeConfig(C.Structure):
@@ -67,6 +81,12 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise ImportError("libslx.so is not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
                               "(there is no fallback implementation)")
+        try:
+            # When PyTorch is installed, its wheel's HIP runtime and RCCL (same SONAMEs as /opt/rocm's) must be the copies this
+            # process binds, whichever of the two libraries is asked for first: buffers and streams cross between them.
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         vp, sz = C.c_void_p, C.c_size_t
         L.slx_validate_config.argtypes = [C.POINTER(SlxConfig), C.c_char_p, sz]
@@ -79,6 +99,18 @@ def lib():
         L.slx_set_frame.argtypes = [vp, C.c_int, C.c_int, vp, sz, C.c_int]
         L.slx_decode.argtypes = [vp, vp]
         L.slx_decode_batch.argtypes = [vp, C.c_int, vp, sz, vp, sz, sz, vp, vp]
+        L.slx_decode_batch_ex.argtypes = [vp, C.c_int, vp, sz, vp, sz, sz, C.POINTER(SlxBatchOut), vp]
+        L.slx_comm_unique_id.argtypes = [vp, sz]
+        L.slx_comm_create.argtypes = [vp, vp, sz, C.c_int, C.c_int, C.POINTER(vp)]
+        L.slx_comm_adopt.argtypes = [vp, vp, C.POINTER(vp)]
+        L.slx_comm_destroy.argtypes = [vp]
+        L.slx_comm_destroy.restype = None
+        L.slx_comm_info.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.slx_comm_last_error.argtypes = [vp]
+        L.slx_comm_last_error.restype = C.c_char_p
+        L.slx_comm_synchronize.argtypes = [vp]
+        L.slx_gather_depth.argtypes = [vp, C.POINTER(SlxShard), C.c_int, C.c_int, vp, sz, vp, C.c_int, vp]
+        L.slx_decode_gather.argtypes = [vp, vp, C.POINTER(SlxShard), C.c_int, C.c_int, vp, sz, vp, sz, sz, vp, vp, C.c_int, vp]
         L.slx_synchronize.argtypes = [vp]
         L.slx_get_output.argtypes = [vp, C.c_int, vp, sz, C.c_int]
         L.slx_get_depth.argtypes = [vp, vp, C.c_int]
@@ -105,7 +137,7 @@ def lib():
         L.slx_pipe_last_error.argtypes = [vp]
         L.slx_pipe_last_error.restype = C.c_char_p
         for name in SYMBOLS:
-            if name not in ("slx_destroy", "slx_last_error", "slx_pipe_destroy", "slx_pipe_last_error"):
+            if name not in ("slx_destroy", "slx_last_error", "slx_pipe_destroy", "slx_pipe_last_error", "slx_comm_destroy", "slx_comm_last_error"):
                 getattr(L, name).restype = C.c_int
         _lib = L
     return _lib
@@ -230,6 +262,25 @@ class Context:
         ref = phase if phase is not None else gray
         rs = ref.stride(-2) if row_stride is None else row_stride
         self._check(lib().slx_decode_batch(self._h, n_sets, pb, ps, gb, gs, rs, z_out.data_ptr(), stream))
+
+    def decode_batch_ex(self, n_sets, phase=None, gray=None, z=None, x=None, y=None, U=None, k=None, mask=None, plane_stride=0, stream=None,
+                        row_stride=None):
+        """slx_decode_batch_ex: like decode_batch, with the optional outputs (CUDA tensors, or raw device addresses) and a
+        plane stride in elements (0 = dense)."""
+        def base(t):
+            if t is None:
+                return None, 0
+            assert t.is_cuda and t.stride(-1) == 1
+            return t.data_ptr(), t.stride(0) * t.element_size()
+
+        def addr(t):
+            return None if t is None else (t if isinstance(t, int) else t.data_ptr())
+        pb, ps = base(phase)
+        gb, gs = base(gray)
+        ref = phase if phase is not None else gray
+        rs = ref.stride(-2) if row_stride is None else row_stride
+        out = SlxBatchOut(addr(z), addr(x), addr(y), addr(U), addr(k), addr(mask), int(plane_stride))
+        self._check(lib().slx_decode_batch_ex(self._h, n_sets, pb, ps, gb, gs, rs, C.byref(out), stream))
 
     def synchronize(self):
         self._check(lib().slx_synchronize(self._h))
@@ -374,6 +425,77 @@ class Pipe:
             return d.value, n.value
         buf = (C.c_double * (n.value * self.height * self.width)).from_address(h.value)
         return np.frombuffer(buf, dtype=np.float64).reshape(n.value, self.height, self.width)
+
+
+def comm_unique_id():
+    """128 bytes from ncclGetUniqueId (rank 0 makes it; the other ranks receive it by any means)."""
+    buf = C.create_string_buffer(COMM_ID_BYTES)
+    rc = lib().slx_comm_unique_id(buf, COMM_ID_BYTES)
+    if rc != OK:
+        raise SlxError(rc, lib().slx_comm_last_error(None).decode())
+    return buf.raw
+
+
+def shard_table(shards):
+    """[(set0, n_sets, row0, rows), ...] per rank -> the C array slx_gather_depth takes."""
+    arr = (SlxShard * len(shards))()
+    for i, (set0, n, row0, rows) in enumerate(shards):
+        arr[i] = SlxShard(int(set0), int(n), int(row0), int(rows))
+    return arr
+
+
+class Comm:
+    """The RCCL communicator of the depth-map gather (slx_comm_*), one per rank, bound to a Context."""
+
+    def __init__(self, ctx, unique_id, world, rank):
+        self._ctx = ctx
+        self._h = C.c_void_p()
+        rc = lib().slx_comm_create(ctx._h, unique_id, len(unique_id), int(world), int(rank), C.byref(self._h))
+        if rc != OK:
+            self._h = C.c_void_p()
+            raise SlxError(rc, lib().slx_comm_last_error(None).decode())
+        w, r = C.c_int(), C.c_int()
+        lib().slx_comm_info(self._h, C.byref(w), C.byref(r))
+        self.world, self.rank = w.value, r.value
+
+    def close(self):
+        if self._h:
+            lib().slx_comm_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != OK:
+            raise SlxError(rc, lib().slx_comm_last_error(self._h).decode())
+
+    def synchronize(self):
+        self._check(lib().slx_comm_synchronize(self._h))
+
+    def gather_depth(self, shards, height, width, local, full, root=0, local_plane_stride=0, stream=None):
+        """shards: [(set0, n_sets, row0, rows)] per rank; local / full: CUDA float64 tensors (full may be None on ranks that
+        do not receive).  Asynchronous on the comm's gather stream (or `stream`)."""
+        self._check(lib().slx_gather_depth(self._h, shard_table(shards), int(height), int(width), None if local is None else local.data_ptr(),
+                                           int(local_plane_stride), None if full is None else full.data_ptr(), int(root), stream))
+
+    def decode_gather(self, shards, full_height, chunk_sets, phase, gray, scratch, full, root=0, stream=None, row_stride=None):
+        """slx_decode_gather: this rank's shard decoded chunk by chunk, every chunk gathered while the next decodes."""
+        def base(t):
+            if t is None:
+                return None, 0
+            assert t.is_cuda and t.stride(-1) == 1
+            return t.data_ptr(), t.stride(0) * t.element_size()
+        pb, ps = base(phase)
+        gb, gs = base(gray)
+        ref = phase if phase is not None else gray
+        rs = ref.stride(-2) if row_stride is None else row_stride
+        self._check(lib().slx_decode_gather(self._h, self._ctx._h, shard_table(shards), int(full_height), int(chunk_sets), pb, ps, gb, gs, rs,
+                                            None if scratch is None else scratch.data_ptr(), None if full is None else full.data_ptr(),
+                                            int(root), stream))
 
 
 def _read_gray_file(fn, path):

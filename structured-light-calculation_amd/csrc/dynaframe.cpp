@@ -99,7 +99,8 @@ bool CDecodePhase::SetMat(int num, const Image8 &pic)
 
 bool CDecodePhase::Decode()
 {
-    if (!m_ctx || slx_decode(m_ctx, nullptr) != SLX_OK) {
+    // synchronous, like the reference's Decode(): borrowed device images may be rewritten as soon as it returns
+    if (!m_ctx || slx_decode(m_ctx, nullptr) != SLX_OK || slx_synchronize(m_ctx) != SLX_OK) {
         m_err = m_ctx ? slx_last_error(m_ctx) : "CDecodePhase.Decode()->CountResult fault";
         return false;
     }
@@ -181,7 +182,7 @@ bool CDecodeGray::Decode()
         m_err = "Gray Decode->Open file error.";
         return false;
     }
-    if (slx_set_gray_lut(m_ctx, lut.data(), lut.size()) != SLX_OK || slx_decode(m_ctx, nullptr) != SLX_OK) {
+    if (slx_set_gray_lut(m_ctx, lut.data(), lut.size()) != SLX_OK || slx_decode(m_ctx, nullptr) != SLX_OK || slx_synchronize(m_ctx) != SLX_OK) {
         m_err = slx_last_error(m_ctx);
         return false;
     }
@@ -262,7 +263,7 @@ bool CCalculation::SetSensorFrame(int groupNum, int idx, const Image8 &pic)
 bool CCalculation::CalculateFirst()
 {
     if (!m_ctx) return false;                           // R/CCalculation.cpp:176-181
-    if (slx_decode(m_ctx, nullptr) != SLX_OK) {
+    if (slx_decode(m_ctx, nullptr) != SLX_OK || slx_synchronize(m_ctx) != SLX_OK) {   // synchronous, like the reference's
         m_err = slx_last_error(m_ctx);
         return false;
     }

@@ -38,6 +38,11 @@ struct slx_ctx {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
+    // Completion of the most recent work that wrote the context's outputs or read its staged inputs, on whatever stream it
+    // ran (the context's own or a caller's): what a later host copy / staging overwrite / launch on another stream waits for.
+    hipEvent_t ev_done = nullptr;
+    hipStream_t ev_stream = nullptr;           // the stream ev_done was recorded on
+    bool ev_pending = false;
     std::vector<int16_t> lut;
     int16_t *d_lut = nullptr;
     std::vector<Plane> phase, gray;
@@ -46,7 +51,13 @@ struct slx_ctx {
     size_t cloud_capacity = 0;
     // dynamic-frame tracker: previous frame's strips, unblurred deltaP, staged camera image
     float *d_stripW_prev = nullptr, *d_stripB_prev = nullptr, *d_deltaP_raw = nullptr;
-    uint8_t *d_track_img = nullptr;
+    // camera images of host-fed dynamic frames: two pinned host buffers and two device buffers, used alternately, so that
+    // frame n+1's copy-in (copy stream) overlaps frame n's kernels (the context's stream)
+    uint8_t *h_track_img[2] = {nullptr, nullptr}, *d_track_img[2] = {nullptr, nullptr};
+    hipEvent_t ev_track_copied[2] = {nullptr, nullptr}, ev_track_used[2] = {nullptr, nullptr};
+    bool track_slot_used[2] = {false, false};
+    hipStream_t copy_stream = nullptr;
+    unsigned track_slot = 0;
     int track_window = 0;
     void *out[SLX_OUT_COUNT] = {};
     size_t out_bytes[SLX_OUT_COUNT] = {};
@@ -215,6 +226,25 @@ bool is_reflected_gray(const std::vector<int16_t> &lut)
 
 bool ptr_aligned(const void *p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
 
+// The three uses of ev_done (see slx_ctx).
+int mark_done(slx_ctx *ctx, hipStream_t s)
+{
+    SLX_HIP(ctx, hipEventRecord(ctx->ev_done, s));
+    ctx->ev_stream = s;
+    ctx->ev_pending = true;
+    return SLX_OK;
+}
+int wait_done_host(slx_ctx *ctx)
+{
+    if (ctx->ev_pending) SLX_HIP(ctx, hipEventSynchronize(ctx->ev_done));
+    return SLX_OK;
+}
+int order_after_done(slx_ctx *ctx, hipStream_t s)
+{
+    if (ctx->ev_pending && s != ctx->ev_stream) SLX_HIP(ctx, hipStreamWaitEvent(s, ctx->ev_done, 0));   // same stream: already ordered
+    return SLX_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -244,11 +274,16 @@ void slx_destroy(slx_ctx *ctx)
     for (void *o : ctx->out)
         if (o) (void)hipFree(o);
     if (ctx->d_lut) (void)hipFree(ctx->d_lut);
+    if (ctx->ev_pending) (void)hipEventSynchronize(ctx->ev_done);
+    if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
     for (void *q : {(void *)ctx->d_cloud_counts, (void *)ctx->d_cloud_offsets, (void *)ctx->d_cloud, (void *)ctx->d_stripW_prev,
-                    (void *)ctx->d_stripB_prev, (void *)ctx->d_deltaP_raw, (void *)ctx->d_track_img})
+                    (void *)ctx->d_stripB_prev, (void *)ctx->d_deltaP_raw, (void *)ctx->d_track_img[0], (void *)ctx->d_track_img[1]})
         if (q) (void)hipFree(q);
-    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
-    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    for (uint8_t *h : ctx->h_track_img)
+        if (h) (void)hipHostFree(h);
+    for (hipEvent_t e : {ctx->ev0, ctx->ev1, ctx->ev_done, ctx->ev_track_copied[0], ctx->ev_track_copied[1], ctx->ev_track_used[0], ctx->ev_track_used[1]})
+        if (e) (void)hipEventDestroy(e);
+    if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -290,6 +325,7 @@ int slx_create(const slx_config *cfg, slx_ctx **out)
     SLX_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
     SLX_TRY(hipEventCreate(&ctx->ev0));
     SLX_TRY(hipEventCreate(&ctx->ev1));
+    SLX_TRY(hipEventCreateWithFlags(&ctx->ev_done, hipEventDisableTiming));
 
     const slx_config &c = ctx->cfg;
     const int n_phase = mode_has_phase(c.mode) ? c.n_freq * c.n_steps : 0;
@@ -377,6 +413,8 @@ int slx_set_frame(slx_ctx *ctx, int group, int idx, const uint8_t *data, size_t 
         p.stride = stride_bytes;
     } else {
         if (!p.owned) SLX_HIP(ctx, hipMalloc((void **)&p.owned, ctx->staging_pitch * (size_t)ctx->cfg.height));
+        // the previous decode (asynchronous, on the context's or a caller's stream) may still be reading the staging buffer
+        if (int rc = wait_done_host(ctx)) return rc;
         // deep copy, complete before return (pic.copyTo, R/CDecodePhase.cpp:114)
         SLX_HIP(ctx, hipMemcpy2D(p.owned, ctx->staging_pitch, data, stride_bytes, (size_t)ctx->cfg.width,
                                  (size_t)ctx->cfg.height, hipMemcpyHostToDevice));
@@ -394,7 +432,7 @@ int slx_set_gray_lut(slx_ctx *ctx, const int16_t *lut, size_t n)
     if (n != ctx->lut.size()) return fail(ctx, SLX_ERR_INVALID_ARG, "table has %zu entries, expected %zu", n, ctx->lut.size());
     ctx->lut.assign(lut, lut + n);
     SLX_HIP(ctx, hipSetDevice(ctx->device));
-    SLX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (int rc = wait_done_host(ctx)) return rc;          // the last decode may still be reading the table, on any stream
     SLX_HIP(ctx, hipMemcpy(ctx->d_lut, ctx->lut.data(), n * sizeof(int16_t), hipMemcpyHostToDevice));
     ctx->kp.std_gray = is_reflected_gray(ctx->lut) ? 1 : 0;
     return SLX_OK;
@@ -413,6 +451,12 @@ static int launch(slx_ctx *ctx, SlxKParams &kp, int n_sets, bool aux, void *stre
     for (const void *o : {(const void *)kp.z, (const void *)kp.x, (const void *)kp.y, (const void *)kp.U, (const void *)kp.pix,
                           (const void *)kp.gray_out, (const void *)kp.k, (const void *)kp.mask})
         al = al && ptr_aligned(o, 16);
+    // every plane of every frame-set must start 16-byte aligned too: (set * planes + plane) * out_set_stride elements in
+    auto pitch_ok = [&](const void *o, size_t elem, size_t planes) {
+        return !o || (n_sets == 1 && planes <= 1) || (kp.out_set_stride * elem) % 16 == 0;
+    };
+    al = al && pitch_ok(kp.z, 8, 1) && pitch_ok(kp.x, 8, 1) && pitch_ok(kp.y, 8, 1) && pitch_ok(kp.U, 8, 1) && pitch_ok(kp.gray_out, 8, 1) &&
+         pitch_ok(kp.pix, 8, (size_t)kp.n_freq) && pitch_ok(kp.k, 4, (size_t)(kp.n_freq > 1 ? kp.n_freq - 1 : 1)) && pitch_ok(kp.mask, 1, 1);
     kp.aligned = al ? 1 : 0;
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
     SLX_HIP(ctx, hipSetDevice(ctx->device));
@@ -420,11 +464,14 @@ static int launch(slx_ctx *ctx, SlxKParams &kp, int n_sets, bool aux, void *stre
         return fail(ctx, SLX_ERR_UNAVAILABLE, "variant %d (strip kernel) cannot run this configuration or these operands", ctx->variant);
     if (ctx->variant == SLX_VARIANT_GENERIC_FAST && !(mode_has_depth(c.mode) && slx_fast_arith_ok(kp)))
         return fail(ctx, SLX_ERR_UNAVAILABLE, "variant %d (cheap exact arithmetic) needs a depth mode, periods <= 2^14 and moderate calibration magnitudes", ctx->variant);
+    // ordered after the last work on the context's outputs when that ran on another stream (tracker / cloud kernels on the
+    // context's stream, an earlier decode on a caller's stream)
+    if (int rc2 = order_after_done(ctx, s)) return rc2;
     if (ctx->timed) SLX_HIP(ctx, hipEventRecord(ctx->ev0, s));
     int e = slx_launch_fused(kp, c.mode, aux, n_sets, ctx->variant, s, &ctx->tune);
     if (e != 0) return hip_fail(ctx, (hipError_t)e, "kernel launch");
     if (ctx->timed) SLX_HIP(ctx, hipEventRecord(ctx->ev1, s));
-    return SLX_OK;
+    return mark_done(ctx, s);
 }
 
 int slx_decode(slx_ctx *ctx, void *stream)
@@ -450,41 +497,69 @@ int slx_decode(slx_ctx *ctx, void *stream)
     return rc;
 }
 
-int slx_decode_batch(slx_ctx *ctx, int n_sets, const uint8_t *phase_base, size_t phase_set_stride,
-                     const uint8_t *gray_base, size_t gray_set_stride, size_t row_stride, double *z_out, void *stream)
+int slx_decode_batch_ex(slx_ctx *ctx, int n_sets, const uint8_t *phase_base, size_t phase_set_stride, const uint8_t *gray_base,
+                        size_t gray_set_stride, size_t row_stride, const slx_batch_out *out, void *stream)
 {
     if (!ctx) return SLX_ERR_INVALID_ARG;
     const slx_config &c = ctx->cfg;
     const size_t n_phase = ctx->phase.size(), n_gray = ctx->gray.size();
+    if (!out) return fail(ctx, SLX_ERR_INVALID_ARG, "out is NULL");
     if (n_phase && !phase_base) return fail(ctx, SLX_ERR_MISSING_FRAME, "phase_base is NULL");
     if (n_gray && !gray_base) return fail(ctx, SLX_ERR_MISSING_FRAME, "gray_base is NULL");
     if (row_stride < (size_t)c.width) return fail(ctx, SLX_ERR_INVALID_ARG, "row stride %zu is smaller than the width %d", row_stride, c.width);
     const size_t plane_bytes = row_stride * (size_t)c.height;
     if (n_sets > 1 && n_phase && phase_set_stride < n_phase * plane_bytes) return fail(ctx, SLX_ERR_INVALID_ARG, "phase_set_stride %zu overlaps frame-sets", phase_set_stride);
     if (n_sets > 1 && n_gray && gray_set_stride < n_gray * plane_bytes) return fail(ctx, SLX_ERR_INVALID_ARG, "gray_set_stride %zu overlaps frame-sets", gray_set_stride);
+    const size_t hw = (size_t)c.width * (size_t)c.height;
+    if (out->plane_stride != 0 && out->plane_stride < hw) return fail(ctx, SLX_ERR_INVALID_ARG, "plane_stride %zu is smaller than the tile (%zu pixels)", out->plane_stride, hw);
     SlxKParams kp = ctx->kp;
     for (size_t i = 0; i < n_phase; i++) kp.phase[i] = phase_base + i * plane_bytes;
     for (size_t i = 0; i < n_gray; i++) kp.gray[i] = gray_base + i * plane_bytes;
     kp.phase_set_stride = n_phase ? phase_set_stride : 0;
     kp.gray_set_stride = n_gray ? gray_set_stride : 0;
     kp.row_stride = row_stride;
-    // the batch path produces the primary output only
-    double *primary = z_out;
+    kp.out_set_stride = out->plane_stride ? out->plane_stride : hw;
+    double *primary = out->z;
     if (!primary) return fail(ctx, SLX_ERR_INVALID_ARG, "z_out is NULL");
     kp.x = kp.y = kp.U = nullptr;
     kp.k = nullptr;
     kp.mask = nullptr;
     kp.z = kp.pix = kp.gray_out = nullptr;
+    bool aux = false;
     if (c.mode == SLX_MODE_PHASE_ONLY) kp.pix = primary;
     else if (c.mode == SLX_MODE_GRAY_ONLY) kp.gray_out = primary;
-    else kp.z = primary;
-    return launch(ctx, kp, n_sets, false, stream);
+    else {
+        kp.z = primary;
+        kp.x = out->x;
+        kp.y = out->y;
+        kp.U = out->U;
+        kp.mask = out->mask;
+        if (out->k) {
+            if (!(c.mode != SLX_MODE_GRAY_PHASE && c.n_freq > 1)) return fail(ctx, SLX_ERR_UNAVAILABLE, "this mode has no fringe orders (k)");
+            kp.k = out->k;
+        }
+        aux = out->x || out->y || out->U || out->mask || out->k;
+    }
+    if (!mode_has_depth(c.mode) && (out->x || out->y || out->U || out->mask || out->k))
+        return fail(ctx, SLX_ERR_UNAVAILABLE, "mode %d produces no depth-side outputs", c.mode);
+    return launch(ctx, kp, n_sets, aux, stream);
+}
+
+int slx_decode_batch(slx_ctx *ctx, int n_sets, const uint8_t *phase_base, size_t phase_set_stride,
+                     const uint8_t *gray_base, size_t gray_set_stride, size_t row_stride, double *z_out, void *stream)
+{
+    if (!ctx) return SLX_ERR_INVALID_ARG;
+    if (!z_out) return fail(ctx, SLX_ERR_INVALID_ARG, "z_out is NULL");
+    slx_batch_out out{};
+    out.z = z_out;
+    return slx_decode_batch_ex(ctx, n_sets, phase_base, phase_set_stride, gray_base, gray_set_stride, row_stride, &out, stream);
 }
 
 int slx_synchronize(slx_ctx *ctx)
 {
     if (!ctx) return SLX_ERR_INVALID_ARG;
     SLX_HIP(ctx, hipSetDevice(ctx->device));
+    if (int rc = wait_done_host(ctx)) return rc;          // the last launch, whichever stream it ran on
     SLX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return SLX_OK;
 }
@@ -507,7 +582,7 @@ int slx_get_output(slx_ctx *ctx, int which, void *dst, size_t dst_bytes, int mem
     if (dst_bytes < ctx->out_bytes[which]) return fail(ctx, SLX_ERR_INVALID_ARG, "destination holds %zu bytes, output needs %zu", dst_bytes, ctx->out_bytes[which]);
     if (mem_kind != SLX_MEM_HOST && mem_kind != SLX_MEM_DEVICE) return fail(ctx, SLX_ERR_INVALID_ARG, "unknown mem_kind %d", mem_kind);
     SLX_HIP(ctx, hipSetDevice(ctx->device));
-    SLX_HIP(ctx, hipDeviceSynchronize());   // the decode may have run on a caller stream
+    if (int rc = wait_done_host(ctx)) return rc;          // the producer of the outputs, on whichever stream it ran; nothing else is stalled
     SLX_HIP(ctx, hipMemcpy(dst, ctx->out[which], ctx->out_bytes[which],
                            mem_kind == SLX_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice));
     return SLX_OK;
@@ -527,7 +602,7 @@ int slx_get_point_cloud(slx_ctx *ctx, double *xyz, size_t capacity_points, size_
     if (!ctx->decoded) return fail(ctx, SLX_ERR_NOT_DECODED, "no decode has run yet");
     if (mem_kind != SLX_MEM_HOST && mem_kind != SLX_MEM_DEVICE) return fail(ctx, SLX_ERR_INVALID_ARG, "unknown mem_kind %d", mem_kind);
     SLX_HIP(ctx, hipSetDevice(ctx->device));
-    SLX_HIP(ctx, hipDeviceSynchronize());   // the decode may have run on a caller stream
+    if (int rc = order_after_done(ctx, ctx->stream)) return rc;   // the decode may have run on a caller stream: device-side wait only
     const int entries = slx_cloud_entries(c.width, c.height);
     const size_t w1 = (size_t)entries + 1;
     if (!ctx->d_cloud_counts) SLX_HIP(ctx, hipMalloc((void **)&ctx->d_cloud_counts, w1 * sizeof(unsigned)));
@@ -574,10 +649,14 @@ int slx_get_point_cloud(slx_ctx *ctx, double *xyz, size_t capacity_points, size_
     return SLX_OK;
 }
 
-// Camera image of a dynamic frame on the device: borrowed, or staged through the context's buffer.
-static int track_image(slx_ctx *ctx, const uint8_t *image, size_t stride, int mem_kind, const uint8_t **dev, size_t *dev_stride)
+// Camera image of a dynamic frame on the device: borrowed, or staged.  A host image is copied into one of two pinned
+// buffers (the caller's buffer is free again on return, like CSensor::GetCamPicture's deep copy, R/CSensorV.cpp:171-179)
+// and goes to the device on the copy stream; the context's stream waits for that copy on the device, not the host, so the
+// call returns while the previous frame's kernels are still running and frame n+1's copy-in overlaps them.
+static int track_image(slx_ctx *ctx, const uint8_t *image, size_t stride, int mem_kind, const uint8_t **dev, size_t *dev_stride, int *slot_out)
 {
     const slx_config &c = ctx->cfg;
+    *slot_out = -1;
     if (!image) return fail(ctx, SLX_ERR_INVALID_ARG, "image is NULL");
     if (stride < (size_t)c.width) return fail(ctx, SLX_ERR_INVALID_ARG, "stride %zu is smaller than the width %d", stride, c.width);
     if (mem_kind == SLX_MEM_DEVICE) {
@@ -586,11 +665,30 @@ static int track_image(slx_ctx *ctx, const uint8_t *image, size_t stride, int me
         return SLX_OK;
     }
     if (mem_kind != SLX_MEM_HOST) return fail(ctx, SLX_ERR_INVALID_ARG, "unknown mem_kind %d", mem_kind);
-    if (!ctx->d_track_img) SLX_HIP(ctx, hipMalloc((void **)&ctx->d_track_img, (size_t)c.width * c.height));
-    SLX_HIP(ctx, hipStreamSynchronize(ctx->stream));     // the previous frame may still be reading the staging buffer
-    SLX_HIP(ctx, hipMemcpy2D(ctx->d_track_img, (size_t)c.width, image, stride, (size_t)c.width, (size_t)c.height, hipMemcpyHostToDevice));
-    *dev = ctx->d_track_img;
+    const size_t bytes = (size_t)c.width * c.height;
+    if (!ctx->copy_stream) SLX_HIP(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+    const unsigned i = ctx->track_slot & 1u;
+    ctx->track_slot++;
+    if (!ctx->h_track_img[i]) {
+        SLX_HIP(ctx, hipHostMalloc((void **)&ctx->h_track_img[i], bytes, hipHostMallocDefault));
+        SLX_HIP(ctx, hipMalloc((void **)&ctx->d_track_img[i], bytes));
+        SLX_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_track_copied[i], hipEventDisableTiming));
+        SLX_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_track_used[i], hipEventDisableTiming));
+    }
+    if (ctx->track_slot_used[i]) {
+        // slot i was last used two frames ago: its kernels must have read the device copy (device-side wait on the copy
+        // stream), and its transfer must have left the pinned buffer before the host overwrites it
+        SLX_HIP(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->ev_track_used[i], 0));
+        SLX_HIP(ctx, hipEventSynchronize(ctx->ev_track_copied[i]));
+    }
+    for (int r = 0; r < c.height; r++) std::memcpy(ctx->h_track_img[i] + (size_t)r * c.width, image + (size_t)r * stride, (size_t)c.width);
+    SLX_HIP(ctx, hipMemcpyAsync(ctx->d_track_img[i], ctx->h_track_img[i], bytes, hipMemcpyHostToDevice, ctx->copy_stream));
+    SLX_HIP(ctx, hipEventRecord(ctx->ev_track_copied[i], ctx->copy_stream));
+    SLX_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_track_copied[i], 0));
+    ctx->track_slot_used[i] = true;
+    *dev = ctx->d_track_img[i];
     *dev_stride = (size_t)c.width;
+    *slot_out = (int)i;
     return SLX_OK;
 }
 
@@ -603,7 +701,7 @@ int slx_track_begin(slx_ctx *ctx, const uint8_t *image, size_t stride_bytes, int
     if (!ctx->decoded) return fail(ctx, SLX_ERR_NOT_DECODED, "decode frame 0 first");
     if (window < 3 || window > 201 || (window & 1) == 0) return fail(ctx, SLX_ERR_INVALID_ARG, "window must be odd and in [3,201] (got %d)", window);
     SLX_HIP(ctx, hipSetDevice(ctx->device));
-    SLX_HIP(ctx, hipDeviceSynchronize());                 // frame 0 may have been decoded on a caller stream
+    if (int rc0 = order_after_done(ctx, ctx->stream)) return rc0;   // frame 0 may have been decoded on a caller stream: device-side wait
     const size_t hw = (size_t)c.width * c.height;
     for (int w : {SLX_OUT_DELTAZ, SLX_OUT_DELTAP, SLX_OUT_STRIPW, SLX_OUT_STRIPB}) {
         if (ctx->out[w]) continue;
@@ -616,12 +714,14 @@ int slx_track_begin(slx_ctx *ctx, const uint8_t *image, size_t stride_bytes, int
     for (int w : {SLX_OUT_DELTAZ, SLX_OUT_DELTAP}) SLX_HIP(ctx, hipMemsetAsync(ctx->out[w], 0, ctx->out_bytes[w], ctx->stream));
     const uint8_t *img;
     size_t istride;
-    int rc = track_image(ctx, image, stride_bytes, mem_kind, &img, &istride);
+    int slot;
+    int rc = track_image(ctx, image, stride_bytes, mem_kind, &img, &istride, &slot);
     if (rc != SLX_OK) return rc;
     ctx->track_window = window;
     int e = slx_launch_strip_regression(img, istride, c.width, c.height, window, (float *)ctx->out[SLX_OUT_STRIPW], (float *)ctx->out[SLX_OUT_STRIPB], ctx->stream);
     if (e != 0) return hip_fail(ctx, (hipError_t)e, "strip regression");
-    return SLX_OK;
+    if (slot >= 0) SLX_HIP(ctx, hipEventRecord(ctx->ev_track_used[slot], ctx->stream));
+    return mark_done(ctx, ctx->stream);
 }
 
 int slx_track_next(slx_ctx *ctx, const uint8_t *image, size_t stride_bytes, int mem_kind)
@@ -630,9 +730,11 @@ int slx_track_next(slx_ctx *ctx, const uint8_t *image, size_t stride_bytes, int 
     const slx_config &c = ctx->cfg;
     if (ctx->track_window == 0) return fail(ctx, SLX_ERR_NOT_CONFIGURED, "slx_track_begin has not been called");
     SLX_HIP(ctx, hipSetDevice(ctx->device));
+    if (int rc0 = order_after_done(ctx, ctx->stream)) return rc0;
     const uint8_t *img;
     size_t istride;
-    int rc = track_image(ctx, image, stride_bytes, mem_kind, &img, &istride);
+    int slot;
+    int rc = track_image(ctx, image, stride_bytes, mem_kind, &img, &istride, &slot);
     if (rc != SLX_OK) return rc;
     // the strips of the previous frame move aside; the new ones start from 0 (R/CCalculation.cpp:827-828)
     float *curW = (float *)ctx->out[SLX_OUT_STRIPW], *curB = (float *)ctx->out[SLX_OUT_STRIPB];
@@ -648,7 +750,8 @@ int slx_track_next(slx_ctx *ctx, const uint8_t *image, size_t stride_bytes, int 
                                     (double *)ctx->out[SLX_OUT_Z], (double *)ctx->out[SLX_OUT_X], (double *)ctx->out[SLX_OUT_Y],
                                     (double *)ctx->out[SLX_OUT_DELTAZ], ctx->stream);
     if (e != 0) return hip_fail(ctx, (hipError_t)e, "dynamic-frame kernels");
-    return SLX_OK;
+    if (slot >= 0) SLX_HIP(ctx, hipEventRecord(ctx->ev_track_used[slot], ctx->stream));
+    return mark_done(ctx, ctx->stream);
 }
 
 // ---- frame ingest pipeline ---------------------------------------------------------
@@ -887,6 +990,14 @@ int slx_set_variant(slx_ctx *ctx, int variant)
     if (variant < 0 || variant >= slx_num_variants()) return fail(ctx, SLX_ERR_INVALID_ARG, "variant %d outside [0,%d)", variant, slx_num_variants());
     ctx->variant = variant;
     return SLX_OK;
+}
+
+int slx_internal_device(const slx_ctx *ctx) { return ctx->device; }
+void *slx_internal_stream(const slx_ctx *ctx) { return (void *)ctx->stream; }
+void slx_internal_tile(const slx_ctx *ctx, int *width, int *height)
+{
+    *width = ctx->cfg.width;
+    *height = ctx->cfg.height;
 }
 
 int slx_set_tuning(slx_ctx *ctx, int key, int value)

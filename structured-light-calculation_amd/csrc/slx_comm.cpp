@@ -1,0 +1,325 @@
+// slx_comm.cpp -- the one collective of the path: the gather of finished depth maps over RCCL / xGMI.
+//
+// The reference is a single process (no distributed backend); BASELINE.json's north_star spreads a
+// batch over the 8 GPUs of a node by row tile and gathers the depth maps at the end.  Every decode stage is
+// pixel-independent, so this file is the only place where ranks talk to each other.
+//
+// xGMI on MI355X is point to point (7 links per GPU): a gather to one root is bound by the root's 7 ingest links, and
+// a ring would be bound by ONE link.  So the gather is a single group of ncclSend / ncclRecv -- every peer sends straight
+// to the root at once, one message per (peer, frame-set) that lands at the tile's row offset inside that set of the
+// full [set][H][W] array.  No staging buffer, no transpose, no second pass over HBM.
+#include <hip/hip_runtime_api.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "slx.h"
+#include "slx_kernels.h"
+
+namespace {
+thread_local std::string g_comm_create_error;
+}
+
+struct slx_comm {
+    slx_ctx *ctx = nullptr;
+    ncclComm_t comm = nullptr;
+    bool owned = false;
+    int world = 0, rank = 0, device = 0;
+    hipStream_t stream = nullptr;            // the gather stream
+    std::vector<hipEvent_t> ev_chunk;        // decode of chunk i finished (recorded on the decode stream)
+    hipEvent_t ev_gathered = nullptr;        // everything queued on the gather stream so far has finished
+    bool gathered_pending = false;
+    std::string err;
+};
+
+namespace {
+
+int cfail(slx_comm *c, int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf;
+    else g_comm_create_error = buf;
+    return code;
+}
+
+#define SLXC_HIP(c, call)                                                                                   \
+    do {                                                                                                    \
+        hipError_t e_ = (call);                                                                             \
+        if (e_ != hipSuccess) return cfail(c, SLX_ERR_HIP, "%s: %s", #call, hipGetErrorString(e_));          \
+    } while (0)
+#define SLXC_NCCL(c, call)                                                                                  \
+    do {                                                                                                    \
+        ncclResult_t r_ = (call);                                                                           \
+        if (r_ != ncclSuccess) return cfail(c, SLX_ERR_HIP, "%s: %s", #call, ncclGetErrorString(r_));        \
+    } while (0)
+
+// The shard table must describe a partition every rank can act on without talking: the same frame width everywhere,
+// rows inside the frame, no rank beyond the communicator.
+int check_shards(slx_comm *c, const slx_shard *shards, int height, int width, int root)
+{
+    if (!shards) return cfail(c, SLX_ERR_INVALID_ARG, "shards is NULL");
+    if (height <= 0 || width <= 0) return cfail(c, SLX_ERR_INVALID_ARG, "height/width must be positive");
+    if (root < -1 || root >= c->world) return cfail(c, SLX_ERR_INVALID_ARG, "root %d outside [-1,%d)", root, c->world);
+    for (int r = 0; r < c->world; r++) {
+        const slx_shard &s = shards[r];
+        if (s.n_sets < 0 || s.set0 < 0 || s.rows < 0 || s.row0 < 0 || s.row0 + s.rows > height)
+            return cfail(c, SLX_ERR_INVALID_ARG, "shard %d (sets %d+%d, rows %d+%d) does not fit a %d-row frame", r, s.set0, s.n_sets, s.row0, s.rows, height);
+    }
+    return SLX_OK;
+}
+
+// One group of sends / receives for the frame-sets [first, first + count) of every rank's shard, counted within the shard
+// (chunk c of a pipelined gather = sets [c * chunk, (c+1) * chunk) of each shard).  `local` addresses this rank's shard as
+// documented at slx_gather_depth.
+int gather_range(slx_comm *c, const slx_shard *shards, int height, int width, int first, int count, const double *local,
+                 size_t local_plane_stride, double *full, int root, hipStream_t s)
+{
+    const int me = c->rank;
+    const bool i_receive = root < 0 || root == me;
+    const size_t W = (size_t)width, H = (size_t)height;
+    auto clip = [&](const slx_shard &sh, int &lo, int &n) {          // sets of the shard that fall into the range
+        lo = std::min(first, sh.n_sets);
+        n = std::min(first + count, sh.n_sets) - lo;
+    };
+    const slx_shard &mine = shards[me];
+    const size_t lstride = local_plane_stride ? local_plane_stride : (size_t)mine.rows * W;
+    int my_lo, my_n;
+    clip(mine, my_lo, my_n);
+    const bool in_place = i_receive && local == full + ((size_t)mine.set0 * H + (size_t)mine.row0) * W && lstride == H * W;
+    // whole-frame shards travel as ONE message per peer (the receiver posts one receive for the run of sets), so they must be dense
+    if ((size_t)mine.rows == H && lstride != H * W) return cfail(c, SLX_ERR_INVALID_ARG, "a whole-frame shard must be dense (plane stride %zu, frame %zu pixels)", lstride, H * W);
+
+    SLXC_NCCL(c, ncclGroupStart());
+    ncclResult_t r = ncclSuccess;
+    if (i_receive && full) {
+        for (int p = 0; p < c->world && r == ncclSuccess; p++) {
+            if (p == me) continue;
+            const slx_shard &sh = shards[p];
+            int lo, n;
+            clip(sh, lo, n);
+            if (n <= 0 || sh.rows == 0) continue;
+            if ((size_t)sh.rows == H) {                              // whole frames: the peer's sets are one contiguous run
+                r = ncclRecv(full + (size_t)(sh.set0 + lo) * H * W, (size_t)n * H * W, ncclDouble, p, c->comm, s);
+            } else {
+                for (int k = 0; k < n && r == ncclSuccess; k++)
+                    r = ncclRecv(full + ((size_t)(sh.set0 + lo + k) * H + (size_t)sh.row0) * W, (size_t)sh.rows * W, ncclDouble, p, c->comm, s);
+            }
+        }
+    }
+    if (r == ncclSuccess && my_n > 0 && mine.rows > 0 && local) {
+        for (int d = 0; d < c->world && r == ncclSuccess; d++) {
+            if (d == me || !(root < 0 || root == d)) continue;
+            if ((size_t)mine.rows == H) {
+                r = ncclSend(local + (size_t)my_lo * lstride, (size_t)my_n * H * W, ncclDouble, d, c->comm, s);
+            } else {
+                for (int k = 0; k < my_n && r == ncclSuccess; k++)
+                    r = ncclSend(local + (size_t)(my_lo + k) * lstride, (size_t)mine.rows * W, ncclDouble, d, c->comm, s);
+            }
+        }
+    }
+    const ncclResult_t rg = ncclGroupEnd();
+    if (r != ncclSuccess) return cfail(c, SLX_ERR_HIP, "ncclSend/ncclRecv: %s", ncclGetErrorString(r));
+    if (rg != ncclSuccess) return cfail(c, SLX_ERR_HIP, "ncclGroupEnd: %s", ncclGetErrorString(rg));
+    // this rank's own tile, when it was not decoded in place
+    if (i_receive && full && local && !in_place && my_n > 0 && mine.rows > 0) {
+        SLXC_HIP(c, hipMemcpy2DAsync(full + ((size_t)(mine.set0 + my_lo) * H + (size_t)mine.row0) * W, H * W * sizeof(double),
+                                     local + (size_t)my_lo * lstride, lstride * sizeof(double), (size_t)mine.rows * W * sizeof(double),
+                                     (size_t)my_n, hipMemcpyDeviceToDevice, s));
+    }
+    return SLX_OK;
+}
+
+int finish_create(slx_comm *c, slx_comm **out)
+{
+    SLXC_HIP(c, hipSetDevice(c->device));
+    SLXC_HIP(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    SLXC_HIP(c, hipEventCreateWithFlags(&c->ev_gathered, hipEventDisableTiming));
+    *out = c;
+    return SLX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int slx_comm_unique_id(void *id, size_t id_bytes)
+{
+    if (!id || id_bytes < SLX_COMM_ID_BYTES) return cfail(nullptr, SLX_ERR_INVALID_ARG, "id buffer must hold %d bytes", SLX_COMM_ID_BYTES);
+    static_assert(sizeof(ncclUniqueId) == SLX_COMM_ID_BYTES, "SLX_COMM_ID_BYTES must match ncclUniqueId");
+    ncclUniqueId u;
+    SLXC_NCCL(nullptr, ncclGetUniqueId(&u));
+    std::memcpy(id, &u, sizeof u);
+    return SLX_OK;
+}
+
+void slx_comm_destroy(slx_comm *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->owned && c->comm) (void)ncclCommDestroy(c->comm);
+    for (hipEvent_t e : c->ev_chunk)
+        if (e) (void)hipEventDestroy(e);
+    if (c->ev_gathered) (void)hipEventDestroy(c->ev_gathered);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int slx_comm_create(slx_ctx *ctx, const void *id, size_t id_bytes, int world, int rank, slx_comm **out)
+{
+    if (!out) return cfail(nullptr, SLX_ERR_INVALID_ARG, "out is NULL");
+    *out = nullptr;
+    if (!ctx || !id || id_bytes < SLX_COMM_ID_BYTES) return cfail(nullptr, SLX_ERR_INVALID_ARG, "ctx / id missing, or id shorter than %d bytes", SLX_COMM_ID_BYTES);
+    if (world < 1 || rank < 0 || rank >= world) return cfail(nullptr, SLX_ERR_INVALID_ARG, "bad rank %d of %d", rank, world);
+    slx_comm *c = new slx_comm;
+    c->ctx = ctx;
+    c->world = world;
+    c->rank = rank;
+    c->device = slx_internal_device(ctx);
+    c->owned = true;
+    auto bail = [&](int rc) {
+        g_comm_create_error = c->err;
+        slx_comm_destroy(c);
+        return rc;
+    };
+    if (hipSetDevice(c->device) != hipSuccess) return bail(cfail(c, SLX_ERR_HIP, "hipSetDevice(%d) failed", c->device));
+    ncclUniqueId u;
+    std::memcpy(&u, id, sizeof u);
+    ncclResult_t r = ncclCommInitRank(&c->comm, world, u, rank);
+    if (r != ncclSuccess) {
+        c->comm = nullptr;
+        return bail(cfail(c, SLX_ERR_HIP, "ncclCommInitRank(rank %d of %d, device %d): %s", rank, world, c->device, ncclGetErrorString(r)));
+    }
+    int rc = finish_create(c, out);
+    return rc == SLX_OK ? rc : bail(rc);
+}
+
+int slx_comm_adopt(slx_ctx *ctx, void *nccl_comm, slx_comm **out)
+{
+    if (!out) return cfail(nullptr, SLX_ERR_INVALID_ARG, "out is NULL");
+    *out = nullptr;
+    if (!ctx || !nccl_comm) return cfail(nullptr, SLX_ERR_INVALID_ARG, "ctx / communicator is NULL");
+    slx_comm *c = new slx_comm;
+    c->ctx = ctx;
+    c->comm = (ncclComm_t)nccl_comm;
+    c->owned = false;
+    c->device = slx_internal_device(ctx);
+    auto bail = [&](int rc) {
+        g_comm_create_error = c->err;
+        slx_comm_destroy(c);
+        return rc;
+    };
+    int dev = -1;
+    if (ncclCommCount(c->comm, &c->world) != ncclSuccess || ncclCommUserRank(c->comm, &c->rank) != ncclSuccess || ncclCommCuDevice(c->comm, &dev) != ncclSuccess)
+        return bail(cfail(c, SLX_ERR_INVALID_ARG, "not a usable ncclComm_t"));
+    if (dev != c->device) return bail(cfail(c, SLX_ERR_INVALID_ARG, "the communicator lives on device %d, the context on device %d", dev, c->device));
+    int rc = finish_create(c, out);
+    return rc == SLX_OK ? rc : bail(rc);
+}
+
+int slx_comm_info(const slx_comm *c, int *world, int *rank)
+{
+    if (!c) return SLX_ERR_INVALID_ARG;
+    if (world) *world = c->world;
+    if (rank) *rank = c->rank;
+    return SLX_OK;
+}
+
+const char *slx_comm_last_error(const slx_comm *c) { return c ? c->err.c_str() : g_comm_create_error.c_str(); }
+
+int slx_comm_synchronize(slx_comm *c)
+{
+    if (!c) return SLX_ERR_INVALID_ARG;
+    SLXC_HIP(c, hipSetDevice(c->device));
+    SLXC_HIP(c, hipStreamSynchronize(c->stream));
+    return SLX_OK;
+}
+
+int slx_gather_depth(slx_comm *c, const slx_shard *shards, int height, int width, const double *local, size_t local_plane_stride,
+                     double *full, int root, void *stream)
+{
+    if (!c) return SLX_ERR_INVALID_ARG;
+    int rc = check_shards(c, shards, height, width, root);
+    if (rc != SLX_OK) return rc;
+    const bool i_receive = root < 0 || root == c->rank;
+    if (i_receive && !full) return cfail(c, SLX_ERR_INVALID_ARG, "full is NULL on a destination rank");
+    if (!local && shards[c->rank].n_sets > 0 && shards[c->rank].rows > 0) return cfail(c, SLX_ERR_INVALID_ARG, "local is NULL but this rank holds a shard");
+    SLXC_HIP(c, hipSetDevice(c->device));
+    int most = 0;
+    for (int r = 0; r < c->world; r++) most = std::max(most, shards[r].n_sets);
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    rc = gather_range(c, shards, height, width, 0, most, local, local_plane_stride, full, root, s);
+    if (rc != SLX_OK) return rc;
+    if (s == c->stream) {
+        SLXC_HIP(c, hipEventRecord(c->ev_gathered, c->stream));
+        c->gathered_pending = true;
+    }
+    return SLX_OK;
+}
+
+int slx_decode_gather(slx_comm *c, slx_ctx *ctx, const slx_shard *shards, int full_height, int chunk_sets, const uint8_t *phase_base,
+                      size_t phase_set_stride, const uint8_t *gray_base, size_t gray_set_stride, size_t row_stride, double *scratch,
+                      double *full, int root, void *stream)
+{
+    if (!c || !ctx) return SLX_ERR_INVALID_ARG;
+    if (ctx != c->ctx) return cfail(c, SLX_ERR_INVALID_ARG, "the communicator was created for another context");
+    if (chunk_sets < 1) return cfail(c, SLX_ERR_INVALID_ARG, "chunk_sets must be positive (got %d)", chunk_sets);
+    int width = 0, tile_rows = 0;
+    slx_internal_tile(ctx, &width, &tile_rows);
+    int rc = check_shards(c, shards, full_height, width, root);
+    if (rc != SLX_OK) return rc;
+    const slx_shard &mine = shards[c->rank];
+    if (mine.rows != tile_rows) return cfail(c, SLX_ERR_INVALID_ARG, "this rank's shard has %d rows, its context decodes %d", mine.rows, tile_rows);
+    const bool i_receive = root < 0 || root == c->rank;
+    if (i_receive && !full) return cfail(c, SLX_ERR_INVALID_ARG, "full is NULL on a destination rank");
+    if (!i_receive && !scratch && mine.n_sets > 0) return cfail(c, SLX_ERR_INVALID_ARG, "scratch is NULL on a rank that does not receive");
+    SLXC_HIP(c, hipSetDevice(c->device));
+    hipStream_t ds = stream ? (hipStream_t)stream : (hipStream_t)slx_internal_stream(ctx);
+
+    const size_t W = (size_t)width, H = (size_t)full_height;
+    // where this rank decodes: in place on a destination rank, else the scratch tile stack
+    double *local = i_receive ? full + ((size_t)mine.set0 * H + (size_t)mine.row0) * W : scratch;
+    const size_t lstride = i_receive ? H * W : (size_t)mine.rows * W;
+
+    int most = 0;
+    for (int r = 0; r < c->world; r++) most = std::max(most, shards[r].n_sets);
+    const int n_chunks = (most + chunk_sets - 1) / chunk_sets;
+    while ((int)c->ev_chunk.size() < n_chunks) {
+        hipEvent_t e;
+        SLXC_HIP(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        c->ev_chunk.push_back(e);
+    }
+    // the previous gather may still be sending from / receiving into the buffers this decode is about to overwrite
+    if (c->gathered_pending) SLXC_HIP(c, hipStreamWaitEvent(ds, c->ev_gathered, 0));
+    for (int k = 0; k < n_chunks; k++) {
+        const int first = k * chunk_sets;
+        const int n = std::min(first + chunk_sets, mine.n_sets) - std::min(first, mine.n_sets);
+        if (n > 0) {
+            slx_batch_out out{};
+            out.z = local + (size_t)first * lstride;
+            out.plane_stride = lstride;
+            rc = slx_decode_batch_ex(ctx, n, phase_base ? phase_base + (size_t)first * phase_set_stride : nullptr, phase_set_stride,
+                                     gray_base ? gray_base + (size_t)first * gray_set_stride : nullptr, gray_set_stride, row_stride, &out, ds);
+            if (rc != SLX_OK) return cfail(c, rc, "decode of chunk %d: %s", k, slx_last_error(ctx));
+        }
+        SLXC_HIP(c, hipEventRecord(c->ev_chunk[(size_t)k], ds));
+        SLXC_HIP(c, hipStreamWaitEvent(c->stream, c->ev_chunk[(size_t)k], 0));
+        // chunk k travels on the gather stream while chunk k+1 decodes on ds
+        rc = gather_range(c, shards, full_height, width, first, chunk_sets, local, lstride, full, root, c->stream);
+        if (rc != SLX_OK) return rc;
+    }
+    SLXC_HIP(c, hipEventRecord(c->ev_gathered, c->stream));
+    c->gathered_pending = true;
+    return SLX_OK;
+}
+
+}  // extern "C"

@@ -106,6 +106,11 @@ struct SlxTuning {
 // Returns 0, or a hipError_t value.  `variant` selects a kernel variant, `tune` (may be null) the item geometry.
 int slx_launch_fused(const SlxKParams &kp, int mode, bool aux, int n_sets, int variant, void *stream, const SlxTuning *tune = nullptr);
 
+// For the other translation units of the library (slx_comm.cpp): the context's device and its own stream.
+extern "C" int slx_internal_device(const slx_ctx *ctx);
+extern "C" void *slx_internal_stream(const slx_ctx *ctx);
+extern "C" void slx_internal_tile(const slx_ctx *ctx, int *width, int *height);
+
 // Number of distinct variants slx_launch_fused understands.
 int slx_num_variants(void);
 

@@ -67,3 +67,78 @@ def gather_depth(local, dst=0, group=None, all_ranks=False):
     if not all_ranks and rank != dst:
         return None
     return torch.cat([g[:c] for g, c in zip(gathered, counts)], dim=0)
+
+
+# ---- the shard table and the reassembling gather ---------------------------------------------------------------------
+# A shard = (set0, n_sets, row0, rows): the rows [row0, row0+rows) of the frame-sets [set0, set0+n_sets) of a batch whose
+# full result is [total_sets][height][width].  The same table drives the native RCCL gather (slx_gather_depth /
+# slx_decode_gather in include/slx.h, api.Comm) and the torch.distributed one below, which exists for CPU (gloo) tests and
+# one-GPU rehearsals: same messages -- one per (peer, frame-set), or one per peer for whole-frame shards -- same result.
+
+def shards_by_frameset(total_sets, world, height):
+    out = []
+    for r in range(world):
+        lo, hi = split_range(total_sets, world, r)
+        out.append((lo, hi - lo, 0, height))
+    return out
+
+
+def shards_by_rows(total_sets, world, height):
+    out = []
+    for r in range(world):
+        lo, hi = split_range(height, world, r)
+        out.append((0, total_sets, lo, hi - lo))
+    return out
+
+
+def total_sets(shards):
+    return max((s0 + n for s0, n, _, _ in shards), default=0)
+
+
+def gather_shards(local, shards, height, width, dst=0, group=None):
+    """local: this rank's shard, [n_sets, rows, width] (contiguous).  Returns the reassembled [total_sets, height, width]
+    tensor on rank `dst` (None elsewhere), or on every rank when dst is None.  Row tiles land at their row offset of every
+    frame-set; ragged tile heights and ragged set counts are fine."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    assert len(shards) == world
+    set0, n, row0, rows = shards[rank]
+    assert tuple(local.shape) == (n, rows, width), (tuple(local.shape), shards[rank], width)
+    local = local.contiguous()
+    receives = dst is None or dst == rank
+    full = None
+    ops = []
+    if receives:
+        full = torch.zeros((total_sets(shards), height, width), dtype=local.dtype, device=local.device)
+        full[set0:set0 + n, row0:row0 + rows] = local
+        for p, (ps0, pn, pr0, prows) in enumerate(shards):
+            if p == rank or pn == 0 or prows == 0:
+                continue
+            if prows == height:
+                ops.append(dist.P2POp(dist.irecv, full[ps0:ps0 + pn], p, group))                 # contiguous run of whole frames
+            else:
+                for k in range(pn):
+                    ops.append(dist.P2POp(dist.irecv, full[ps0 + k, pr0:pr0 + prows], p, group))  # contiguous: rows of one set
+    if n and rows:
+        for d in range(world):
+            if d == rank or not (dst is None or dst == d):
+                continue
+            if rows == height:
+                ops.append(dist.P2POp(dist.isend, local, d, group))
+            else:
+                for k in range(n):
+                    ops.append(dist.P2POp(dist.isend, local[k], d, group))
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+    return full
+
+
+def gather_rows(local, heights, dst=0, group=None):
+    """Row-tile gather: local [n_sets, h_rank, W]; heights = tile height of every rank -> [n_sets, sum(heights), W]."""
+    n_sets, _, width = local.shape
+    shards, row0 = [], 0
+    for h in heights:
+        shards.append((0, n_sets, row0, h))
+        row0 += h
+    return gather_shards(local, shards, row0, width, dst=dst, group=group)

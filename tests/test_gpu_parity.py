@@ -800,3 +800,143 @@ def test_cpp_data_directory(tmp_path, oracle, synth, golden_dir):
         pts = oracle.point_cloud(spec, oracle.triangulate(spec, U)["z"])
         assert open(os.path.join(d, "PointCloud", "cFrame%d.txt" % f)).read() == "".join("%g %g %g\n" % tuple(p) for p in pts), f
         sw0, sb0 = sw1, sb1
+
+
+# ------------------------------------------------------------------ round 2: batch outputs in place, native gather, stream order
+def test_decode_batch_ex_writes_row_tiles_into_a_full_height_map(api, oracle, synth, shard, torch_cuda):
+    """slx_decode_batch_ex with a plane stride: every rank's row tile decoded straight into its rows of [set][H][W] (what the
+    gather delivers), here all "ranks" in one process; ragged tile heights; depth plus the optional planes."""
+    torch = torch_cuda
+    spec = small_spec(synth, "C2", 128, 50)
+    n_sets, H, W = 3, spec["height"], spec["width"]
+    sets = [synth.random_planes(spec, seed=300 + s)[0] for s in range(n_sets)]
+    ref = [oracle.pipeline(spec, p, None, want=("z", "x", "y", "U", "k", "mask")) for p in sets]
+    full = {n: torch.full((n_sets, H, W), -7.0, dtype=torch.float64, device="cuda") for n in ("z", "x", "y", "U")}
+    kfull = torch.full((n_sets, 2, H, W), -7, dtype=torch.int32, device="cuda")
+    mfull = torch.full((n_sets, H, W), 9, dtype=torch.uint8, device="cuda")
+    world = 3
+    for rank in range(world):
+        tile, lo, hi = shard.row_tile_spec(spec, world, rank)
+        ph = torch.from_numpy(np.stack([p[:, lo:hi] for p in sets])).cuda()
+        torch.cuda.synchronize()
+        with api.Context(tile) as ctx:
+            ctx.decode_batch_ex(n_sets, ph, None, z=full["z"][0, lo:], x=full["x"][0, lo:], y=full["y"][0, lo:], U=full["U"][0, lo:],
+                                k=kfull[0, 0, lo:], mask=mfull[0, lo:], plane_stride=H * W)
+            ctx.synchronize()
+    for s in range(n_sets):
+        for n in ("z", "x", "y", "U"):
+            assert np.array_equal(full[n][s].cpu().numpy(), ref[s][n], equal_nan=True), (s, n)
+        assert np.array_equal(kfull[s].cpu().numpy(), ref[s]["k"]), s
+        assert np.array_equal(mfull[s].cpu().numpy(), ref[s]["mask"]), s
+
+
+@pytest.mark.parametrize("split", ["framesets", "rows"])
+@pytest.mark.parametrize("root", [0, -1])
+def test_native_gather_world_of_one(api, oracle, synth, shard, torch_cuda, split, root):
+    """slx_comm_* / slx_gather_depth / slx_decode_gather on RCCL with the one rank this box has: communicator creation from a
+    unique id, the in-place path, the copy path for a separate local buffer, chunking with a ragged last chunk.  (N > 1 message
+    patterns: tests/test_shard_gloo.py runs the same shard tables through torch.distributed.)"""
+    torch = torch_cuda
+    spec = small_spec(synth, "C4", 128, 40)
+    n_sets, H, W = 5, spec["height"], spec["width"]
+    sets = [synth.random_planes(spec, seed=400 + s)[0] for s in range(n_sets)]
+    want = np.stack([oracle.pipeline(spec, p, None, want=("z",))["z"] for p in sets])
+    table = (shard.shards_by_frameset if split == "framesets" else shard.shards_by_rows)(n_sets, 1, H)
+    phase = torch.from_numpy(np.stack(sets)).cuda()
+    torch.cuda.synchronize()
+    with api.Context(spec) as ctx:
+        comm = api.Comm(ctx, api.comm_unique_id(), 1, 0)
+        assert (comm.world, comm.rank) == (1, 0)
+        full = torch.full((n_sets, H, W), -1.0, dtype=torch.float64, device="cuda")
+        torch.cuda.synchronize()
+        comm.decode_gather(table, H, 2, phase, None, None, full, root=root)        # chunks of 2, 2, 1 frame-sets
+        comm.synchronize()
+        assert np.array_equal(full.cpu().numpy(), want, equal_nan=True)
+        # a separate local buffer: the gather copies this rank's own shard into place
+        local = torch.empty((n_sets, H, W), dtype=torch.float64, device="cuda")
+        full.fill_(-1.0)
+        torch.cuda.synchronize()
+        ctx.decode_batch(n_sets, phase, None, local)
+        ctx.synchronize()
+        comm.gather_depth(table, H, W, local, full, root=root)
+        comm.synchronize()
+        assert np.array_equal(full.cpu().numpy(), want, equal_nan=True)
+        with pytest.raises(api.SlxError):
+            comm.gather_depth([(0, n_sets, 0, H + 1)], H, W, local, full)          # a shard taller than the frame
+        comm.close()
+
+
+def test_host_frames_can_be_replaced_right_after_decode(api, oracle, synth):
+    """slx_decode is asynchronous; slx_set_frame(SLX_MEM_HOST) rewrites the staging buffers the decode reads.  The library
+    orders the two (it waits for the event of the last launch), so decode(); set_frame(next) keeps the first result intact."""
+    spec = synth.make_spec("C3")                                       # 24 planes of 1920 x 1200: the decode takes a while
+    a = synth.random_planes(spec, seed=1)
+    b = synth.random_planes(spec, seed=2)
+    ra = oracle.pipeline(spec, a[0], a[1], want=("z",), threads=8)["z"]
+    rb = oracle.pipeline(spec, b[0], b[1], want=("z",), threads=8)["z"]
+    with api.Context(spec) as ctx:
+        ctx.set_frames(*a)
+        for _ in range(3):
+            ctx.decode()
+            ctx.set_frames(*b)                                         # at once, no synchronize in between
+            za = ctx.get_depth()
+            ctx.decode()
+            ctx.set_frames(*a)
+            zb = ctx.get_depth()
+            assert np.array_equal(za, ra, equal_nan=True) and np.array_equal(zb, rb, equal_nan=True)
+
+
+def test_pipe_and_a_second_context_run_concurrently(api, oracle, synth, torch_cuda):
+    """Waiting for one context's result must not depend on, or disturb, other work on the device: an ingest pipe keeps its slots
+    full while a second context decodes on a caller stream and reads its outputs back; both stay bit-equal to the oracle."""
+    torch = torch_cuda
+    spec = small_spec(synth, "C2", 256, 120)
+    sets = [synth.random_planes(spec, seed=500 + i)[0] for i in range(8)]
+    want = [oracle.pipeline(spec, p, None, want=("z",))["z"] for p in sets]
+    other_spec = small_spec(synth, "C1x4", 320, 100)
+    oph, ogr = synth.random_planes(other_spec, seed=77)
+    owant = oracle.pipeline(other_spec, oph, ogr, want=("z", "U"))
+    s = torch.cuda.Stream()
+    with api.Context(spec) as pctx, api.Context(other_spec, aux=("U",)) as octx:
+        pipe = api.Pipe(pctx, slots=3, sets_per_slot=1)
+        octx.set_frames(torch.from_numpy(oph).cuda(), torch.from_numpy(ogr).cuda())
+        torch.cuda.synchronize()
+        got, in_flight = [], 0
+        for i, p in enumerate(sets):
+            if in_flight == 3:
+                got.append(np.array(pipe.collect()[0]))
+                in_flight -= 1
+            buf = pipe.acquire()
+            buf[0, :, :, :spec["width"]] = p
+            pipe.submit(1)
+            in_flight += 1
+            octx.decode(stream=s.cuda_stream)                          # on a caller stream, between the pipe's submissions
+            for w in ("z", "U"):
+                assert np.array_equal(octx.get_output(w), owant[w], equal_nan=True), (i, w)
+        while in_flight:
+            got.append(np.array(pipe.collect()[0]))
+            in_flight -= 1
+        pipe.close()
+    for i in range(8):
+        assert np.array_equal(got[i], want[i], equal_nan=True), i
+
+
+def test_bench_two_ranks_rehearsed_on_one_gpu():
+    """`python bench.py --gpus 2` as typed: the parent starts the ranks.  With one GPU on the box the ranks share it and talk
+    over gloo (--rehearse-on-one-gpu); the line must be valid and carry both gather splits, checked against the local decodes."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearse-on-one-gpu", "--steps", "20", "--warmup", "5",
+                        "--sets-per-gpu", "4"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["rccl_world_size"] == 2 and d["value"] > 0 and d["roofline"]["frac"] > 0
+    for split in ("framesets", "rows"):
+        g = d["with_gather"][split]
+        assert "error" not in g, g
+        assert g["gathered_equals_local_decodes"] is True and g["gathered_shape"] == [8, 1200, 1920]
+        assert g["kernel_only"]["value"] > 0 and g["end_to_end"]["value"] > 0

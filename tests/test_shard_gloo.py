@@ -25,8 +25,8 @@ def _free_port():
 
 def _small_spec(synth):
     spec = dict(synth.make_spec("C2"))
-    spec["width"], spec["height"] = 48, 30
-    spec["calib"] = synth.scaled_calibration(48, 30, spec["proj_width"])
+    spec["width"], spec["height"] = 48, 31          # 31 rows: no world size of the tests divides it
+    spec["calib"] = synth.scaled_calibration(48, 31, spec["proj_width"])
     return spec
 
 
@@ -49,19 +49,29 @@ def _worker(rank, world, port, n_sets, by, outdir):
                 np.save(os.path.join(outdir, "frameset.npy"), full.numpy())
             everyone = shard.gather_depth(local, all_ranks=True)
             assert everyone.shape[0] == n_sets
+            # the shard-table gather (same messages as the native RCCL one) delivers the same array, on every rank too
+            table = shard.shards_by_frameset(n_sets, world, spec["height"])
+            again = shard.gather_shards(local, table, spec["height"], spec["width"], dst=None)
+            assert torch.equal(again, everyone)
         else:
             tile, lo, hi = shard.row_tile_spec(spec, world, rank)
             local = np.stack([O.pipeline(tile, sets[s][:, lo:hi], None, want=("z",))["z"] for s in range(n_sets)])
-            # gather along rows: move the row axis first
-            t = torch.from_numpy(np.ascontiguousarray(local.transpose(1, 0, 2)))
-            full = shard.gather_depth(t, dst=0)
+            # the library call as the bench uses it: [n_sets, rows of this rank, W] in, [n_sets, H, W] out, no reshuffling here
+            heights = [shard.split_range(spec["height"], world, r)[1] - shard.split_range(spec["height"], world, r)[0] for r in range(world)]
+            full = shard.gather_rows(torch.from_numpy(local), heights, dst=0)
+            assert (full is None) == (rank != 0)
             if rank == 0:
-                np.save(os.path.join(outdir, "rows.npy"), full.numpy().transpose(1, 0, 2))
+                np.save(os.path.join(outdir, "rows.npy"), full.numpy())
+            last = world - 1
+            full_last = shard.gather_shards(torch.from_numpy(local), shard.shards_by_rows(n_sets, world, spec["height"]), spec["height"],
+                                            spec["width"], dst=last)
+            if rank == last:
+                np.save(os.path.join(outdir, "rows_last.npy"), full_last.numpy())
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n_sets,by", [(2, 4, "frameset"), (2, 3, "frameset"), (3, 4, "rows"), (2, 2, "rows")])
+@pytest.mark.parametrize("world,n_sets,by", [(2, 4, "frameset"), (2, 3, "frameset"), (3, 4, "rows"), (2, 2, "rows"), (4, 3, "rows"), (3, 2, "frameset")])
 def test_sharded_decode_and_gather(tmp_path, world, n_sets, by):
     import oracle as O
     synth = pkg("synth")
@@ -72,3 +82,5 @@ def test_sharded_decode_and_gather(tmp_path, world, n_sets, by):
     got = np.load(os.path.join(str(tmp_path), "frameset.npy" if by == "frameset" else "rows.npy"))
     assert got.shape == want.shape
     assert np.array_equal(got, want, equal_nan=True)
+    if by == "rows":
+        assert np.array_equal(np.load(os.path.join(str(tmp_path), "rows_last.npy")), want, equal_nan=True)
