@@ -217,13 +217,14 @@ int slx_set_variant(slx_ctx *ctx, int variant);
  * result.  This entry is the ONLY way to set them: the library does not read the process environment. */
 enum slx_tuning_key {
     SLX_TUNE_STRIP_ROWS = 0,   /* rows per work item, 1..32                                             */
-    SLX_TUNE_TAIL_PCT = 1,     /* percent of every frame-set's rows cut into short items, 1..99; -1 none */
-    SLX_TUNE_TAIL_ROWS = 2,    /* rows per short item, 1..32                                            */
+    SLX_TUNE_TAIL_PCT = 1,     /* percent of every frame-set's rows cut into shorter items, 1..99; -1 none */
+    SLX_TUNE_TAIL_ROWS = 2,    /* rows per item of the second tier, 1..32 (later tiers quarter it)       */
     SLX_TUNE_GRAY_PLAIN = 3,   /* 1: Gray planes by ordinary loads instead of the LDS-DMA ring          */
     SLX_TUNE_STRIP_WAVES = 4,  /* waves per workgroup, 1..4                                             */
     SLX_TUNE_LDS_PAD_KIB = 5,  /* extra LDS per workgroup in KiB (lowers the occupancy), 1..128         */
     SLX_TUNE_PLAIN_ORDER = 6,  /* 1: Gray-mask work items in plain order instead of XCD-grouped         */
-    SLX_TUNE_COUNT = 7
+    SLX_TUNE_TIERS = 7,        /* tiers of ever shorter work items towards the end of a launch, 1..4    */
+    SLX_TUNE_COUNT = 8
 };
 int slx_set_tuning(slx_ctx *ctx, int key, int value);
 

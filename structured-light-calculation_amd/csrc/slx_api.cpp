@@ -1006,7 +1006,7 @@ int slx_set_tuning(slx_ctx *ctx, int key, int value)
     struct Range { int *field; int lo, hi; };
     SlxTuning &t = ctx->tune;
     const Range r[SLX_TUNE_COUNT] = {{&t.strip_rows, 0, 32}, {&t.tail_pct, -1, 99}, {&t.tail_rows, 0, 32}, {&t.gray_plain, 0, 1},
-                                     {&t.strip_waves, 0, 4}, {&t.lds_pad_kib, 0, 128}, {&t.plain_order, 0, 1}};
+                                     {&t.strip_waves, 0, 4}, {&t.lds_pad_kib, 0, 128}, {&t.plain_order, 0, 1}, {&t.tiers, 0, SLX_MAX_TIERS}};
     if (key < 0 || key >= SLX_TUNE_COUNT) return fail(ctx, SLX_ERR_INVALID_ARG, "unknown tuning key %d", key);
     if (value < r[key].lo || value > r[key].hi) return fail(ctx, SLX_ERR_INVALID_ARG, "tuning key %d takes values in [%d,%d] (got %d)", key, r[key].lo, r[key].hi, value);
     *r[key].field = value;

@@ -12,6 +12,7 @@
 
 // Pixels one lane owns per step: one dword of every 8-bit input plane.
 #define SLX_QUAD 4
+#define SLX_MAX_TIERS 4
 
 struct SlxKParams {
     // inputs: plane p of frame-set s starts at plane[p] + s * set_stride
@@ -46,12 +47,16 @@ struct SlxKParams {
     int std_gray;                               // lut is the reflected Gray code: bin = prefix-xor(gray)
     unsigned interleave;                        // rows laid end to end so that their quads fill whole waves: 64 / gcd(quads_per_row, 64)
     unsigned chunks_per_group;                  // interleave * quads_per_row / 64 (64-quad chunks of a row group)
-    unsigned rows_per_lane;                     // rows one lane walks per work item (even)
-    unsigned items_per_set;                     // ceil(H / (interleave * rows_per_lane)) * chunks_per_group
-    unsigned long long total_items;             // all items of the launch
-    unsigned long long items_head;              // items [0, items_head) are the long ones: items_per_set per frame-set, rows_per_lane rows each
-    unsigned rows_per_lane_tail;                // items [items_head, total_items): the rows from tail_row0 on, in items of this many rows
-    unsigned items_per_set_tail, tail_row0;
+    // Work items come in up to SLX_MAX_TIERS tiers, dispatched one after the other: tier t covers the rows from tier_row0[t]
+    // up to the next tier's first row of EVERY frame-set, in items of tier_rows[t] rows per lane.  Long items first (they
+    // amortise the item start-up), ever shorter ones towards the end of the launch, where the chip drains for about one
+    // item's lifetime.  A tier starts on a workgroup boundary: workgroups [tier_first_wg[t], tier_first_wg[t] + tier_wgs[t]).
+    unsigned n_tiers;
+    unsigned tier_rows[SLX_MAX_TIERS];          // rows one lane walks per work item
+    unsigned tier_row0[SLX_MAX_TIERS];          // first image row of the tier
+    unsigned tier_items_per_set[SLX_MAX_TIERS]; // row groups of the tier * chunks_per_group
+    unsigned tier_items[SLX_MAX_TIERS];         // tier_items_per_set * frame-sets of the launch
+    unsigned tier_first_wg[SLX_MAX_TIERS], tier_wgs[SLX_MAX_TIERS];
     int fast_arith;                             // generic kernel: use the bit-identical cheap unwrap / in-range division (host-checked)
     int plain_order;                            // Gray-mask strip kernel: items in plain order instead of XCD-grouped (slx_set_tuning, A/B only)
     unsigned long long *stamps;                 // diagnostics: 4 words per work item (s_memtime / s_memrealtime at start, end) or null
@@ -94,8 +99,9 @@ bool slx_strip_eligible(const SlxKParams &kp, int mode, bool aux);
 // work is cut into items, never a result; the process environment is not consulted anywhere.
 struct SlxTuning {
     int strip_rows;      // rows per work item, 1..32
-    int tail_pct;        // share of every frame-set's rows that goes into short items, 1..99 (-1: none)
-    int tail_rows;       // rows per short item
+    int tail_pct;        // share of every frame-set's rows that goes into the shorter tiers, 1..99 (-1: none, one tier)
+    int tail_rows;       // rows per item of the second tier (the following tiers quarter it again)
+    int tiers;           // number of tiers, 1..SLX_MAX_TIERS
     int gray_plain;      // 1: Gray planes by ordinary loads instead of the DMA ring
     int strip_waves;     // waves per workgroup, 1..4
     int lds_pad_kib;     // extra LDS per workgroup (lowers the occupancy), 0..128

@@ -570,6 +570,38 @@ __device__ __forceinline__ V pix_tail_inrange(V y, V x, float Tf)
     return pix_from_octant_angle(a, v_mul_sat(x, -0x1p60f), v_mul_sat(y, -0x1p60f), Tf);
 }
 
+// a3 for the four pixels of a quad at once (R/CDecodeGray.cpp:150-176: bit = pattern > inverse, ties -> 0), on the dwords
+// of a plane pair, with 2-cycle integer operations instead of a compare + select per pixel:
+//   t = (y | 0x80..) - (x & 0x7f..)   per byte 0x80 + ylow - xlow, never a borrow between bytes: bit 7 = (ylow >= xlow)
+//   e = x ^ y                         bit 7 set: the top bits differ, and the byte whose top bit is set is the larger
+//   bit 7 of (e ? y : t) = (y >= x) = NOT (x > y)
+// The caller collects NOT(bit) and inverts once.
+__device__ __forceinline__ uint32_t swar_ge_u8_bit7(uint32_t y, uint32_t x)
+{
+    const uint32_t t = (y | 0x80808080u) - (x & 0x7f7f7f7fu);
+    const uint32_t e = x ^ y;
+    return (e & y) | (~e & t);                                       // v_bfi_b32
+}
+// One more bit plane into the running code of four pixels: the new bit enters at bit 7 of each byte and the older ones move
+// down, so after G <= 8 planes, taken LSB first, bit b sits at position 8 - G + b and nothing ever crossed a byte boundary.
+__device__ __forceinline__ uint32_t swar_push_bit7(uint32_t acc, uint32_t bit7)
+{
+    return (acc >> 1) | (bit7 & 0x80808080u);                        // v_lshrrev + v_and_or
+}
+// The four G-bit codes (one per byte) from the collected NOT-bits.
+__device__ __forceinline__ uint32_t swar_finish_code(uint32_t acc_not, int G)
+{
+    return ~(acc_not >> (8 - G)) & (0x01010101u * ((1u << G) - 1u));
+}
+// Inverse reflected Gray code of four codes of at most 8 bits, one per byte: prefix xor inside every byte.
+__device__ __forceinline__ uint32_t swar_gray_to_binary_u8(uint32_t g)
+{
+    g ^= (g >> 1) & 0x7f7f7f7fu;
+    g ^= (g >> 2) & 0x3f3f3f3fu;
+    g ^= (g >> 4) & 0x0f0f0f0fu;
+    return g;
+}
+
 // ------------------------------------------------------------------------------------------
 // Fast path: waves walking column strips, fringe stack staged through LDS.
 //
@@ -666,24 +698,29 @@ __global__ __launch_bounds__(256) void slx_strip_kernel(const SlxKParams p)
     // and start at 248-byte multiples, and their shared 128-byte lines are then fetched from HBM once, not twice.
     // Placement only affects speed; any dispatch order gives the same result.
     // The other modes have no reuse and run in plain order, which is what lets the LAST items be the small ones (below).
+    // Tiers of items (SlxKParams): which tier this workgroup belongs to, then its place inside the tier.
     unsigned wg = blockIdx.x;
+    unsigned RB = p.tier_rows[0], items_per_set = p.tier_items_per_set[0], region_row0 = 0, tier_items = p.tier_items[0], tier_wgs = p.tier_wgs[0];
+    unsigned item_base = 0;
+#pragma unroll
+    for (int t = 1; t < SLX_MAX_TIERS; t++) {
+        if (t < (int)p.n_tiers && blockIdx.x >= p.tier_first_wg[t]) {
+            wg = blockIdx.x - p.tier_first_wg[t];
+            RB = p.tier_rows[t];
+            items_per_set = p.tier_items_per_set[t];
+            region_row0 = p.tier_row0[t];
+            tier_items = p.tier_items[t];
+            tier_wgs = p.tier_wgs[t];
+            item_base = p.tier_first_wg[t] * (blockDim.x >> 6);
+        }
+    }
     if (MASKED && !p.plain_order) {                                 // plain order: A/B measurements only (slx_set_tuning)
-        const unsigned nb = gridDim.x, q = nb >> 3, r = nb & 7u, x = wg & 7u, within = wg >> 3;
+        const unsigned nb = tier_wgs, q = nb >> 3, r = nb & 7u, x = wg & 7u, within = wg >> 3;
         wg = x * q + (x < r ? x : r) + within;
     }
     unsigned item = wg * (blockDim.x >> 6) + wave_in_wg;
-    if (item >= p.total_items) return;
-    // Two regions of items: the head of every frame-set in items of rows_per_lane rows, then the last rows of every
-    // frame-set in short items (rows_per_lane_tail).  Long items amortise the item start-up; the short ones run last and
-    // cut the end of the launch, where the chip drains for about one item's lifetime, to a quarter.
-    unsigned RB = p.rows_per_lane, items_per_set = p.items_per_set, region_row0 = 0;
-    const unsigned item_id = item;
-    if (item >= p.items_head) {
-        item -= (unsigned)p.items_head;
-        RB = p.rows_per_lane_tail;
-        items_per_set = p.items_per_set_tail;
-        region_row0 = p.tail_row0;
-    }
+    if (item >= tier_items) return;
+    const unsigned item_id = item_base + item;                      // diagnostics (stamps): unique over the launch
     if (p.stamps && lane == 0 && item_id < p.stamp_items) {   // diagnostics only (slx_debug_stamps)
         p.stamps[4 * item_id + 0] = __builtin_amdgcn_s_memtime();
         p.stamps[4 * item_id + 2] = __builtin_amdgcn_s_memrealtime();
@@ -845,33 +882,47 @@ __global__ __launch_bounds__(256) void slx_strip_kernel(const SlxKParams p)
             if constexpr (HAS_GRAY) {
                 const unsigned voff = row * row_stride + pos.cq * SLX_QUAD;
                 unsigned code[SLX_QUAD] = {0u, 0u, 0u, 0u};
-                if constexpr (GB > 0) {
+                const int G = GB > 0 ? GB : p.gray_bits;
+                if (GB > 0 || G <= 8) {
+                    // a3 + the bit-pack of a4 on the whole quad: the four codes live in the four bytes of one register
+                    uint32_t acc = 0u;
+                    if constexpr (GB > 0) {
 #pragma unroll
-                    for (int b = GB - 1; b >= 0; b--) {                 // MSB first: code = 2*code + bit
-                        const uint32_t wa = gw[2 * b], wb = gw[2 * b + 1];
-#pragma unroll
-                        for (int j = 0; j < SLX_QUAD; j++)
-                            code[j] = code[j] + code[j] + (ibyte(wa, j) > ibyte(wb, j) ? 1u : 0u);
+                        for (int b = 0; b < GB; b++) acc = swar_push_bit7(acc, swar_ge_u8_bit7(gw[2 * b + 1], gw[2 * b]));
+                    } else {
+                        for (int b = 0; b < G; b++) {
+                            const uint32_t wa = *reinterpret_cast<const uint32_t *>(p.gray[2 * b] + gset + voff);
+                            const uint32_t wb = *reinterpret_cast<const uint32_t *>(p.gray[2 * b + 1] + gset + voff);
+                            acc = swar_push_bit7(acc, swar_ge_u8_bit7(wb, wa));
+                        }
                     }
+                    uint32_t code4 = swar_finish_code(acc, G);
+                    if (p.std_gray) code4 = swar_gray_to_binary_u8(code4);   // lut[gray] = bin is the reflected code's inverse (one uniform branch)
+#pragma unroll
+                    for (int j = 0; j < SLX_QUAD; j++) code[j] = (code4 >> (8 * j)) & 0xffu;
                 } else {
-                    for (int b = p.gray_bits - 1; b >= 0; b--) {
+                    for (int b = G - 1; b >= 0; b--) {                  // more than 8 bits: per pixel, MSB first: code = 2*code + bit
                         const uint32_t wa = *reinterpret_cast<const uint32_t *>(p.gray[2 * b] + gset + voff);
                         const uint32_t wb = *reinterpret_cast<const uint32_t *>(p.gray[2 * b + 1] + gset + voff);
 #pragma unroll
                         for (int j = 0; j < SLX_QUAD; j++)
                             code[j] = code[j] + code[j] + (ibyte(wa, j) > ibyte(wb, j) ? 1u : 0u);
                     }
-                }
-                if (p.std_gray) {                                       // inverse reflected Gray code: prefix xor (one uniform branch)
+                    if (p.std_gray) {
 #pragma unroll
-                    for (int j = 0; j < SLX_QUAD; j++) {
-                        unsigned g = code[j];
-                        g ^= g >> 1;
-                        g ^= g >> 2;
-                        g ^= g >> 4;
-                        g ^= g >> 8;
-                        bin[j] = (int)g;
+                        for (int j = 0; j < SLX_QUAD; j++) {
+                            unsigned g = code[j];
+                            g ^= g >> 1;
+                            g ^= g >> 2;
+                            g ^= g >> 4;
+                            g ^= g >> 8;
+                            code[j] = g;
+                        }
                     }
+                }
+                if (p.std_gray) {
+#pragma unroll
+                    for (int j = 0; j < SLX_QUAD; j++) bin[j] = (int)code[j];
                 } else {
 #pragma unroll
                     for (int j = 0; j < SLX_QUAD; j++) bin[j] = (int)p.lut[code[j]];
@@ -1254,33 +1305,49 @@ int slx_launch_fused(const SlxKParams &kp_in, int mode, bool aux, int n_sets, in
     kp.plain_order = tn.plain_order ? 1 : 0;
     // <= 32 rows: slx_strip_eligible bounds the 32-bit output offsets for interleave (<= 64) x 32 rows past the tile
     if (tn.strip_rows >= 1 && tn.strip_rows <= 32) rb = (unsigned)tn.strip_rows;
-    kp.rows_per_lane = rb;
-    const unsigned rows_group = kp.interleave * rb;
-    const unsigned groups = ((unsigned)kp.height + rows_group - 1) / rows_group;
-    kp.items_per_set = groups * kp.chunks_per_group;
-    kp.total_items = (unsigned long long)kp.items_per_set * (unsigned)n_sets;
-    kp.items_head = kp.total_items;
-    kp.rows_per_lane_tail = rb;
-    kp.items_per_set_tail = 0;
-    kp.tail_row0 = 0;
-    // Short items at the end of the launch (plain-order modes, launches of many long items): the last ~20 % of every
-    // frame-set's rows go in items a quarter as long, dispatched after all the long ones.
-    unsigned tail_pct = 20, tail_rb = rb / 4;
+    // Tiers: the head of every frame-set in items of rb rows, then ever shorter items (a quarter of the previous tier's
+    // rows) for the last tail_pct % of the rows, each tier taking 60 % of what is left, the last one all of it.  Short
+    // items run last and cut the end of the launch, where the chip drains for about one item's lifetime.
+    unsigned tail_pct = 25, tail_rb = rb / 4, tiers = 3;
     if (tn.tail_pct != 0) tail_pct = tn.tail_pct < 0 ? 0u : (unsigned)tn.tail_pct;
     if (tn.tail_rows > 0) tail_rb = (unsigned)tn.tail_rows;
-    if (mode != SLX_MODE_MULTIFREQ_GRAYMASK && rb >= 8 && tail_rb >= 1 && tail_rb < rb && tail_pct > 0 && tail_pct < 100 && groups >= 4) {
-        unsigned head_groups = (unsigned)((unsigned long long)groups * (100u - tail_pct) / 100u);
-        if (head_groups >= 1 && head_groups < groups) {
-            const unsigned head_rows = head_groups * rows_group;                     // < height
-            const unsigned tail_group_rows = kp.interleave * tail_rb;
-            const unsigned tail_groups = ((unsigned)kp.height - head_rows + tail_group_rows - 1) / tail_group_rows;
-            kp.items_per_set = head_groups * kp.chunks_per_group;
-            kp.items_per_set_tail = tail_groups * kp.chunks_per_group;
-            kp.rows_per_lane_tail = tail_rb;
-            kp.tail_row0 = head_rows;
-            kp.items_head = (unsigned long long)kp.items_per_set * (unsigned)n_sets;
-            kp.total_items = kp.items_head + (unsigned long long)kp.items_per_set_tail * (unsigned)n_sets;
+    if (tn.tiers >= 1 && tn.tiers <= SLX_MAX_TIERS) tiers = (unsigned)tn.tiers;
+    const unsigned rows_group = kp.interleave * rb;
+    const unsigned groups = ((unsigned)kp.height + rows_group - 1) / rows_group;
+    if (!(rb >= 8 && tail_rb >= 1 && tail_rb < rb && tail_pct > 0 && tail_pct < 100 && groups >= 4)) tiers = 1;
+    unsigned waves_per_wg = 4u;
+    if (tn.strip_waves >= 1 && tn.strip_waves <= 4) waves_per_wg = (unsigned)tn.strip_waves;
+    unsigned long long need_wgs = 0;
+    {
+        unsigned row0 = 0, t = 0, r = rb;
+        unsigned head_groups = tiers > 1 ? (unsigned)((unsigned long long)groups * (100u - tail_pct) / 100u) : groups;
+        if (head_groups < 1 || head_groups >= groups) { head_groups = groups; tiers = 1; }
+        unsigned long long first_wg = 0;
+        while (true) {
+            const unsigned group_rows = kp.interleave * r;
+            const unsigned left = (unsigned)kp.height - row0;
+            unsigned g_here;
+            if (t == 0) g_here = head_groups;
+            else if (t + 1 == tiers || r == 1) g_here = (left + group_rows - 1) / group_rows;        // the last tier takes what is left
+            else g_here = std::max(1u, (unsigned)((unsigned long long)left * 60u / 100u / group_rows));
+            if ((unsigned long long)g_here * group_rows >= left) g_here = (left + group_rows - 1) / group_rows;
+            kp.tier_rows[t] = r;
+            kp.tier_row0[t] = row0;
+            kp.tier_items_per_set[t] = g_here * kp.chunks_per_group;
+            const unsigned long long items = (unsigned long long)kp.tier_items_per_set[t] * (unsigned)n_sets;
+            const unsigned long long wgs = (items + waves_per_wg - 1) / waves_per_wg;
+            if (items >= (1ull << 32) || first_wg + wgs >= (1ull << 31)) return (int)hipErrorInvalidValue;
+            kp.tier_items[t] = (unsigned)items;
+            kp.tier_first_wg[t] = (unsigned)first_wg;
+            kp.tier_wgs[t] = (unsigned)wgs;
+            first_wg += wgs;
+            row0 += g_here * group_rows;
+            t++;
+            if (row0 >= (unsigned)kp.height || t == SLX_MAX_TIERS) break;
+            r = t == 1 ? tail_rb : std::max(1u, r / 4u);
         }
+        kp.n_tiers = t;
+        need_wgs = first_wg;                                             // the waves past a tier's last item idle
     }
     // Gray planes ride the DMA ring when there are 6 bits of them (the reference's and config 3's count) and every
     // plane, in every frame-set of the launch, sits within 2 GiB above the lowest plane; otherwise the kernel reads
@@ -1306,13 +1373,10 @@ int slx_launch_fused(const SlxKParams &kp_in, int mode, bool aux, int n_sets, in
         }
     }
     // LDS per wave: 2 ring slots (max(4 n_freq, 2 gb) planes with 4 steps, 8 planes with 8 steps, 256 B each) + 2 KiB of depth staging
-    unsigned waves_per_wg = 4u;
-    if (tn.strip_waves >= 1 && tn.strip_waves <= 4) waves_per_wg = (unsigned)tn.strip_waves;
     const unsigned ring_planes = kp.n_steps == 4 ? std::max((unsigned)kp.n_freq * 4u, 2u * (unsigned)gb) : 8u;
     const unsigned lds_wave = 2u * ring_planes * 256u + 2048u;
-    if (lds_wave * waves_per_wg > 32u * 1024u) waves_per_wg = 2u;       // keep >= 5 workgroups per CU
+    if (lds_wave * waves_per_wg > 40u * 1024u) return (int)hipErrorInvalidValue;   // 4 workgroups of 4 waves per CU must fit 160 KiB
     const unsigned threads = waves_per_wg * 64u;
-    const unsigned long long need_wgs = (kp.total_items + waves_per_wg - 1) / waves_per_wg;
     if (need_wgs == 0 || need_wgs >= (1ull << 31)) return (int)hipErrorInvalidValue;
     kernel_fn fn = mode == SLX_MODE_MULTIFREQ ? (kp.n_steps == 8 ? pick_strip<SLX_MODE_MULTIFREQ, 0, 8>(kp.n_freq) : pick_strip<SLX_MODE_MULTIFREQ, 0>(kp.n_freq))
                    : mode == SLX_MODE_MULTIFREQ_GRAYMASK

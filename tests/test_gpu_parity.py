@@ -277,15 +277,15 @@ def test_strip_kernel_geometries(api, oracle, synth, variant, shape):
         assert_same(got, ref, ("z",))
 
 
-@pytest.mark.parametrize("rows,tail_pct,tail_rows", [(8, 20, 2), (16, 30, 4), (8, 50, 1), (12, 10, 3)])
+@pytest.mark.parametrize("rows,tail_pct,tail_rows,tiers", [(8, 20, 2, 2), (16, 30, 4, 3), (8, 50, 1, 4), (12, 10, 3, 3), (16, 60, 4, 4), (32, 70, 8, 4)])
 @pytest.mark.parametrize("shape", [(67, 256), (130, 1000), (200, 64), (97, 1920)])
-def test_strip_kernel_long_and_short_items(api, oracle, synth, shape, rows, tail_pct, tail_rows):
-    """The two-region item layout (long items first, the last rows of every frame-set in short items) is chosen
+def test_strip_kernel_long_and_short_items(api, oracle, synth, shape, rows, tail_pct, tail_rows, tiers):
+    """The tiered item layout (long items first, the last rows of every frame-set in ever shorter items) is chosen
     automatically only for large launches; slx_set_tuning forces it here on small, ragged tiles, for a batch of 3
-    frame-sets, in the plain-order modes (the Gray-mask mode keeps one region)."""
+    frame-sets, in every strip-kernel mode (the Gray-mask mode re-groups each tier's workgroups by XCD)."""
     import torch
     h, w = shape
-    for name in ("C1x4", "C4", "C5"):
+    for name in ("C1x4", "C4", "C5", "C3"):
         spec = small_spec(synth, name, w, h)
         sets = [synth.random_planes(spec, seed=7 * h + w + i) for i in range(3)]
         want = [oracle.pipeline(spec, ph, gr, want=("z",))["z"] for ph, gr in sets]
@@ -295,7 +295,7 @@ def test_strip_kernel_long_and_short_items(api, oracle, synth, shape, rows, tail
         torch.cuda.synchronize()
         with api.Context(spec) as ctx:
             ctx.set_variant(2)
-            ctx.set_tuning(strip_rows=rows, tail_pct=tail_pct, tail_rows=tail_rows)
+            ctx.set_tuning(strip_rows=rows, tail_pct=tail_pct, tail_rows=tail_rows, tiers=tiers)
             ctx.decode_batch(3, phase, gray, z)
             ctx.synchronize()
         got = z.cpu().numpy()
@@ -316,13 +316,14 @@ def test_environment_is_ignored(api, oracle, synth, monkeypatch):
         got = api.decode_frameset(spec, ph, gr, want=("z",), variant=api.VARIANT_STRIP)
         assert_same(got, ref, ("z",))
     with api.Context(small_spec(synth, "C4", 64, 8)) as ctx:
-        for bad in (dict(strip_rows=33), dict(strip_rows=-1), dict(tail_pct=100), dict(strip_waves=5), dict(lds_pad_kib=129)):
+        for bad in (dict(strip_rows=33), dict(strip_rows=-1), dict(tail_pct=100), dict(strip_waves=5), dict(lds_pad_kib=129), dict(tiers=5)):
             with pytest.raises(api.SlxError) as e:
                 ctx.set_tuning(**bad)
             assert e.value.code == api.ERR_INVALID_ARG
 
 
-@pytest.mark.parametrize("tune", [dict(gray_plain=1), dict(strip_waves=2), dict(plain_order=1), dict(lds_pad_kib=40), dict(strip_rows=1), dict(tail_pct=-1)])
+@pytest.mark.parametrize("tune", [dict(gray_plain=1), dict(strip_waves=2), dict(plain_order=1), dict(lds_pad_kib=40), dict(strip_rows=1), dict(tail_pct=-1), dict(tiers=1),
+                                  dict(strip_rows=8, tiers=4, tail_pct=60, tail_rows=2)])
 def test_tuning_keys_do_not_change_results(api, oracle, synth, tune):
     spec = small_spec(synth, "C3", 500, 67)
     ph, gr = synth.random_planes(spec, seed=17)
@@ -940,3 +941,26 @@ def test_bench_two_ranks_rehearsed_on_one_gpu():
         assert "error" not in g, g
         assert g["gathered_equals_local_decodes"] is True and g["gathered_shape"] == [8, 1200, 1920]
         assert g["kernel_only"]["value"] > 0 and g["end_to_end"]["value"] > 0
+
+
+@pytest.mark.parametrize("bits", [1, 3, 6, 7, 8, 10, 12])
+@pytest.mark.parametrize("std_lut", [True, False])
+def test_strip_kernel_gray_widths(api, oracle, synth, bits, std_lut):
+    """The strip kernel packs the Gray bits of a quad's four pixels in one register (up to 8 bits per pixel; wider codes go
+    pixel by pixel): every width class, the reflected-code shortcut and an arbitrary table, exact ties included, in the
+    reference's mode and the Gray-mask mode."""
+    for name in ("C1x4", "C3"):
+        spec = small_spec(synth, name, 256, 40)
+        spec["gray_bits"] = bits
+        spec["gray_stripe"] = max(1, spec["proj_width"] // (1 << bits))
+        if name == "C1x4":
+            spec["periods"] = [max(2, 2 * spec["gray_stripe"])]
+        rng = np.random.default_rng(bits)
+        spec["gray_lut"] = synth.standard_gray_lut(bits) if std_lut else rng.integers(-50, 3000, 1 << bits).astype(np.int16)
+        ph, gr = synth.random_planes(spec, seed=900 + bits)
+        gr[:, :, :128] = np.where(gr[:, :, :128] > 127, 220, 20)
+        gr[1::2, :, 64:96] = gr[0::2, :, 64:96]                        # exact ties: pattern == inverse -> bit 0
+        ref = oracle.pipeline(spec, ph, gr, want=("z",))
+        for variant in (api.VARIANT_STRIP, api.VARIANT_GENERIC):
+            got = api.decode_frameset(spec, ph, gr, want=("z",), variant=variant)
+            assert_same(got, ref, ("z",))

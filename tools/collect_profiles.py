@@ -13,9 +13,12 @@ mine = [r for r in csv.DictReader(open(trace)) if "slx_" in r["Kernel_Name"]]
 with open(os.path.join(out, prefix + "_kernel_trace_slx.csv"), "w") as g:
     w = csv.DictWriter(g, fieldnames=list(mine[0].keys())); w.writeheader(); w.writerows(mine)
 vals = {}
-for name in ["pmc_sq", "pmc_sq2", "pmc_fetch", "pmc_write"]:
+for name in ["pmc_sq", "pmc_sq2", "pmc_sq3", "pmc_sq4", "pmc_fetch", "pmc_write"]:
     acc = collections.defaultdict(list)
-    for r in csv.DictReader(open("gpurun_out/prof_%s/%s.csv" % (tag, name))):
+    path = "gpurun_out/prof_%s/%s.csv" % (tag, name)
+    if not os.path.exists(path):
+        continue
+    for r in csv.DictReader(open(path)):
         acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k, v in acc.items():
         vals[k] = {"mean_per_dispatch": sum(v) / len(v), "dispatches": len(v)}
