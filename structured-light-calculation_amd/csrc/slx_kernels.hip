@@ -231,6 +231,24 @@ __device__ __forceinline__ double div_f64_inrange(double num, double den)
     return __builtin_fma(__builtin_fma(-den, q, num), r, q);
 }
 
+// n / d for a divisor that is constant over the item: r = the refined reciprocal of d (v_rcp_f64 + two Newton steps, the
+// first half of div_f64_inrange, computed once), then the same quotient + residual correction.  Bit-identical to the
+// IEEE division whenever no scaling would occur; a NaN out of a non-NaN numerator (overflow of n * r) and a zero quotient
+// (whose sign the correction step would lose, and which also covers an underflowing one) take the literal division.
+__device__ __forceinline__ double refined_rcp_f64(double d)
+{
+    double r = __builtin_amdgcn_rcp(d);
+    r = __builtin_fma(r, __builtin_fma(-d, r, 1.0), r);
+    return __builtin_fma(r, __builtin_fma(-d, r, 1.0), r);
+}
+__device__ __forceinline__ double div_by_item_const(double n, double d, double r)
+{
+    const double q = n * r;
+    double o = __builtin_fma(__builtin_fma(-d, q, n), r, q);
+    if (__builtin_expect((o != o) | (__builtin_fabs(o) < 0x1p-900), 0)) o = n / d;
+    return o;
+}
+
 // a7 for one pixel: z = -(cA - cB U)/(cC - cD U), FOV clamp, U == 0 / mask -> 0.
 template <bool LEAN>
 __device__ __forceinline__ double tri_depth(double Uv, double cC, double cD, double cA, double cB,
@@ -667,7 +685,13 @@ __device__ __forceinline__ StripPos strip_locate(const SlxKParams &p, unsigned i
 // s_waitcnt takes an immediate); GB == 0: Gray planes, if any, are read with ordinary loads inside the step.
 // NS: phase-shift steps, 4 (the reference's, planes through the DMA ring) or another compile-time count (x1:
 // the planes are read with ordinary loads, F * NS of them would not fit the ring at a useful occupancy).
-template <int MODE, int F, int GB, int NS>
+// AUX: also the optional planes the reference computes beside z -- x, y (R/CCalculation.cpp:756-771), the projector column U,
+// the fringe orders k, the validity mask -- for the whole batch.  The f64 planes take the same LDS transpose as z (a second
+// 2-KiB staging area, reused plane after plane: a wave's LDS operations execute in order), k and the mask leave straight from
+// the lanes that own the pixels (16 / 4 contiguous bytes per lane).  Planes that were not asked for are "stored" against an
+// empty buffer descriptor, so every step issues the same number of memory instructions -- which the counted s_waitcnt
+// immediates of the DMA ring rely on.
+template <int MODE, int F, int GB, int NS, bool AUX>
 __global__ __launch_bounds__(256) void slx_strip_kernel(const SlxKParams p)
 {
     constexpr bool MASKED = MODE == SLX_MODE_MULTIFREQ_GRAYMASK;
@@ -682,6 +706,11 @@ __global__ __launch_bounds__(256) void slx_strip_kernel(const SlxKParams p)
     constexpr int NGR = 2 * GB;                   // planes in the Gray chunk
     constexpr int NPMAX = NPH > NGR ? NPH : NGR;
     constexpr unsigned ROW_DW = NPMAX * 64;       // one ring slot in LDS, dwords per wave
+    constexpr int NK = (F > 1 && MODE != SLX_MODE_GRAY_PHASE) ? F - 1 : 0;   // planes of fringe orders
+    constexpr int NZ = 2;                         // depth stores per row
+    constexpr int NA = AUX ? 6 + NK + 1 : 0;      // store instructions of the optional planes per row: x, y, U (2 each), k, mask
+    // the counted waits below are exact only when every vector-memory operation of a step is one this code issues itself
+    constexpr bool EXACT_WAITS = GB > 0 || !HAS_GRAY;
     typedef double vec2 __attribute__((ext_vector_type(2)));
     typedef __attribute__((address_space(3))) void lds_void;
     // LDS per wave: [fringe-stack ring: 2 chunks x NP planes x 256 B] [2 KiB depth staging]
@@ -691,8 +720,9 @@ __global__ __launch_bounds__(256) void slx_strip_kernel(const SlxKParams p)
     // wave-uniform by construction; readfirstlane tells hipcc so (scalar addressing, M0 straight from
     // an SGPR, no waterfall loops around the buffer descriptor)
     const unsigned wave_in_wg = __builtin_amdgcn_readfirstlane(t >> 6);
-    uint32_t *ring = lds_raw + wave_in_wg * (2u * ROW_DW + 512u);
+    uint32_t *ring = lds_raw + wave_in_wg * (2u * ROW_DW + 512u + (AUX ? 512u : 0u));
     vec2 *stage = reinterpret_cast<vec2 *>(ring + 2u * ROW_DW);
+    vec2 *stage2 = stage + 128;                   // AUX only
     // XCD-aware item order: the dispatcher deals workgroups round-robin over the 8 XCDs (blocks b and b + 8 share
     // an L2), so consecutive items go to ONE XCD: neighbouring chunks of the Gray-mask mode overlap by a halo quad
     // and start at 248-byte multiples, and their shared 128-byte lines are then fetched from HBM once, not twice.
@@ -763,15 +793,15 @@ __global__ __launch_bounds__(256) void slx_strip_kernel(const SlxKParams p)
         uint32_t *dst = ring + slot * ROW_DW;
         // every byte is read once: nontemporal loads (+1.6 % on config 4) -- except in the Gray-mask mode, whose halo
         // quads are re-read by the neighbouring wave out of L2 (-10 % with nt there)
-        constexpr int AUX = MASKED ? 0 : 2;
+        constexpr int POLICY = MASKED ? 0 : 2;
         if (GRAY_CHUNK && cc == 1) {
 #pragma unroll
             for (int k = 0; k < NGR; k++)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void *)(dst + k * 64), 4, voff, gray_soff[k], 0, AUX);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void *)(dst + k * 64), 4, voff, gray_soff[k], 0, POLICY);
         } else {
 #pragma unroll
             for (int k = 0; k < NPH; k++)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void *)(dst + k * 64), 4, voff, p.phase_rel[(NS == 4 ? 0 : cc * NPH) + k], 0, AUX);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void *)(dst + k * 64), 4, voff, p.phase_rel[(NS == 4 ? 0 : cc * NPH) + k], 0, POLICY);
         }
     };
     // Depth stores: buffer stores against a descriptor of this frame-set's depth map -- one 32-bit byte offset per store
@@ -795,6 +825,29 @@ __global__ __launch_bounds__(256) void slx_strip_kernel(const SlxKParams p)
         }
     };
 
+    // The optional planes: a descriptor per plane (an empty one for a plane that was not asked for), the byte offset of the
+    // lane's own quad in the 4-byte and 1-byte planes, the reciprocals of the two divisors of a7's second pass.
+    __amdgpu_buffer_rsrc_t xrsrc = zrsrc, yrsrc = zrsrc, Ursrc = zrsrc, mrsrc = zrsrc, krsrc[NK > 0 ? NK : 1];
+    unsigned own_px = 0x3FFFFFFCu, own_step = 0u;
+    double rfu = 0.0, rfv = 0.0;
+    if constexpr (AUX) {
+        auto plane = [&](const void *base, size_t planes_per_set, size_t q, unsigned elem) {
+            const char *b = base ? static_cast<const char *>(base) + ((size_t)pos.set * planes_per_set + q) * p.out_set_stride * elem : nullptr;
+            return __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(b ? b : reinterpret_cast<const char *>(zset)), 0, b ? H * W * elem : 0u, 0x00020000);
+        };
+        xrsrc = plane(p.x, 1, 0, 8);
+        yrsrc = plane(p.y, 1, 0, 8);
+        Ursrc = plane(p.U, 1, 0, 8);
+        mrsrc = plane(p.mask, 1, 0, 1);
+#pragma unroll
+        for (int f = 0; f < NK; f++) krsrc[f] = plane(p.k, NK, f, 4);
+        const bool own = lane_valid && (!MASKED || (lane >= 1u && lane <= 62u));
+        own_px = own ? pos.row * W + pos.cq * SLX_QUAD : 0x3FFFFFFCu;   // x 4 bytes still fits 32 bits and stays out of range
+        own_step = own ? step_rows * W : 0u;
+        rfu = refined_rcp_f64(p.fu);
+        rfv = refined_rcp_f64(p.fv);
+    }
+
     // a6, column part: a = (u - cx)*fv ; aC = a*P00 ; aD = a*P20
     double aC[SLX_QUAD], aD[SLX_QUAD];
 #pragma unroll
@@ -816,10 +869,35 @@ __global__ __launch_bounds__(256) void slx_strip_kernel(const SlxKParams p)
         for (int c = 0; c < CPR; c++) {
             const unsigned g = i * CPR + c;
             const unsigned slot = g & 1u;
-            // vmcnt retires in issue order: "all but the youngest chunk's loads" = everything up to this chunk's DMA
+            // vmcnt retires in issue order, loads and stores alike: the wait for chunk g names how many operations were issued
+            // AFTER its DMA -- the DMA of the chunk(s) behind it, the depth stores (NZ) and the optional planes' stores (NA)
+            // that fell in between -- and so leaves exactly those in flight.  A smaller count is always safe (it waits for
+            // more); the exact one keeps a row's stores from being waited for in the step that issued them.
+            //   one chunk per row:   L(i) | A(i-2) | Z(i-2) L(i+1) A(i-1) | wait
+            //   phase + Gray chunk:  L(i,0) | L(i,1) A(i-1) | wait0      L(i,1) | A(i-1) Z(i-1) L(i+1,0) | wait1
+            //   8 steps, F chunks:   c = 0: L(i,1) A(i-1)   c = 1: A(i-1) Z(i-1) L(next)   c >= 2: L(next)
+            // (the first steps of an item have fewer stores behind them: i selects the variant)
             if (g + 1 >= total_chunks) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            else if (GRAY_CHUNK && c == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NGR) : "memory");   // the Gray chunk is the younger one
-            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPH) : "memory");
+            else if (!EXACT_WAITS) {
+                if (GRAY_CHUNK && c == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NGR) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPH) : "memory");
+            } else if (CPR == 1) {
+                if (i >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPH + NZ + 2 * NA) : "memory");
+                else if (i == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPH + NA) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPH) : "memory");
+            } else if (GRAY_CHUNK) {
+                if (c == 0) {
+                    if (i >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NGR + NA) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NGR) : "memory");
+                } else {
+                    if (i >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPH + NZ + NA) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPH) : "memory");
+                }
+            } else {
+                if (c == 0 && i >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPH + NA) : "memory");
+                else if (c == 1 && i >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPH + NZ + NA) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPH) : "memory");
+            }
             if (c == 0 && i > 0) flush_row(i - 1);                      // last row's stores, one step late
             if (row < H) {
                 const uint32_t *src = ring + slot * ROW_DW + lane;
@@ -870,14 +948,19 @@ __global__ __launch_bounds__(256) void slx_strip_kernel(const SlxKParams p)
             if (g + 2 < total_chunks) issue_chunk(slot, (c + 2) % CPR); // rows past the tile: keeps the DMA count per step fixed
         }
 
-        double z[SLX_QUAD];
-        if constexpr (MASKED) {                                         // the mask pass below runs for every lane
+        double z[SLX_QUAD], U[SLX_QUAD];
+        int kf[NK > 0 ? NK : 1][SLX_QUAD];
+        if constexpr (MASKED || AUX) {                                  // the mask pass / the optional planes below run for every lane
 #pragma unroll
-            for (int j = 0; j < SLX_QUAD; j++) z[j] = 0.0;
+            for (int j = 0; j < SLX_QUAD; j++) z[j] = 0.0, U[j] = 0.0;
+#pragma unroll
+            for (int f = 0; f < NK; f++)
+#pragma unroll
+                for (int j = 0; j < SLX_QUAD; j++) kf[f][j] = 0;
         }
         int v0[SLX_QUAD] = {1, 1, 1, 1};                                // x3: lanes without pixels never veto
+        int okq[SLX_QUAD] = {1, 1, 1, 1};                               // the mask plane: 1 outside the Gray-mask mode
         if (row < H) {
-            double U[SLX_QUAD];
             int bin[SLX_QUAD] = {0, 0, 0, 0};
             if constexpr (HAS_GRAY) {
                 const unsigned voff = row * row_stride + pos.cq * SLX_QUAD;
@@ -950,6 +1033,7 @@ __global__ __launch_bounds__(256) void slx_strip_kernel(const SlxKParams p)
                     for (int f = 1; f < F; f++) {
                         int k;
                         Uf = unwrap_stage<true>(Uf, (double)pix[f][j], p.period[f], p.inv_period[f], hb[f], k);
+                        if constexpr (AUX && NK > 0) kf[f - 1][j] = k;
                     }
                     U[j] = Uf;
                 }
@@ -995,11 +1079,50 @@ __global__ __launch_bounds__(256) void slx_strip_kernel(const SlxKParams p)
                 if (u0 + j > 0) ok &= l;
                 if (u0 + j + 1 < (int)W) ok &= r;
                 if (!ok) z[j] = 0.0;
+                okq[j] = ok;
             }
             if (lane >= 1u && lane <= 62u) {
                 stage[2 * (lane - 1u) + 0] = vec2{z[0], z[1]};
                 stage[2 * (lane - 1u) + 1] = vec2{z[2], z[3]};
             }
+        }
+        if constexpr (AUX) {
+            // a7, second pass (R/CCalculation.cpp:756-771): x = (z uc)/fu, y = (z vc)/fv from the final depth; then the planes
+            // leave in this order, NA store instructions in all, whatever was asked for (see the descriptors above)
+            double xo[SLX_QUAD], yo[SLX_QUAD];
+            const double vc = (double)((int)row + p.row_offset) - p.cy;
+#pragma unroll
+            for (int j = 0; j < SLX_QUAD; j++) {
+                const double uc = (double)(int)(pos.cq * SLX_QUAD + j) - p.cx;
+                xo[j] = div_by_item_const(z[j] * uc, p.fu, rfu);
+                yo[j] = div_by_item_const(z[j] * vc, p.fv, rfv);
+            }
+            const unsigned sl = MASKED ? lane - 1u : lane;
+            const bool holds = !MASKED || (lane >= 1u && lane <= 62u);
+            auto emit_f64 = [&](const double (&v)[SLX_QUAD], __amdgpu_buffer_rsrc_t r) {
+                if (holds) {
+                    stage2[2 * sl + 0] = vec2{v[0], v[1]};
+                    stage2[2 * sl + 1] = vec2{v[2], v[3]};
+                }
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int k = 0; k < 2; k++) {
+                    const u32x4 t4 = *reinterpret_cast<const u32x4 *>(stage2 + k * 64 + lane);
+                    __builtin_amdgcn_raw_buffer_store_b128(t4, r, out_boff[k], 0, 2 /* nt */);   // out_boff: this row's slots (z follows next step)
+                }
+                __builtin_amdgcn_wave_barrier();
+            };
+            emit_f64(xo, xrsrc);
+            emit_f64(yo, yrsrc);
+            emit_f64(U, Ursrc);
+#pragma unroll
+            for (int f = 0; f < NK; f++) {
+                const u32x4 k4 = {(unsigned)kf[f][0], (unsigned)kf[f][1], (unsigned)kf[f][2], (unsigned)kf[f][3]};
+                __builtin_amdgcn_raw_buffer_store_b128(k4, krsrc[f], own_px * 4u, 0, 2);
+            }
+            const unsigned m4 = (unsigned)(okq[0] != 0) | (unsigned)(okq[1] != 0) << 8 | (unsigned)(okq[2] != 0) << 16 | (unsigned)(okq[3] != 0) << 24;
+            __builtin_amdgcn_raw_buffer_store_b32(m4, mrsrc, own_px, 0, 2);
+            own_px += own_step;
         }
         __builtin_amdgcn_wave_barrier();
     }
@@ -1165,13 +1288,13 @@ kernel_fn pick(int mode, int F, bool n4, bool aux)
 }
 
 template <int MODE, int GB, int NS = 4>
-kernel_fn pick_strip(int F)
+kernel_fn pick_strip(int F, bool aux)
 {
     switch (F) {
-    case 1: return slx_strip_kernel<MODE, 1, GB, NS>;
-    case 2: return slx_strip_kernel<MODE, 2, GB, NS>;
-    case 3: return slx_strip_kernel<MODE, 3, GB, NS>;
-    case 4: return slx_strip_kernel<MODE, 4, GB, NS>;
+    case 1: return aux ? slx_strip_kernel<MODE, 1, GB, NS, true> : slx_strip_kernel<MODE, 1, GB, NS, false>;
+    case 2: return aux ? slx_strip_kernel<MODE, 2, GB, NS, true> : slx_strip_kernel<MODE, 2, GB, NS, false>;
+    case 3: return aux ? slx_strip_kernel<MODE, 3, GB, NS, true> : slx_strip_kernel<MODE, 3, GB, NS, false>;
+    case 4: return aux ? slx_strip_kernel<MODE, 4, GB, NS, true> : slx_strip_kernel<MODE, 4, GB, NS, false>;
     }
     return nullptr;
 }
@@ -1217,7 +1340,13 @@ bool slx_fast_arith_ok(const SlxKParams &kp)
 
 bool slx_strip_eligible(const SlxKParams &kp, int mode, bool aux)
 {
-    if (aux || !kp.aligned) return false;
+    if (!kp.aligned) return false;
+    if (aux && (kp.pix || kp.gray_out)) return false;                // the per-frequency pix planes and the Gray plane come from the generic kernel only
+    {
+        // second-pass divisors (x = z uc / fu, y = z vc / fv) must sit well inside the double range for the unscaled division
+        const double lo = 0x1p-90;
+        if (aux && !(__builtin_fabs(kp.fu) > lo && __builtin_fabs(kp.fv) > lo)) return false;
+    }
     if (kp.n_steps != 4) {                                           // x1 fast path: 8 steps, Gray-free, the expected weight table
         if (!(kp.n_steps == 8 && mode == SLX_MODE_MULTIFREQ)) return false;
         const float r = kp.wy[1];
@@ -1305,10 +1434,10 @@ int slx_launch_fused(const SlxKParams &kp_in, int mode, bool aux, int n_sets, in
     kp.plain_order = tn.plain_order ? 1 : 0;
     // <= 32 rows: slx_strip_eligible bounds the 32-bit output offsets for interleave (<= 64) x 32 rows past the tile
     if (tn.strip_rows >= 1 && tn.strip_rows <= 32) rb = (unsigned)tn.strip_rows;
-    // Tiers: the head of every frame-set in items of rb rows, then ever shorter items (a quarter of the previous tier's
-    // rows) for the last tail_pct % of the rows, each tier taking 60 % of what is left, the last one all of it.  Short
-    // items run last and cut the end of the launch, where the chip drains for about one item's lifetime.
-    unsigned tail_pct = 25, tail_rb = rb / 4, tiers = 3;
+    // Tiers: the head of every frame-set in items of rb rows, then shorter items (a quarter of the previous tier's rows)
+    // for the last tail_pct % of the rows; with more than two tiers each takes 60 % of what is left, the last one all of
+    // it.  Short items run last and cut the end of the launch, where the chip drains for about one item's lifetime.
+    unsigned tail_pct = 20, tail_rb = rb / 4, tiers = 2;   // measured (tools/ab.py, C4 and C3): 2 tiers beat 1 by 2 %, 3 and 4 lose it again
     if (tn.tail_pct != 0) tail_pct = tn.tail_pct < 0 ? 0u : (unsigned)tn.tail_pct;
     if (tn.tail_rows > 0) tail_rb = (unsigned)tn.tail_rows;
     if (tn.tiers >= 1 && tn.tiers <= SLX_MAX_TIERS) tiers = (unsigned)tn.tiers;
@@ -1374,14 +1503,14 @@ int slx_launch_fused(const SlxKParams &kp_in, int mode, bool aux, int n_sets, in
     }
     // LDS per wave: 2 ring slots (max(4 n_freq, 2 gb) planes with 4 steps, 8 planes with 8 steps, 256 B each) + 2 KiB of depth staging
     const unsigned ring_planes = kp.n_steps == 4 ? std::max((unsigned)kp.n_freq * 4u, 2u * (unsigned)gb) : 8u;
-    const unsigned lds_wave = 2u * ring_planes * 256u + 2048u;
+    const unsigned lds_wave = 2u * ring_planes * 256u + 2048u + (aux ? 2048u : 0u);      // + the optional planes' staging area
     if (lds_wave * waves_per_wg > 40u * 1024u) return (int)hipErrorInvalidValue;   // 4 workgroups of 4 waves per CU must fit 160 KiB
     const unsigned threads = waves_per_wg * 64u;
     if (need_wgs == 0 || need_wgs >= (1ull << 31)) return (int)hipErrorInvalidValue;
-    kernel_fn fn = mode == SLX_MODE_MULTIFREQ ? (kp.n_steps == 8 ? pick_strip<SLX_MODE_MULTIFREQ, 0, 8>(kp.n_freq) : pick_strip<SLX_MODE_MULTIFREQ, 0>(kp.n_freq))
+    kernel_fn fn = mode == SLX_MODE_MULTIFREQ ? (kp.n_steps == 8 ? pick_strip<SLX_MODE_MULTIFREQ, 0, 8>(kp.n_freq, aux) : pick_strip<SLX_MODE_MULTIFREQ, 0>(kp.n_freq, aux))
                    : mode == SLX_MODE_MULTIFREQ_GRAYMASK
-                       ? (gb ? pick_strip<SLX_MODE_MULTIFREQ_GRAYMASK, 6>(kp.n_freq) : pick_strip<SLX_MODE_MULTIFREQ_GRAYMASK, 0>(kp.n_freq))
-                       : (gb ? pick_strip<SLX_MODE_GRAY_PHASE, 6>(1) : pick_strip<SLX_MODE_GRAY_PHASE, 0>(1));
+                       ? (gb ? pick_strip<SLX_MODE_MULTIFREQ_GRAYMASK, 6>(kp.n_freq, aux) : pick_strip<SLX_MODE_MULTIFREQ_GRAYMASK, 0>(kp.n_freq, aux))
+                       : (gb ? pick_strip<SLX_MODE_GRAY_PHASE, 6>(1, aux) : pick_strip<SLX_MODE_GRAY_PHASE, 0>(1, aux));
     if (!fn) return (int)hipErrorInvalidValue;
     size_t lds = (size_t)waves_per_wg * lds_wave;
     if (tn.lds_pad_kib > 0 && tn.lds_pad_kib <= 128) lds += (size_t)tn.lds_pad_kib * 1024u;   // experiments: lower the occupancy

@@ -57,6 +57,12 @@ def all_outputs(spec):
     return tuple(want)
 
 
+def strip_outputs(spec):
+    """What the strip kernel produces: the depth-side planes (the per-frequency pix planes and the Gray plane are the generic
+    kernel's)."""
+    return tuple(w for w in all_outputs(spec) if w not in ("pix", "gray"))
+
+
 def assert_same(got, want, names, tol=RMS_TOL_MM):
     for n in names:
         g, w = got[n], want[n]
@@ -133,6 +139,10 @@ def test_baseline_configs_full_size(api, oracle, synth, name, scene):
     ref = oracle.pipeline(spec, ph, gr, want=want, threads=8)
     assert_same(got, ref, want)
     assert (got["z"] > 0).mean() > 0.9
+    # x, y, U, the fringe orders and the mask from the strip kernel (variant 2 refuses to fall back)
+    sw = strip_outputs(spec)
+    got = api.decode_frameset(spec, ph, gr, want=sw, variant=api.VARIANT_STRIP)
+    assert_same(got, ref, sw)
 
 
 def test_baseline_config_c5(api, oracle, synth):
@@ -146,6 +156,8 @@ def test_baseline_config_c5(api, oracle, synth):
     for variant in (api.VARIANT_GENERIC, api.VARIANT_STRIP):
         got = api.decode_frameset(spec, ph, None, want=("z",), variant=variant)
         assert_same(got, ref, ("z",), RMS_TOL_MM_C5)
+    got = api.decode_frameset(spec, ph, None, want=("z", "k", "U"), variant=api.VARIANT_STRIP)
+    assert_same(got, ref, ("z", "k", "U"), RMS_TOL_MM_C5)
 
 
 # ------------------------------------------------------------------ unstructured inputs, every branch
@@ -229,6 +241,8 @@ def test_unwrap_rounding_ties(api, oracle, synth, name):
     for variant in (api.VARIANT_AUTO, api.VARIANT_STRIP):
         got = api.decode_frameset(spec, ph, None, want=("z",), variant=variant)
         assert_same(got, ref, ("z",))
+        got = api.decode_frameset(spec, ph, None, want=("z", "k", "U"), variant=variant)      # "phase indices bit-exact" on the fast path
+        assert_same(got, ref, ("z", "k", "U"))
 
 
 @pytest.mark.parametrize("variant", [0, 1, 2, 3])
@@ -964,3 +978,52 @@ def test_strip_kernel_gray_widths(api, oracle, synth, bits, std_lut):
         for variant in (api.VARIANT_STRIP, api.VARIANT_GENERIC):
             got = api.decode_frameset(spec, ph, gr, want=("z",), variant=variant)
             assert_same(got, ref, ("z",))
+
+
+@pytest.mark.parametrize("name", ["C1", "C1x4", "C2", "C3", "C4", "C5", "C5x4"])
+@pytest.mark.parametrize("shape", [(7, 64), (33, 1024), (67, 500), (1, 4), (130, 256), (37, 1920)])
+def test_strip_kernel_optional_planes(api, oracle, synth, torch_cuda, name, shape):
+    """x, y, U, k and the mask from the strip kernel: every mode and step count it runs, ragged geometries, unstructured bytes
+    (so every branch of the unwrap / merge / mask is taken), one frame-set through slx_decode and a batch of three through
+    slx_decode_batch_ex into planes with a pitch (as a row tile lands in a full-height map); any subset of the planes."""
+    torch = torch_cuda
+    h, w = shape
+    spec = small_spec(synth, "C5" if name == "C5x4" else name, w, h)
+    if name == "C5x4":
+        spec["n_steps"] = 4
+    want = strip_outputs(spec)
+    sets = [synth.random_planes(spec, seed=h * 31 + w + i) for i in range(3)]
+    if sets[0][1] is not None and w >= 8:
+        for _, gr in sets:
+            gr[:, :, : w // 2] = np.where(gr[:, :, : w // 2] > 127, 220, 20)
+    refs = [oracle.pipeline(spec, ph, gr, want=want) for ph, gr in sets]
+    got = api.decode_frameset(spec, sets[0][0], sets[0][1], want=want, variant=api.VARIANT_STRIP)
+    assert_same(got, refs[0], want)
+    sub = tuple(x for x in want if x in ("z", "y", "mask"))
+    got = api.decode_frameset(spec, sets[0][0], sets[0][1], want=sub, variant=api.VARIANT_STRIP)
+    assert_same(got, refs[0], sub)
+    # batch, planes 2 rows taller than the tile, the tile starting at row 1
+    Hp = h + 2
+    phase = torch.from_numpy(np.stack([ph for ph, _ in sets])).cuda()
+    gray = torch.from_numpy(np.stack([gr for _, gr in sets])).cuda() if sets[0][1] is not None else None
+    nk = spec["n_freq"] - 1 if (spec["mode"] in (3, 4) and spec["n_freq"] > 1) else 0
+    out = {n: torch.full((3, Hp, w), -5.0, dtype=torch.float64, device="cuda") for n in ("z", "x", "y", "U")}
+    kk = torch.full((3, max(nk, 1), Hp, w), -5, dtype=torch.int32, device="cuda")
+    mm = torch.full((3, Hp, w), 7, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    with api.Context(spec) as ctx:
+        ctx.set_variant(api.VARIANT_STRIP)
+        ctx.decode_batch_ex(3, phase, gray, z=out["z"][0, 1:], x=out["x"][0, 1:], y=out["y"][0, 1:], U=out["U"][0, 1:],
+                            k=kk[0, 0, 1:] if nk else None, mask=mm[0, 1:], plane_stride=Hp * w)
+        ctx.synchronize()
+    for i in range(3):
+        for n in ("z", "x", "y", "U"):
+            a = out[n][i].cpu().numpy()
+            assert np.array_equal(a[1:h + 1], refs[i][n], equal_nan=True), (i, n)
+            assert np.all(a[0] == -5.0) and np.all(a[h + 1] == -5.0), (i, n)             # nothing outside the tile's rows
+        if nk:
+            a = kk[i].cpu().numpy()
+            assert np.array_equal(a[:, 1:h + 1], refs[i]["k"]) and np.all(a[:, 0] == -5) and np.all(a[:, h + 1] == -5), i
+        a = mm[i].cpu().numpy()
+        want_mask = refs[i]["mask"] if "mask" in refs[i] else np.ones((h, w), np.uint8)
+        assert np.array_equal(a[1:h + 1], want_mask) and np.all(a[0] == 7) and np.all(a[h + 1] == 7), i
