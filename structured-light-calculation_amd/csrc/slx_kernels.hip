@@ -170,14 +170,34 @@ __device__ __forceinline__ V pix_from_octant_angle(V a, V mc, V ms, float Tf)
 // under a power-of-two scale that stays inside the normal range -- max/min/compare, v_rcp_f32 (a function of the
 // mantissa), the quotient and its residual, the sign tests -- so the result is the same bit for bit; only the
 // 0/0 guard and the saturation factor of the sign tests move with the scale.
-template <bool SCALED, typename V>
-__device__ __forceinline__ V wrapped_pix_from_diffs(V s2, V c2, float Tf)
+// Reciprocal of the larger difference, two ways.  RcpUnit: v_rcp_f32 (8 issue cycles per pixel).  RcpTable: the larger
+// difference is an integer b in [1, 255] (times 2^-23), so 1/b comes out of a 255-entry table in LDS -- the LDS port is
+// idle in this kernel, the VALU is what binds it.  The table index costs one 2-cycle multiply: b 2^-23 * 2^-124 is the
+// denormal whose BIT PATTERN is the integer 4 b, the entry's byte offset.  Any faithfully rounded reciprocal gives the same
+// corrected quotient (see the identities above): the table's entries are the double quotient rounded to float.
+struct RcpUnit {
+    __device__ __forceinline__ f32x2 operator()(f32x2 x) const { return v_rcp(x); }
+    __device__ __forceinline__ F32x2x2 operator()(F32x2x2 x) const { return v_rcp(x); }
+};
+struct RcpTable {
+    const char *table;                                               // LDS, entry b at byte 4 b: 2^23 / b
+    __device__ __forceinline__ float one(float x) const
+    {
+        const unsigned off = __builtin_bit_cast(unsigned, x * 0x1p-124f);
+        return *reinterpret_cast<const float *>(table + off);
+    }
+    __device__ __forceinline__ f32x2 operator()(f32x2 x) const { return {one(x.x), one(x.y)}; }
+    __device__ __forceinline__ F32x2x2 operator()(F32x2x2 x) const { return {(*this)(x.a), (*this)(x.b)}; }
+};
+
+template <bool SCALED, typename V, typename RCP = RcpUnit>
+__device__ __forceinline__ V wrapped_pix_from_diffs(V s2, V c2, float Tf, RCP rcp = RCP())
 {
     constexpr float kGuard = SCALED ? 0x1p-23f : 1.0f;
     const V as = v_abs(s2), ac = v_abs(c2);
     const V mx = v_max3(as, ac, kGuard);
     const V mn = v_min(as, ac);
-    const V r = v_rcp(mx);
+    const V r = rcp(mx);
     const V q0 = mn * r;
     const V c = v_fma(v_fma(-mx, q0, mn), r, q0);                   // RN(mn / mx)
     const V cc = c * c;
@@ -720,7 +740,16 @@ __global__ __launch_bounds__(256) void slx_strip_kernel(const SlxKParams p)
     // wave-uniform by construction; readfirstlane tells hipcc so (scalar addressing, M0 straight from
     // an SGPR, no waterfall loops around the buffer descriptor)
     const unsigned wave_in_wg = __builtin_amdgcn_readfirstlane(t >> 6);
-    uint32_t *ring = lds_raw + wave_in_wg * (2u * ROW_DW + 512u + (AUX ? 512u : 0u));
+    // [0, 1 KiB): the reciprocal table of the 4-step wrapped phase, one per workgroup; then the waves' areas
+    constexpr bool RTAB = NS == 4;
+    constexpr unsigned TAB_DW = RTAB ? 256u : 0u;
+    if constexpr (RTAB) {
+        for (unsigned b = t; b < 256u; b += blockDim.x)
+            reinterpret_cast<float *>(lds_raw)[b] = b ? (float)(8388608.0 / (double)b) : 0.f;     // 2^23 / b to within an ulp: all the corrected quotient needs
+        __syncthreads();                                             // before any wave leaves: every wave of the workgroup gets here
+    }
+    const RcpTable rtab{reinterpret_cast<const char *>(lds_raw)};
+    uint32_t *ring = lds_raw + TAB_DW + wave_in_wg * (2u * ROW_DW + 512u + (AUX ? 512u : 0u));
     vec2 *stage = reinterpret_cast<vec2 *>(ring + 2u * ROW_DW);
     vec2 *stage2 = stage + 128;                   // AUX only
     // XCD-aware item order: the dispatcher deals workgroups round-robin over the 8 XCDs (blocks b and b + 8 share
@@ -932,7 +961,7 @@ __global__ __launch_bounds__(256) void slx_strip_kernel(const SlxKParams p)
                     const f32x2 kUp = {0x1p126f, 0x1p126f};
                     const F32x2x2 px = wrapped_pix_from_diffs<true>(
                         F32x2x2{f32x2{byte_diff_denorm<0>(w0, w2), byte_diff_denorm<1>(w0, w2)} * kUp, f32x2{byte_diff_denorm<2>(w0, w2), byte_diff_denorm<3>(w0, w2)} * kUp},
-                        F32x2x2{f32x2{byte_diff_denorm<0>(w1, w3), byte_diff_denorm<1>(w1, w3)} * kUp, f32x2{byte_diff_denorm<2>(w1, w3), byte_diff_denorm<3>(w1, w3)} * kUp}, Tf[f]);
+                        F32x2x2{f32x2{byte_diff_denorm<0>(w1, w3), byte_diff_denorm<1>(w1, w3)} * kUp, f32x2{byte_diff_denorm<2>(w1, w3), byte_diff_denorm<3>(w1, w3)} * kUp}, Tf[f], rtab);
                     pix[f][0] = px.a.x;
                     pix[f][1] = px.a.y;
                     pix[f][2] = px.b.x;
@@ -1434,6 +1463,32 @@ int slx_launch_fused(const SlxKParams &kp_in, int mode, bool aux, int n_sets, in
     kp.plain_order = tn.plain_order ? 1 : 0;
     // <= 32 rows: slx_strip_eligible bounds the 32-bit output offsets for interleave (<= 64) x 32 rows past the tile
     if (tn.strip_rows >= 1 && tn.strip_rows <= 32) rb = (unsigned)tn.strip_rows;
+    // Gray planes ride the DMA ring when there are 6 bits of them (the reference's and config 3's count) and every
+    // plane, in every frame-set of the launch, sits within 2 GiB above the lowest plane; otherwise the kernel reads
+    // them with ordinary loads
+    int gb = 0;
+    if (mode != SLX_MODE_MULTIFREQ && kp.gray_bits == 6 && !tn.gray_plain) {
+        gb = 6;
+        const uint8_t *lo = kp.phase_base;
+        for (int k = 0; k < 12; k++) lo = kp.gray[k] < lo ? kp.gray[k] : lo;
+        const long long delta = (long long)kp.gray_set_stride - (long long)kp.phase_set_stride;
+        for (int k = 0; k < 12; k++) {
+            const long long rel = (long long)(kp.gray[k] - lo);
+            const long long hi = rel + delta * (long long)(n_sets - 1);
+            if (rel >= (1ll << 31) || hi < 0 || hi >= (1ll << 31)) gb = 0;
+        }
+        for (int k = 0; k < kp.n_freq * 4; k++)
+            if ((long long)(kp.phase[k] - lo) >= (1ll << 31)) gb = 0;
+        if (gb) {
+            kp.phase_base = lo;
+            for (int k = 0; k < kp.n_freq * 4; k++) kp.phase_rel[k] = (unsigned)(kp.phase[k] - lo);
+            for (int k = 0; k < 12; k++) kp.gray_rel[k] = (unsigned)(kp.gray[k] - lo);
+            kp.gray_set_delta = delta;
+        }
+    }
+    // LDS per wave: 2 ring slots (max(4 n_freq, 2 gb) planes with 4 steps, 8 planes with 8 steps, 256 B each) + 2 KiB of depth staging
+    const unsigned ring_planes = kp.n_steps == 4 ? std::max((unsigned)kp.n_freq * 4u, 2u * (unsigned)gb) : 8u;
+    const unsigned lds_wave = 2u * ring_planes * 256u + 2048u + (aux ? 2048u : 0u);      // + the optional planes' staging area
     // Tiers: the head of every frame-set in items of rb rows, then shorter items (a quarter of the previous tier's rows)
     // for the last tail_pct % of the rows; with more than two tiers each takes 60 % of what is left, the last one all of
     // it.  Short items run last and cut the end of the launch, where the chip drains for about one item's lifetime.
@@ -1444,7 +1499,16 @@ int slx_launch_fused(const SlxKParams &kp_in, int mode, bool aux, int n_sets, in
     const unsigned rows_group = kp.interleave * rb;
     const unsigned groups = ((unsigned)kp.height + rows_group - 1) / rows_group;
     if (!(rb >= 8 && tail_rb >= 1 && tail_rb < rb && tail_pct > 0 && tail_pct < 100 && groups >= 4)) tiers = 1;
+    // waves per workgroup: as many as keep the most waves resident in the CU's 160 KiB of LDS (16 at most: 4 per SIMD)
+    const unsigned lds_shared = kp.n_steps == 4 ? 1024u : 0u;           // the reciprocal table, one per workgroup
     unsigned waves_per_wg = 4u;
+    {
+        unsigned best = 0;
+        for (unsigned w = 4; w >= 1; w--) {
+            const unsigned resident = std::min(16u, w * (160u * 1024u / (w * lds_wave + lds_shared)));
+            if (resident > best) { best = resident; waves_per_wg = w; }
+        }
+    }
     if (tn.strip_waves >= 1 && tn.strip_waves <= 4) waves_per_wg = (unsigned)tn.strip_waves;
     unsigned long long need_wgs = 0;
     {
@@ -1478,33 +1542,6 @@ int slx_launch_fused(const SlxKParams &kp_in, int mode, bool aux, int n_sets, in
         kp.n_tiers = t;
         need_wgs = first_wg;                                             // the waves past a tier's last item idle
     }
-    // Gray planes ride the DMA ring when there are 6 bits of them (the reference's and config 3's count) and every
-    // plane, in every frame-set of the launch, sits within 2 GiB above the lowest plane; otherwise the kernel reads
-    // them with ordinary loads
-    int gb = 0;
-    if (mode != SLX_MODE_MULTIFREQ && kp.gray_bits == 6 && !tn.gray_plain) {
-        gb = 6;
-        const uint8_t *lo = kp.phase_base;
-        for (int k = 0; k < 12; k++) lo = kp.gray[k] < lo ? kp.gray[k] : lo;
-        const long long delta = (long long)kp.gray_set_stride - (long long)kp.phase_set_stride;
-        for (int k = 0; k < 12; k++) {
-            const long long rel = (long long)(kp.gray[k] - lo);
-            const long long hi = rel + delta * (long long)(n_sets - 1);
-            if (rel >= (1ll << 31) || hi < 0 || hi >= (1ll << 31)) gb = 0;
-        }
-        for (int k = 0; k < kp.n_freq * 4; k++)
-            if ((long long)(kp.phase[k] - lo) >= (1ll << 31)) gb = 0;
-        if (gb) {
-            kp.phase_base = lo;
-            for (int k = 0; k < kp.n_freq * 4; k++) kp.phase_rel[k] = (unsigned)(kp.phase[k] - lo);
-            for (int k = 0; k < 12; k++) kp.gray_rel[k] = (unsigned)(kp.gray[k] - lo);
-            kp.gray_set_delta = delta;
-        }
-    }
-    // LDS per wave: 2 ring slots (max(4 n_freq, 2 gb) planes with 4 steps, 8 planes with 8 steps, 256 B each) + 2 KiB of depth staging
-    const unsigned ring_planes = kp.n_steps == 4 ? std::max((unsigned)kp.n_freq * 4u, 2u * (unsigned)gb) : 8u;
-    const unsigned lds_wave = 2u * ring_planes * 256u + 2048u + (aux ? 2048u : 0u);      // + the optional planes' staging area
-    if (lds_wave * waves_per_wg > 40u * 1024u) return (int)hipErrorInvalidValue;   // 4 workgroups of 4 waves per CU must fit 160 KiB
     const unsigned threads = waves_per_wg * 64u;
     if (need_wgs == 0 || need_wgs >= (1ull << 31)) return (int)hipErrorInvalidValue;
     kernel_fn fn = mode == SLX_MODE_MULTIFREQ ? (kp.n_steps == 8 ? pick_strip<SLX_MODE_MULTIFREQ, 0, 8>(kp.n_freq, aux) : pick_strip<SLX_MODE_MULTIFREQ, 0>(kp.n_freq, aux))
@@ -1512,7 +1549,7 @@ int slx_launch_fused(const SlxKParams &kp_in, int mode, bool aux, int n_sets, in
                        ? (gb ? pick_strip<SLX_MODE_MULTIFREQ_GRAYMASK, 6>(kp.n_freq, aux) : pick_strip<SLX_MODE_MULTIFREQ_GRAYMASK, 0>(kp.n_freq, aux))
                        : (gb ? pick_strip<SLX_MODE_GRAY_PHASE, 6>(1, aux) : pick_strip<SLX_MODE_GRAY_PHASE, 0>(1, aux));
     if (!fn) return (int)hipErrorInvalidValue;
-    size_t lds = (size_t)waves_per_wg * lds_wave;
+    size_t lds = (size_t)waves_per_wg * lds_wave + lds_shared;
     if (tn.lds_pad_kib > 0 && tn.lds_pad_kib <= 128) lds += (size_t)tn.lds_pad_kib * 1024u;   // experiments: lower the occupancy
     if (lds > 160u * 1024u) return (int)hipErrorInvalidValue;
     // operand shapes were validated by the caller (slx_api.cpp: check_launch_shapes) and slx_strip_eligible
