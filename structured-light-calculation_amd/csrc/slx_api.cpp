@@ -448,15 +448,16 @@ static int launch(slx_ctx *ctx, SlxKParams &kp, int n_sets, bool aux, void *stre
     bool al = (c.width % SLX_QUAD) == 0 && (kp.row_stride % 4) == 0 && (kp.phase_set_stride % 4) == 0 && (kp.gray_set_stride % 4) == 0;
     for (int i = 0; i < n_phase; i++) al = al && ptr_aligned(kp.phase[i], 4);
     for (int i = 0; i < n_gray; i++) al = al && ptr_aligned(kp.gray[i], 4);
-    for (const void *o : {(const void *)kp.z, (const void *)kp.x, (const void *)kp.y, (const void *)kp.U, (const void *)kp.pix,
-                          (const void *)kp.gray_out, (const void *)kp.k, (const void *)kp.mask})
-        al = al && ptr_aligned(o, 16);
-    // every plane of every frame-set must start 16-byte aligned too: (set * planes + plane) * out_set_stride elements in
-    auto pitch_ok = [&](const void *o, size_t elem, size_t planes) {
-        return !o || (n_sets == 1 && planes <= 1) || (kp.out_set_stride * elem) % 16 == 0;
+    // stores are 16 bytes wide for the f64 and i32 planes and 4 bytes for the mask: the planes' bases, and the start of every
+    // plane of every frame-set ((set * planes + plane) * out_set_stride elements in), must be aligned accordingly
+    auto plane_ok = [&](const void *o, size_t elem, size_t planes, size_t align) {
+        if (!o) return true;
+        if (!ptr_aligned(o, align)) return false;
+        return (n_sets == 1 && planes <= 1) || (kp.out_set_stride * elem) % align == 0;
     };
-    al = al && pitch_ok(kp.z, 8, 1) && pitch_ok(kp.x, 8, 1) && pitch_ok(kp.y, 8, 1) && pitch_ok(kp.U, 8, 1) && pitch_ok(kp.gray_out, 8, 1) &&
-         pitch_ok(kp.pix, 8, (size_t)kp.n_freq) && pitch_ok(kp.k, 4, (size_t)(kp.n_freq > 1 ? kp.n_freq - 1 : 1)) && pitch_ok(kp.mask, 1, 1);
+    al = al && plane_ok(kp.z, 8, 1, 16) && plane_ok(kp.x, 8, 1, 16) && plane_ok(kp.y, 8, 1, 16) && plane_ok(kp.U, 8, 1, 16) &&
+         plane_ok(kp.gray_out, 8, 1, 16) && plane_ok(kp.pix, 8, (size_t)kp.n_freq, 16) &&
+         plane_ok(kp.k, 4, (size_t)(kp.n_freq > 1 ? kp.n_freq - 1 : 1), 16) && plane_ok(kp.mask, 1, 1, 4);
     kp.aligned = al ? 1 : 0;
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
     SLX_HIP(ctx, hipSetDevice(ctx->device));

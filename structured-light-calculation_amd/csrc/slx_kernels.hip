@@ -170,34 +170,14 @@ __device__ __forceinline__ V pix_from_octant_angle(V a, V mc, V ms, float Tf)
 // under a power-of-two scale that stays inside the normal range -- max/min/compare, v_rcp_f32 (a function of the
 // mantissa), the quotient and its residual, the sign tests -- so the result is the same bit for bit; only the
 // 0/0 guard and the saturation factor of the sign tests move with the scale.
-// Reciprocal of the larger difference, two ways.  RcpUnit: v_rcp_f32 (8 issue cycles per pixel).  RcpTable: the larger
-// difference is an integer b in [1, 255] (times 2^-23), so 1/b comes out of a 255-entry table in LDS -- the LDS port is
-// idle in this kernel, the VALU is what binds it.  The table index costs one 2-cycle multiply: b 2^-23 * 2^-124 is the
-// denormal whose BIT PATTERN is the integer 4 b, the entry's byte offset.  Any faithfully rounded reciprocal gives the same
-// corrected quotient (see the identities above): the table's entries are the double quotient rounded to float.
-struct RcpUnit {
-    __device__ __forceinline__ f32x2 operator()(f32x2 x) const { return v_rcp(x); }
-    __device__ __forceinline__ F32x2x2 operator()(F32x2x2 x) const { return v_rcp(x); }
-};
-struct RcpTable {
-    const char *table;                                               // LDS, entry b at byte 4 b: 2^23 / b
-    __device__ __forceinline__ float one(float x) const
-    {
-        const unsigned off = __builtin_bit_cast(unsigned, x * 0x1p-124f);
-        return *reinterpret_cast<const float *>(table + off);
-    }
-    __device__ __forceinline__ f32x2 operator()(f32x2 x) const { return {one(x.x), one(x.y)}; }
-    __device__ __forceinline__ F32x2x2 operator()(F32x2x2 x) const { return {(*this)(x.a), (*this)(x.b)}; }
-};
-
-template <bool SCALED, typename V, typename RCP = RcpUnit>
-__device__ __forceinline__ V wrapped_pix_from_diffs(V s2, V c2, float Tf, RCP rcp = RCP())
+template <bool SCALED, typename V>
+__device__ __forceinline__ V wrapped_pix_from_diffs(V s2, V c2, float Tf)
 {
     constexpr float kGuard = SCALED ? 0x1p-23f : 1.0f;
     const V as = v_abs(s2), ac = v_abs(c2);
     const V mx = v_max3(as, ac, kGuard);
     const V mn = v_min(as, ac);
-    const V r = rcp(mx);
+    const V r = v_rcp(mx);
     const V q0 = mn * r;
     const V c = v_fma(v_fma(-mx, q0, mn), r, q0);                   // RN(mn / mx)
     const V cc = c * c;
@@ -740,16 +720,7 @@ __global__ __launch_bounds__(256) void slx_strip_kernel(const SlxKParams p)
     // wave-uniform by construction; readfirstlane tells hipcc so (scalar addressing, M0 straight from
     // an SGPR, no waterfall loops around the buffer descriptor)
     const unsigned wave_in_wg = __builtin_amdgcn_readfirstlane(t >> 6);
-    // [0, 1 KiB): the reciprocal table of the 4-step wrapped phase, one per workgroup; then the waves' areas
-    constexpr bool RTAB = NS == 4;
-    constexpr unsigned TAB_DW = RTAB ? 256u : 0u;
-    if constexpr (RTAB) {
-        for (unsigned b = t; b < 256u; b += blockDim.x)
-            reinterpret_cast<float *>(lds_raw)[b] = b ? (float)(8388608.0 / (double)b) : 0.f;     // 2^23 / b to within an ulp: all the corrected quotient needs
-        __syncthreads();                                             // before any wave leaves: every wave of the workgroup gets here
-    }
-    const RcpTable rtab{reinterpret_cast<const char *>(lds_raw)};
-    uint32_t *ring = lds_raw + TAB_DW + wave_in_wg * (2u * ROW_DW + 512u + (AUX ? 512u : 0u));
+    uint32_t *ring = lds_raw + wave_in_wg * (2u * ROW_DW + 512u + (AUX ? 512u : 0u));
     vec2 *stage = reinterpret_cast<vec2 *>(ring + 2u * ROW_DW);
     vec2 *stage2 = stage + 128;                   // AUX only
     // XCD-aware item order: the dispatcher deals workgroups round-robin over the 8 XCDs (blocks b and b + 8 share
@@ -961,7 +932,7 @@ __global__ __launch_bounds__(256) void slx_strip_kernel(const SlxKParams p)
                     const f32x2 kUp = {0x1p126f, 0x1p126f};
                     const F32x2x2 px = wrapped_pix_from_diffs<true>(
                         F32x2x2{f32x2{byte_diff_denorm<0>(w0, w2), byte_diff_denorm<1>(w0, w2)} * kUp, f32x2{byte_diff_denorm<2>(w0, w2), byte_diff_denorm<3>(w0, w2)} * kUp},
-                        F32x2x2{f32x2{byte_diff_denorm<0>(w1, w3), byte_diff_denorm<1>(w1, w3)} * kUp, f32x2{byte_diff_denorm<2>(w1, w3), byte_diff_denorm<3>(w1, w3)} * kUp}, Tf[f], rtab);
+                        F32x2x2{f32x2{byte_diff_denorm<0>(w1, w3), byte_diff_denorm<1>(w1, w3)} * kUp, f32x2{byte_diff_denorm<2>(w1, w3), byte_diff_denorm<3>(w1, w3)} * kUp}, Tf[f]);
                     pix[f][0] = px.a.x;
                     pix[f][1] = px.a.y;
                     pix[f][2] = px.b.x;
@@ -1500,7 +1471,7 @@ int slx_launch_fused(const SlxKParams &kp_in, int mode, bool aux, int n_sets, in
     const unsigned groups = ((unsigned)kp.height + rows_group - 1) / rows_group;
     if (!(rb >= 8 && tail_rb >= 1 && tail_rb < rb && tail_pct > 0 && tail_pct < 100 && groups >= 4)) tiers = 1;
     // waves per workgroup: as many as keep the most waves resident in the CU's 160 KiB of LDS (16 at most: 4 per SIMD)
-    const unsigned lds_shared = kp.n_steps == 4 ? 1024u : 0u;           // the reciprocal table, one per workgroup
+    const unsigned lds_shared = 0u;                                     // nothing is shared between the waves of a workgroup
     unsigned waves_per_wg = 4u;
     {
         unsigned best = 0;
