@@ -743,13 +743,21 @@ int slx_track_next(slx_ctx *ctx, const uint8_t *image, size_t stride_bytes, int 
     std::swap(curB, ctx->d_stripB_prev);
     ctx->out[SLX_OUT_STRIPW] = curW;
     ctx->out[SLX_OUT_STRIPB] = curB;
-    // (the kernel writes every pixel of both planes, zeros outside the interior)
-    int e = slx_launch_strip_regression(img, istride, c.width, c.height, ctx->track_window, curW, curB, ctx->stream, ctx->d_stripW_prev,
+    // (the kernels write every pixel of both planes, zeros outside the interior)
+    int e;
+    const bool divisors_in_range = std::fabs(ctx->kp.fu) > 0x1p-90 && std::fabs(ctx->kp.fv) > 0x1p-90 && slx_fast_arith_ok(ctx->kp);
+    if (divisors_in_range && slx_track_fusable(c.width, c.height, ctx->track_window)) {
+        e = slx_launch_track_fused(ctx->kp, img, istride, curW, curB, ctx->d_stripW_prev, ctx->d_stripB_prev, (float *)ctx->out[SLX_OUT_DELTAP],
+                                   (double *)ctx->out[SLX_OUT_U], (double *)ctx->out[SLX_OUT_Z], (double *)ctx->out[SLX_OUT_X],
+                                   (double *)ctx->out[SLX_OUT_Y], (double *)ctx->out[SLX_OUT_DELTAZ], ctx->stream);
+    } else {
+        e = slx_launch_strip_regression(img, istride, c.width, c.height, ctx->track_window, curW, curB, ctx->stream, ctx->d_stripW_prev,
                                         ctx->d_stripB_prev, ctx->d_deltaP_raw);
-    if (e == 0)
-        e = slx_launch_track_update(ctx->kp, ctx->d_deltaP_raw, (float *)ctx->out[SLX_OUT_DELTAP], (double *)ctx->out[SLX_OUT_U],
-                                    (double *)ctx->out[SLX_OUT_Z], (double *)ctx->out[SLX_OUT_X], (double *)ctx->out[SLX_OUT_Y],
-                                    (double *)ctx->out[SLX_OUT_DELTAZ], ctx->stream);
+        if (e == 0)
+            e = slx_launch_track_update(ctx->kp, ctx->d_deltaP_raw, (float *)ctx->out[SLX_OUT_DELTAP], (double *)ctx->out[SLX_OUT_U],
+                                        (double *)ctx->out[SLX_OUT_Z], (double *)ctx->out[SLX_OUT_X], (double *)ctx->out[SLX_OUT_Y],
+                                        (double *)ctx->out[SLX_OUT_DELTAZ], ctx->stream);
+    }
     if (e != 0) return hip_fail(ctx, (hipError_t)e, "dynamic-frame kernels");
     if (slot >= 0) SLX_HIP(ctx, hipEventRecord(ctx->ev_track_used[slot], ctx->stream));
     return mark_done(ctx, ctx->stream);

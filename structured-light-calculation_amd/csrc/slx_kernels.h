@@ -91,6 +91,10 @@ int slx_launch_strip_regression(const uint8_t *cam, size_t stride, int W, int H,
 int slx_launch_delta_p(const float *W0, const float *B0, const float *W1, const float *B1, size_t n, float *raw, void *stream);
 int slx_launch_track_update(const SlxKParams &kp, const float *raw, float *deltaP, double *U, double *z, double *x, double *y, double *deltaZ,
                             void *stream);
+// One dynamic frame in one launch (window 21, images larger than the window): strips, deltaP selection, blur, U, depth, deltaZ.
+bool slx_track_fusable(int W, int H, int win);
+int slx_launch_track_fused(const SlxKParams &kp, const uint8_t *cam, size_t stride, float *stripW, float *stripB, const float *prevW, const float *prevB,
+                           float *deltaP, double *U, double *z, double *x, double *y, double *deltaZ, void *stream);
 
 // True when the strip kernel can run this configuration / these operands.
 bool slx_strip_eligible(const SlxKParams &kp, int mode, bool aux);

@@ -18,6 +18,7 @@
 
 #include <algorithm>
 
+#include "slx_device.h"
 #include "slx_kernels.h"
 
 #pragma clang fp contract(off)
@@ -229,24 +230,6 @@ __device__ __forceinline__ double div_f64_inrange(double num, double den)
     r = __builtin_fma(r, __builtin_fma(-den, r, 1.0), r);
     const double q = num * r;
     return __builtin_fma(__builtin_fma(-den, q, num), r, q);
-}
-
-// n / d for a divisor that is constant over the item: r = the refined reciprocal of d (v_rcp_f64 + two Newton steps, the
-// first half of div_f64_inrange, computed once), then the same quotient + residual correction.  Bit-identical to the
-// IEEE division whenever no scaling would occur; a NaN out of a non-NaN numerator (overflow of n * r) and a zero quotient
-// (whose sign the correction step would lose, and which also covers an underflowing one) take the literal division.
-__device__ __forceinline__ double refined_rcp_f64(double d)
-{
-    double r = __builtin_amdgcn_rcp(d);
-    r = __builtin_fma(r, __builtin_fma(-d, r, 1.0), r);
-    return __builtin_fma(r, __builtin_fma(-d, r, 1.0), r);
-}
-__device__ __forceinline__ double div_by_item_const(double n, double d, double r)
-{
-    const double q = n * r;
-    double o = __builtin_fma(__builtin_fma(-d, q, n), r, q);
-    if (__builtin_expect((o != o) | (__builtin_fabs(o) < 0x1p-900), 0)) o = n / d;
-    return o;
 }
 
 // a7 for one pixel: z = -(cA - cB U)/(cC - cD U), FOV clamp, U == 0 / mask -> 0.
@@ -844,8 +827,8 @@ __global__ __launch_bounds__(256) void slx_strip_kernel(const SlxKParams p)
         const bool own = lane_valid && (!MASKED || (lane >= 1u && lane <= 62u));
         own_px = own ? pos.row * W + pos.cq * SLX_QUAD : 0x3FFFFFFCu;   // x 4 bytes still fits 32 bits and stays out of range
         own_step = own ? step_rows * W : 0u;
-        rfu = refined_rcp_f64(p.fu);
-        rfv = refined_rcp_f64(p.fv);
+        rfu = slx_refined_rcp_f64(p.fu);
+        rfv = slx_refined_rcp_f64(p.fv);
     }
 
     // a6, column part: a = (u - cx)*fv ; aC = a*P00 ; aD = a*P20
@@ -1094,8 +1077,8 @@ __global__ __launch_bounds__(256) void slx_strip_kernel(const SlxKParams p)
 #pragma unroll
             for (int j = 0; j < SLX_QUAD; j++) {
                 const double uc = (double)(int)(pos.cq * SLX_QUAD + j) - p.cx;
-                xo[j] = div_by_item_const(z[j] * uc, p.fu, rfu);
-                yo[j] = div_by_item_const(z[j] * vc, p.fv, rfv);
+                xo[j] = slx_div_item_const(z[j] * uc, p.fu, rfu);
+                yo[j] = slx_div_item_const(z[j] * vc, p.fv, rfv);
             }
             const unsigned sl = MASKED ? lane - 1u : lane;
             const bool holds = !MASKED || (lane >= 1u && lane <= 62u);

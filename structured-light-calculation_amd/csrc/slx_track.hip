@@ -8,6 +8,7 @@
 // R/ = DynaFrame/DynaFrame/ of the reference repository.
 #include <hip/hip_runtime.h>
 
+#include "slx_device.h"
 #include "slx_kernels.h"
 
 #pragma clang fp contract(off)
@@ -194,6 +195,119 @@ __global__ __launch_bounds__(256) void slx_track_update_kernel(const float *raw,
     if (y) y[i] = zz * vc / p.fv;
 }
 
+// One dynamic frame in ONE launch (the reference's window, HW = 10): StripRegression(fN), the deltaP selection against the
+// previous frame's strips, cv::blur 3x3, U += deltaP, FillCoordinate(fN) and deltaZ.  The unblurred deltaP never goes to
+// HBM: a workgroup computes it for its band of kFusedRows rows plus one halo row above and below and one halo column either
+// side (the strips of those halo pixels are computed a second time by the neighbouring workgroup: 25 % more scan work for
+// 8 bytes per pixel less traffic and one launch less), keeps it in LDS, and blurs from there.
+//   phase 1  a lane per column: the 30 image bytes its column contributes to the 10 rows' sliding sums -> sums in LDS
+//   phase 2  236 lanes: the +-10 scan of every row (max3 / min3 over keys, as in the band kernel), strips out for the pixels
+//            this workgroup owns, deltaP selection -> LDS
+//   phase 3  234 lanes: 3x3 box sum from LDS (BORDER_REFLECT_101 at the image border), U, depth, x, y, deltaZ
+// a7's second pass divides by the constants fu, fv: the refined reciprocal is formed once, the quotient takes the residual
+// correction of the IEEE sequence, and anything that sequence cannot do unscaled (zero / NaN) goes to the literal division.
+constexpr int kFusedRows = 8;
+
+template <int HW>
+__global__ __launch_bounds__(kTile) void slx_track_fused_kernel(const uint8_t *cam, size_t stride, float *stripW, float *stripB, const float *prevW,
+                                                                const float *prevB, float *deltaP, double *U, double *z, double *x, double *y,
+                                                                double *deltaZ, const SlxKParams p)
+{
+    static_assert(2 * HW <= 31, "the neighbour rank must fit 5 bits");
+    constexpr int OUT = kTile - 2 * HW - 2;                          // output columns per workgroup
+    constexpr int RR = kFusedRows + 2;                               // rows of unblurred deltaP a band needs
+    __shared__ uint32_t sums[RR][kTile];
+    __shared__ float rawt[RR][kTile];
+    const int W = p.width, H = p.height;
+    const int tx = threadIdx.x;
+    const int c = (int)blockIdx.x * OUT + tx - (HW + 1);             // image column of this lane
+    const int r0 = (int)blockIdx.y * kFusedRows;
+    const int r1 = r0 + kFusedRows < H ? r0 + kFusedRows : H;
+    const int ra = r0 - 1;                                           // image row of tile row 0
+    const bool col_in = c >= 0 && c < W;
+    const bool col_interior = c >= HW && c < W - HW;                 // valSum is 0 elsewhere
+    const int ha = ra > HW ? ra : HW, hb = ra + RR < H - HW ? ra + RR : H - HW;   // interior rows of the tile: [ha, hb)
+    if (ha < hb) {
+        uint32_t b[RR + 2 * HW];
+#pragma unroll
+        for (int k = 0; k < RR + 2 * HW; k++) {
+            const int r = ha - HW + k;
+            b[k] = (col_interior && r < hb + HW) ? cam[(size_t)r * stride + c] : 0u;
+        }
+        uint32_t sum = 0;
+#pragma unroll
+        for (int k = 0; k <= 2 * HW; k++) sum += b[k];
+#pragma unroll
+        for (int j = 0; j < RR; j++) {
+            sums[j][tx] = sum << 5;                                  // row ha + j; 0 outside the interior columns
+            if (j + 1 < RR) sum = sum - b[j] + b[j + 2 * HW + 1];
+        }
+    }
+    __syncthreads();
+    const bool scans = tx >= HW && tx < kTile - HW;
+    const bool owns_col = tx >= HW + 1 && tx < kTile - HW - 1 && c < W;
+#pragma unroll
+    for (int j = 0; j < RR; j++) {
+        const int h = ra + j;
+        float r = 0.f;
+        if (scans && col_in && h >= 0 && h < H) {
+            float mxi = 0.f, mni = 0.f;
+            if (col_interior && h >= ha && h < hb) {
+                const uint32_t *row = &sums[h - ha][tx];
+                uint32_t kmax = row[0] | (uint32_t)(2 * HW), kmin = row[0];
+#pragma unroll
+                for (int i = -HW; i < HW; i += 2) {
+                    const uint32_t s0 = row[i], s1 = row[i + 1];
+                    const uint32_t w0 = s0 | (uint32_t)(HW - 1 - i), w1 = s1 | (uint32_t)(HW - 2 - i);
+                    const uint32_t k0 = s0 | (uint32_t)(i + HW + 1), k1 = s1 | (uint32_t)(i + HW + 2);
+                    kmax = max(max(kmax, w0), w1);
+                    kmin = min(min(kmin, k0), k1);
+                }
+                const int pw = (int)(kmax & 31u), q = (int)(kmin & 31u);
+                mxi = pw == 2 * HW ? 0.f : (float)(HW - 1 - pw);
+                mni = q == 0 ? 0.f : (float)(q - HW - 1);
+            }
+            const size_t o = (size_t)h * W + c;
+            if (owns_col && h >= r0 && h < r1) {
+                stripB[o] = mni;
+                stripW[o] = mxi;
+            }
+            const float dB = prevB[o] - mni, dW = prevW[o] - mxi;    // R/CCalculation.cpp:602-617
+            r = (__builtin_fabsf(dB) < __builtin_fabsf(dW)) ? dB : dW;
+        }
+        rawt[j][tx] = r;
+    }
+    __syncthreads();
+    if (!owns_col) return;
+    const double uc = (double)c - p.cx;
+    const double aC = (uc * p.fv) * p.P00, aD = (uc * p.fv) * p.P20;
+    const double rfu = slx_refined_rcp_f64(p.fu), rfv = slx_refined_rcp_f64(p.fv);
+    const int dl = c - 1 < 0 ? 1 : -1, dr = c + 1 >= W ? -1 : 1;     // BORDER_REFLECT_101: column -1 is column 1, column W is column W-2
+#pragma unroll
+    for (int j = 1; j <= kFusedRows; j++) {
+        const int v = ra + j;
+        if (v >= r1) break;
+        const int ju = v - 1 < 0 ? j + 1 : j - 1, jd = v + 1 >= H ? j - 1 : j + 1;
+        double s = 0.0;                                              // sums of small integers: exact in any order
+        for (int jj : {ju, j, jd}) s += ((double)rawt[jj][tx + dl] + (double)rawt[jj][tx]) + (double)rawt[jj][tx + dr];
+        const float dp = (float)(s * (1. / 9));                     // cv::blur: the box sum times 1./9 (:650)
+        const size_t i = (size_t)v * W + c;
+        deltaP[i] = dp;
+        const double Uv = U[i] + (double)dp;                        // :656-658
+        U[i] = Uv;
+        const double vc = (double)(v + p.row_offset) - p.cy;
+        const double cC = (aC + (vc * p.fu) * p.P01) + p.K1;
+        const double cD = (aD + (vc * p.fu) * p.P21) + p.K2;
+        double zz = -(p.cA - p.cB * Uv) / (cC - cD * Uv);
+        if ((zz < p.fov_min) || (zz > p.fov_max)) zz = 0.0;
+        if (Uv == 0.0) zz = 0.0;                                     // the reference leaves z untouched here; defined 0
+        deltaZ[i] = zz - z[i];                                       // :772-775
+        z[i] = zz;
+        if (x) x[i] = slx_div_item_const(zz * uc, p.fu, rfu);           // :766
+        if (y) y[i] = slx_div_item_const(zz * vc, p.fv, rfv);           // :767
+    }
+}
+
 }  // namespace
 
 static int slx_launch_strip_regression_only(const uint8_t *cam, size_t stride, int W, int H, int win, float *stripW, float *stripB, void *stream,
@@ -239,5 +353,17 @@ int slx_launch_track_update(const SlxKParams &kp, const float *raw, float *delta
 {
     const dim3 grid((unsigned)((kp.width + 63) / 64), (unsigned)((kp.height + 3) / 4));
     hipLaunchKernelGGL(slx_track_update_kernel, grid, dim3(256), 0, (hipStream_t)stream, raw, deltaP, U, z, x, y, deltaZ, kp);
+    return (int)hipGetLastError();
+}
+
+bool slx_track_fusable(int W, int H, int win) { return win / 2 == 10 && (win & 1) && H > 20 && W > 20; }
+
+int slx_launch_track_fused(const SlxKParams &kp, const uint8_t *cam, size_t stride, float *stripW, float *stripB, const float *prevW, const float *prevB,
+                           float *deltaP, double *U, double *z, double *x, double *y, double *deltaZ, void *stream)
+{
+    constexpr int out_cols = kTile - 2 * 10 - 2;
+    const dim3 grid((unsigned)((kp.width + out_cols - 1) / out_cols), (unsigned)((kp.height + kFusedRows - 1) / kFusedRows));
+    hipLaunchKernelGGL(slx_track_fused_kernel<10>, grid, dim3(kTile), 0, (hipStream_t)stream, cam, stride, stripW, stripB, prevW, prevB, deltaP, U, z, x, y,
+                       deltaZ, kp);
     return (int)hipGetLastError();
 }

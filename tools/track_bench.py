@@ -18,6 +18,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--size", default="1920x1200")
 ap.add_argument("--frames", type=int, default=60)
 ap.add_argument("--window", type=int, default=21)
+ap.add_argument("--host", action="store_true", help="feed the camera images from host memory (numpy): the pinned double-buffered path of slx_track_next")
 a = ap.parse_args()
 W, H = (int(v) for v in a.size.split("x"))
 spec = dict(synth.make_spec("REF"))
@@ -25,6 +26,8 @@ spec["width"], spec["height"] = W, H
 spec["calib"] = synth.scaled_calibration(W, H, spec["proj_width"])
 ph, gr, _ = synth.render(spec, "sphere", seed=9, noise_sigma=1.0)
 imgs = [torch.randint(0, 256, (H, W), dtype=torch.uint8, device="cuda") for _ in range(4)]
+if a.host:
+    imgs = [i.cpu().numpy() for i in imgs]
 with api.Context(spec, aux=("U", "x", "y")) as ctx:
     ctx.set_frames(phase=ph, gray=gr)
     ctx.decode()
@@ -41,9 +44,10 @@ with api.Context(spec, aux=("U", "x", "y")) as ctx:
         ctx.track_next(imgs[i % 4])
     ctx.synchronize()
     dt = (time.perf_counter() - t0) / a.frames
-# algorithmic bytes per pixel of one frame: image 1; strips W,B written 8; previous strips read 8, raw deltaP written 4;
-# update: raw deltaP 4, U 8 read + 8 written, deltaP 4 written, z 8 read, z/x/y 24 written, deltaZ 8 written
-bytes_px = 1 + 8 + 8 + 4 + 4 + 8 + 8 + 4 + 8 + 24 + 8
-print(json.dumps({"metric": "dynamic frames/s (slx_track_next)", "size": a.size, "window": a.window, "frames": a.frames,
+# algorithmic bytes per pixel of one frame: image 1; strips W,B written 8; previous strips read 8; U 8 read + 8 written;
+# deltaP 4 written; z 8 read; z/x/y 24 written; deltaZ 8 written.  (The unblurred deltaP stays in LDS in the one-launch
+# kernel of the 21-pixel window; other windows take two launches and move 8 more bytes per pixel.)
+bytes_px = 1 + 8 + 8 + 8 + 8 + 4 + 8 + 24 + 8
+print(json.dumps({"metric": "dynamic frames/s (slx_track_next)", "size": a.size, "window": a.window, "images": "host (pinned double buffer)" if a.host else "device", "frames": a.frames,
                   "value": 1.0 / dt, "us_per_frame": dt * 1e6, "algorithmic_bytes_per_pixel": bytes_px,
                   "achieved_GBps": bytes_px * W * H / dt / 1e9}))
