@@ -40,9 +40,12 @@ struct slx_ctx {
     bool timed = false;
     // Completion of the most recent work that wrote the context's outputs or read its staged inputs, on whatever stream it
     // ran (the context's own or a caller's): what a later host copy / staging overwrite / launch on another stream waits for.
+    // Work on the context's own stream needs no event: the stream itself can be waited for, and an event is recorded on it
+    // only when another stream has to be ordered behind it (a per-launch record would cost a packet between dependent launches).
     hipEvent_t ev_done = nullptr;
-    hipStream_t ev_stream = nullptr;           // the stream ev_done was recorded on
-    bool ev_pending = false;
+    hipStream_t ev_stream = nullptr;           // the caller stream ev_done was recorded on
+    bool ev_pending = false;                   // the most recent work ran on a caller's stream and ev_done marks its end
+    bool own_pending = false;                  // the most recent work ran on the context's own stream
     std::vector<int16_t> lut;
     int16_t *d_lut = nullptr;
     std::vector<Plane> phase, gray;
@@ -229,19 +232,32 @@ bool ptr_aligned(const void *p, size_t a) { return (reinterpret_cast<uintptr_t>(
 // The three uses of ev_done (see slx_ctx).
 int mark_done(slx_ctx *ctx, hipStream_t s)
 {
+    if (s == ctx->stream) {
+        ctx->own_pending = true;               // (ordered behind any earlier caller-stream work by order_after_done)
+        ctx->ev_pending = false;
+        return SLX_OK;
+    }
     SLX_HIP(ctx, hipEventRecord(ctx->ev_done, s));
     ctx->ev_stream = s;
     ctx->ev_pending = true;
+    ctx->own_pending = false;
     return SLX_OK;
 }
 int wait_done_host(slx_ctx *ctx)
 {
-    if (ctx->ev_pending) SLX_HIP(ctx, hipEventSynchronize(ctx->ev_done));
+    if (ctx->own_pending) SLX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    else if (ctx->ev_pending) SLX_HIP(ctx, hipEventSynchronize(ctx->ev_done));
     return SLX_OK;
 }
 int order_after_done(slx_ctx *ctx, hipStream_t s)
 {
-    if (ctx->ev_pending && s != ctx->ev_stream) SLX_HIP(ctx, hipStreamWaitEvent(s, ctx->ev_done, 0));   // same stream: already ordered
+    if (ctx->own_pending) {
+        if (s == ctx->stream) return SLX_OK;   // same stream: already ordered
+        SLX_HIP(ctx, hipEventRecord(ctx->ev_done, ctx->stream));
+        SLX_HIP(ctx, hipStreamWaitEvent(s, ctx->ev_done, 0));
+    } else if (ctx->ev_pending && s != ctx->ev_stream) {
+        SLX_HIP(ctx, hipStreamWaitEvent(s, ctx->ev_done, 0));
+    }
     return SLX_OK;
 }
 
@@ -275,6 +291,7 @@ void slx_destroy(slx_ctx *ctx)
         if (o) (void)hipFree(o);
     if (ctx->d_lut) (void)hipFree(ctx->d_lut);
     if (ctx->ev_pending) (void)hipEventSynchronize(ctx->ev_done);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
     for (void *q : {(void *)ctx->d_cloud_counts, (void *)ctx->d_cloud_offsets, (void *)ctx->d_cloud, (void *)ctx->d_stripW_prev,
                     (void *)ctx->d_stripB_prev, (void *)ctx->d_deltaP_raw, (void *)ctx->d_track_img[0], (void *)ctx->d_track_img[1]})

@@ -246,11 +246,13 @@ __global__ __launch_bounds__(kTile) void slx_track_fused_kernel(const uint8_t *c
     __syncthreads();
     const bool scans = tx >= HW && tx < kTile - HW;
     const bool owns_col = tx >= HW + 1 && tx < kTile - HW - 1 && c < W;
-#pragma unroll
-    for (int j = 0; j < RR; j++) {
+    // strips and deltaP selection of tile row j (image row ra + j) -> rawt[j]
+    auto scan_row = [&](int j) {
         const int h = ra + j;
         float r = 0.f;
         if (scans && col_in && h >= 0 && h < H) {
+            const size_t o = (size_t)h * W + c;
+            const float pB = prevB[o], pW = prevW[o];                // issued first: their latency hides behind the scan
             float mxi = 0.f, mni = 0.f;
             if (col_interior && h >= ha && h < hb) {
                 const uint32_t *row = &sums[h - ha][tx];
@@ -267,33 +269,43 @@ __global__ __launch_bounds__(kTile) void slx_track_fused_kernel(const uint8_t *c
                 mxi = pw == 2 * HW ? 0.f : (float)(HW - 1 - pw);
                 mni = q == 0 ? 0.f : (float)(q - HW - 1);
             }
-            const size_t o = (size_t)h * W + c;
             if (owns_col && h >= r0 && h < r1) {
                 stripB[o] = mni;
                 stripW[o] = mxi;
             }
-            const float dB = prevB[o] - mni, dW = prevW[o] - mxi;    // R/CCalculation.cpp:602-617
+            const float dB = pB - mni, dW = pW - mxi;                // R/CCalculation.cpp:602-617
             r = (__builtin_fabsf(dB) < __builtin_fabsf(dW)) ? dB : dW;
         }
         rawt[j][tx] = r;
-    }
-    __syncthreads();
-    if (!owns_col) return;
+    };
     const double uc = (double)c - p.cx;
     const double aC = (uc * p.fv) * p.P00, aD = (uc * p.fv) * p.P20;
     const double rfu = slx_refined_rcp_f64(p.fu), rfv = slx_refined_rcp_f64(p.fv);
     const int dl = c - 1 < 0 ? 1 : -1, dr = c + 1 >= W ? -1 : 1;     // BORDER_REFLECT_101: column -1 is column 1, column W is column W-2
+    // Row by row: the scan of row j+1 and the output of row j alternate, so that a workgroup's loads and stores are spread
+    // over its lifetime instead of coming in one burst at the end (every workgroup of a frame is resident at once and they all
+    // run the same timeline: phases would otherwise line up across the whole chip).
+    scan_row(0);
+    scan_row(1);
 #pragma unroll
     for (int j = 1; j <= kFusedRows; j++) {
-        const int v = ra + j;
+        const int v = ra + j;                                        // uniform over the workgroup
         if (v >= r1) break;
+        const size_t i = (size_t)v * W + (owns_col ? c : 0);
+        double Uin = 0.0, zin = 0.0;
+        if (owns_col) {                                              // this row's inputs, in flight during the scan below
+            Uin = U[i];
+            zin = z[i];
+        }
+        scan_row(j + 1);
+        __syncthreads();                                             // rows j-1 .. j+1 of rawt are complete; no row is ever rewritten
+        if (!owns_col) continue;
         const int ju = v - 1 < 0 ? j + 1 : j - 1, jd = v + 1 >= H ? j - 1 : j + 1;
         double s = 0.0;                                              // sums of small integers: exact in any order
         for (int jj : {ju, j, jd}) s += ((double)rawt[jj][tx + dl] + (double)rawt[jj][tx]) + (double)rawt[jj][tx + dr];
         const float dp = (float)(s * (1. / 9));                     // cv::blur: the box sum times 1./9 (:650)
-        const size_t i = (size_t)v * W + c;
         deltaP[i] = dp;
-        const double Uv = U[i] + (double)dp;                        // :656-658
+        const double Uv = Uin + (double)dp;                         // :656-658
         U[i] = Uv;
         const double vc = (double)(v + p.row_offset) - p.cy;
         const double cC = (aC + (vc * p.fu) * p.P01) + p.K1;
@@ -301,10 +313,10 @@ __global__ __launch_bounds__(kTile) void slx_track_fused_kernel(const uint8_t *c
         double zz = -(p.cA - p.cB * Uv) / (cC - cD * Uv);
         if ((zz < p.fov_min) || (zz > p.fov_max)) zz = 0.0;
         if (Uv == 0.0) zz = 0.0;                                     // the reference leaves z untouched here; defined 0
-        deltaZ[i] = zz - z[i];                                       // :772-775
+        deltaZ[i] = zz - zin;                                        // :772-775
         z[i] = zz;
-        if (x) x[i] = slx_div_item_const(zz * uc, p.fu, rfu);           // :766
-        if (y) y[i] = slx_div_item_const(zz * vc, p.fv, rfv);           // :767
+        if (x) x[i] = slx_div_item_const(zz * uc, p.fu, rfu);        // :766
+        if (y) y[i] = slx_div_item_const(zz * vc, p.fv, rfv);        // :767
     }
 }
 
