@@ -24,7 +24,7 @@ thread_local std::string g_create_error;
 
 struct Plane {
     const uint8_t *dev = nullptr;   // what the kernel reads
-    uint8_t *owned = nullptr;       // staging buffer for host frames (deep copy)
+    uint8_t *owned = nullptr;       // staging area for host frames (deep copy): this plane's part of its group's slab
     size_t stride = 0;
     bool set = false;
 };
@@ -49,6 +49,9 @@ struct slx_ctx {
     std::vector<int16_t> lut;
     int16_t *d_lut = nullptr;
     std::vector<Plane> phase, gray;
+    // host frames are staged in ONE allocation per group, plane k at k * staging_pitch * height: equally spaced planes are
+    // what the strip kernel's running plane offsets address
+    uint8_t *phase_slab = nullptr, *gray_slab = nullptr;
     unsigned *d_cloud_counts = nullptr, *d_cloud_offsets = nullptr;   // slx_cloud_entries() + 1 each, point-cloud compaction
     double *d_cloud = nullptr;
     size_t cloud_capacity = 0;
@@ -284,9 +287,8 @@ void slx_destroy(slx_ctx *ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-    for (auto *v : {&ctx->phase, &ctx->gray})
-        for (Plane &p : *v)
-            if (p.owned) (void)hipFree(p.owned);
+    if (ctx->phase_slab) (void)hipFree(ctx->phase_slab);
+    if (ctx->gray_slab) (void)hipFree(ctx->gray_slab);
     for (void *o : ctx->out)
         if (o) (void)hipFree(o);
     if (ctx->d_lut) (void)hipFree(ctx->d_lut);
@@ -429,7 +431,12 @@ int slx_set_frame(slx_ctx *ctx, int group, int idx, const uint8_t *data, size_t 
         p.dev = data;
         p.stride = stride_bytes;
     } else {
-        if (!p.owned) SLX_HIP(ctx, hipMalloc((void **)&p.owned, ctx->staging_pitch * (size_t)ctx->cfg.height));
+        if (!p.owned) {
+            uint8_t *&slab = group == SLX_GROUP_GRAY ? ctx->gray_slab : ctx->phase_slab;
+            const size_t plane_bytes = ctx->staging_pitch * (size_t)ctx->cfg.height;
+            if (!slab) SLX_HIP(ctx, hipMalloc((void **)&slab, plane_bytes * v.size()));
+            p.owned = slab + (size_t)idx * plane_bytes;
+        }
         // the previous decode (asynchronous, on the context's or a caller's stream) may still be reading the staging buffer
         if (int rc = wait_done_host(ctx)) return rc;
         // deep copy, complete before return (pic.copyTo, R/CDecodePhase.cpp:114)

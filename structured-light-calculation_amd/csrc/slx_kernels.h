@@ -38,9 +38,12 @@ struct SlxKParams {
     // calibration scalars of R/CCalculation.cpp:151-164: cC = ((u-cx)*fv)*P00 + ((v-cy)*fu)*P01 + K1
     double cx, cy, fu, fv, P00, P01, K1, P20, P21, K2, cA, cB;
     // ---- fast path (slx_strip_kernel) ----
-    const uint8_t *phase_base;                  // lowest phase-plane address: the buffer descriptor's base
-    unsigned phase_rel[SLX_MAX_PHASE_PLANES];   // phase[k] - phase_base (fits 32 bits, checked by slx_strip_eligible)
-    unsigned gray_rel[SLX_MAX_GRAY_PLANES];     // gray[k] + set offset difference - phase_base, when the Gray planes ride the ring
+    // The planes of a group are equally spaced (slx_strip_eligible): plane k of the phase group starts phase_first + k *
+    // phase_step bytes after plane_base, Gray plane k gray_first + k * gray_step -- two running scalar offsets in the kernel
+    // instead of one register per plane.
+    const uint8_t *plane_base;                  // lowest plane address: the buffer descriptor's base
+    unsigned phase_first, phase_step;
+    unsigned gray_first, gray_step;             // only when the Gray planes ride the ring
     long long gray_set_delta;                   // gray_set_stride - phase_set_stride (the descriptor's base advances by phase_set_stride)
     double inv_period[SLX_MAX_FREQ];            // RN(1/T_f)
     double half_biased[SLX_MAX_FREQ];           // 0.5 + 2^-30/T_f

@@ -753,6 +753,17 @@ __global__ __launch_bounds__(256) void slx_strip_kernel(const SlxKParams p)
         hb[f] = p.half_biased[f];
         asm volatile("" : "+v"(hb[f]));
     }
+    // The Gray modes run out of scalar registers (a wave has 102): the per-pixel constants of the triangulation live in
+    // vector registers there (those kernels have them to spare below the 128 that 4 waves per SIMD allow).
+    double kK1 = p.K1, kK2 = p.K2, kcA = p.cA, kcB = p.cB, kfmin = p.fov_min, kfmax = p.fov_max;
+    double kinvT[F];
+#pragma unroll
+    for (int f = 0; f < F; f++) kinvT[f] = p.inv_period[f];
+    if constexpr (MASKED && GB > 0 && F <= 3) {
+        asm volatile("" : "+v"(kK1), "+v"(kK2), "+v"(kcA), "+v"(kcB), "+v"(kfmin), "+v"(kfmax));
+#pragma unroll
+        for (int f = 1; f < F; f++) asm volatile("" : "+v"(kinvT[f]));
+    }
 
     bool lane_valid;
     const StripPos pos = strip_locate<MASKED>(p, item, items_per_set, RB, region_row0, lane_valid);
@@ -762,14 +773,16 @@ __global__ __launch_bounds__(256) void slx_strip_kernel(const SlxKParams p)
 
     // buffer_load ... lds: one 32-bit lane offset for every plane, the plane's offset in an SGPR, no VALU
     const __amdgpu_buffer_rsrc_t rsrc =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(p.phase_base + pset), 0, 0xFFFFFFFFu, 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(p.plane_base + pset), 0, 0xFFFFFFFFu, 0x00020000);
     // lane offsets advance by a constant per row: one add (and a clamp for the DMA) instead of a multiply-add
     const unsigned dma_step = step_rows * row_stride;
     const unsigned dma_last = last_row * row_stride + pos.cq * SLX_QUAD;   // rows past the tile: harmless re-read of the last row
     unsigned dma_off = pos.row * row_stride + pos.cq * SLX_QUAD;           // offset of the row of the next chunk to issue
-    unsigned gray_soff[GB > 0 ? 2 * GB : 1];                           // scalar: plane offset + this set's extra offset
-#pragma unroll
-    for (int k = 0; k < 2 * GB; k++) gray_soff[k] = p.gray_rel[k] + (unsigned)((long long)pos.set * p.gray_set_delta);
+    // Plane offsets are running scalars: first + k * step, advanced by one s_add per load (the asm keeps hipcc from turning
+    // them back into one hoisted register per plane: 24 SGPRs in the Gray modes, which spilled into VGPR lanes and came back
+    // through v_readlane every row).
+    const unsigned gray_first = GB > 0 ? p.gray_first + (unsigned)((long long)pos.set * p.gray_set_delta) : 0u;
+    auto next_plane = [](unsigned &so, unsigned step) { asm volatile("s_add_u32 %0, %0, %1" : "+s"(so) : "s"(step) : "scc"); };
     auto issue_chunk = [&](unsigned slot, int cc) {                    // DMA of the item's next chunk (chunk cc of its row) into ring[slot]
         const unsigned voff = dma_off < dma_last ? dma_off : dma_last;
         if (cc == CPR - 1) dma_off += dma_step;
@@ -778,13 +791,19 @@ __global__ __launch_bounds__(256) void slx_strip_kernel(const SlxKParams p)
         // quads are re-read by the neighbouring wave out of L2 (-10 % with nt there)
         constexpr int POLICY = MASKED ? 0 : 2;
         if (GRAY_CHUNK && cc == 1) {
+            unsigned so = gray_first;
 #pragma unroll
-            for (int k = 0; k < NGR; k++)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void *)(dst + k * 64), 4, voff, gray_soff[k], 0, POLICY);
+            for (int k = 0; k < NGR; k++) {
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void *)(dst + k * 64), 4, voff, so, 0, POLICY);
+                if (k + 1 < NGR) next_plane(so, p.gray_step);
+            }
         } else {
+            unsigned so = p.phase_first + (NS == 4 ? 0u : (unsigned)cc * NPH * p.phase_step);
 #pragma unroll
-            for (int k = 0; k < NPH; k++)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void *)(dst + k * 64), 4, voff, p.phase_rel[(NS == 4 ? 0 : cc * NPH) + k], 0, POLICY);
+            for (int k = 0; k < NPH; k++) {
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void *)(dst + k * 64), 4, voff, so, 0, POLICY);
+                if (k + 1 < NPH) next_plane(so, p.phase_step);
+            }
         }
     };
     // Depth stores: buffer stores against a descriptor of this frame-set's depth map -- one 32-bit byte offset per store
@@ -1015,7 +1034,7 @@ __global__ __launch_bounds__(256) void slx_strip_kernel(const SlxKParams p)
 #pragma unroll
                     for (int f = 1; f < F; f++) {
                         int k;
-                        Uf = unwrap_stage<true>(Uf, (double)pix[f][j], p.period[f], p.inv_period[f], hb[f], k);
+                        Uf = unwrap_stage<true>(Uf, (double)pix[f][j], p.period[f], kinvT[f], hb[f], k);
                         if constexpr (AUX && NK > 0) kf[f - 1][j] = k;
                     }
                     U[j] = Uf;
@@ -1036,9 +1055,9 @@ __global__ __launch_bounds__(256) void slx_strip_kernel(const SlxKParams p)
                 const double tvC = vf * p.P01, tvD = vf * p.P21;
 #pragma unroll
                 for (int j = 0; j < SLX_QUAD; j++) {
-                    const double cC = (aC[j] + tvC) + p.K1;
-                    const double cD = (aD[j] + tvD) + p.K2;
-                    z[j] = tri_depth<true>(U[j], cC, cD, p.cA, p.cB, p.fov_min, p.fov_max, true);
+                    const double cC = (aC[j] + tvC) + kK1;
+                    const double cD = (aD[j] + tvD) + kK2;
+                    z[j] = tri_depth<true>(U[j], cC, cD, kcA, kcB, kfmin, kfmax, true);
                 }
             }
             if constexpr (!MASKED) {
@@ -1343,15 +1362,15 @@ bool slx_strip_eligible(const SlxKParams &kp, int mode, bool aux)
     if (!slx_fast_arith_ok(kp)) return false;
     if ((unsigned long long)kp.row_stride * (unsigned)kp.height >= (1ull << 31)) return false;   // 32-bit plane offsets
     {
-        // every phase plane must sit within 2 GiB of the lowest one (32-bit buffer offsets)
+        // the phase planes must be equally spaced, ascending, the last within 2 GiB of the first (32-bit buffer offsets):
+        // the layout of a batch and of the context's staging slab; anything else takes the generic kernel
         const int np = kp.n_freq * kp.n_steps;
-        uintptr_t lo = ~(uintptr_t)0, hi = 0;
-        for (int k = 0; k < np; k++) {
-            const uintptr_t a = reinterpret_cast<uintptr_t>(kp.phase[k]);
-            lo = a < lo ? a : lo;
-            hi = a > hi ? a : hi;
-        }
-        if (hi - lo >= (1ull << 31)) return false;
+        const uintptr_t a0 = reinterpret_cast<uintptr_t>(kp.phase[0]);
+        const uintptr_t step = np > 1 ? reinterpret_cast<uintptr_t>(kp.phase[1]) - a0 : 0;
+        if (np > 1 && reinterpret_cast<uintptr_t>(kp.phase[1]) < a0) return false;
+        for (int k = 0; k < np; k++)
+            if (reinterpret_cast<uintptr_t>(kp.phase[k]) != a0 + (uintptr_t)k * step) return false;
+        if ((unsigned long long)step * (unsigned)(np > 1 ? np - 1 : 0) >= (1ull << 31)) return false;
     }
     if ((unsigned long long)kp.width * ((unsigned)kp.height + 2048ull) >= (1ull << 29)) return false;   // 32-bit output byte offsets, rows past the tile included
     return true;
@@ -1389,13 +1408,10 @@ int slx_launch_fused(const SlxKParams &kp_in, int mode, bool aux, int n_sets, in
         return launch_generic(kg, mode, aux, n_sets, stream);
     }
     SlxKParams kp = kp_in;
-    {
-        const int np = kp.n_freq * kp.n_steps;
-        const uint8_t *lo = kp.phase[0];
-        for (int k = 1; k < np; k++) lo = kp.phase[k] < lo ? kp.phase[k] : lo;
-        kp.phase_base = lo;
-        for (int k = 0; k < np; k++) kp.phase_rel[k] = (unsigned)(kp.phase[k] - lo);
-    }
+    kp.plane_base = kp.phase[0];                                     // equally spaced, ascending (slx_strip_eligible)
+    kp.phase_first = 0;
+    kp.phase_step = kp.n_freq * kp.n_steps > 1 ? (unsigned)(kp.phase[1] - kp.phase[0]) : 0u;
+    kp.gray_first = kp.gray_step = 0;
     // geometry: `interleave` rows end to end fill whole waves; an item is 64 quads x rows_per_lane rows
     const unsigned QR = kp.quads_per_row;
     unsigned g = QR, h = 64;
@@ -1423,20 +1439,24 @@ int slx_launch_fused(const SlxKParams &kp_in, int mode, bool aux, int n_sets, in
     int gb = 0;
     if (mode != SLX_MODE_MULTIFREQ && kp.gray_bits == 6 && !tn.gray_plain) {
         gb = 6;
-        const uint8_t *lo = kp.phase_base;
-        for (int k = 0; k < 12; k++) lo = kp.gray[k] < lo ? kp.gray[k] : lo;
+        // equally spaced, ascending, like the phase planes
+        const long long gstep = (long long)(kp.gray[1] - kp.gray[0]);
+        for (int k = 0; k < 12; k++)
+            if (gstep < 0 || kp.gray[k] != kp.gray[0] + (long long)k * gstep) gb = 0;
+        const uint8_t *lo = kp.gray[0] < kp.phase[0] ? kp.gray[0] : kp.phase[0];
         const long long delta = (long long)kp.gray_set_stride - (long long)kp.phase_set_stride;
-        for (int k = 0; k < 12; k++) {
-            const long long rel = (long long)(kp.gray[k] - lo);
+        const long long g_first = (long long)(kp.gray[0] - lo), g_last = g_first + 11 * gstep;
+        const long long p_last = (long long)(kp.phase[0] - lo) + (long long)(kp.n_freq * 4 - 1) * kp.phase_step;
+        for (long long rel : {g_first, g_last}) {
             const long long hi = rel + delta * (long long)(n_sets - 1);
             if (rel >= (1ll << 31) || hi < 0 || hi >= (1ll << 31)) gb = 0;
         }
-        for (int k = 0; k < kp.n_freq * 4; k++)
-            if ((long long)(kp.phase[k] - lo) >= (1ll << 31)) gb = 0;
+        if (p_last >= (1ll << 31) || gstep >= (1ll << 31)) gb = 0;
         if (gb) {
-            kp.phase_base = lo;
-            for (int k = 0; k < kp.n_freq * 4; k++) kp.phase_rel[k] = (unsigned)(kp.phase[k] - lo);
-            for (int k = 0; k < 12; k++) kp.gray_rel[k] = (unsigned)(kp.gray[k] - lo);
+            kp.plane_base = lo;
+            kp.phase_first = (unsigned)(kp.phase[0] - lo);
+            kp.gray_first = (unsigned)g_first;
+            kp.gray_step = (unsigned)gstep;
             kp.gray_set_delta = delta;
         }
     }
