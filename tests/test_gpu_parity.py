@@ -1027,3 +1027,30 @@ def test_strip_kernel_optional_planes(api, oracle, synth, torch_cuda, name, shap
         a = mm[i].cpu().numpy()
         want_mask = refs[i]["mask"] if "mask" in refs[i] else np.ones((h, w), np.uint8)
         assert np.array_equal(a[1:h + 1], want_mask) and np.all(a[0] == 7) and np.all(a[h + 1] == 7), i
+
+
+@pytest.mark.parametrize("split", ["rows", "framesets"])
+def test_cpp_gather_host_loop(tmp_path, oracle, synth, split):
+    """tests/cpp/gather_host_loop.cpp: a C++ rank of the multi-GPU host loop through the C ABI alone -- communicator from a
+    unique id handed over in a file, slx_decode_gather in chunks, slx_gather_depth from a separate buffer -- as a world of one
+    (this box has one GPU; the program takes rank / world arguments for a node)."""
+    import subprocess
+    from conftest import ROOT, _ensure_built
+    _ensure_built()
+    exe = os.path.join(ROOT, "tests", "cpp", "gather_host_loop")
+    assert os.path.exists(exe)
+    W, H, sets = 128, 37, 5
+    spec = {"name": "gather", "width": W, "height": H, "row_offset": 0, "proj_width": 1920, "mode": synth.MODE_MULTIFREQ, "n_freq": 3, "n_steps": 4,
+            "periods": [1920, 240, 30], "gray_bits": 0, "gray_stripe": 0, "gray_lut": None, "fov_min": -1e300, "fov_max": 1e300,
+            "calib": {"cam": [3600, 0, (W - 1) / 2.0, 0, 3600, (H - 1) / 2.0, 0, 0, 1], "pro": [3000, 0, 900, 0, 3000, 600, 0, 0, 1],
+                      "rot": [0.99, -0.01, 0.13, 0.02, 0.99, -0.1, -0.13, 0.1, 0.98], "trans": [-31.7, -9.3, 39.4]}}
+    planes = [synth.random_planes(spec, seed=700 + s)[0] for s in range(sets)]
+    np.stack(planes).tofile(str(tmp_path / "in.bin"))
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run([exe, "0", "1", str(tmp_path / "id.bin"), split, str(W), str(H), str(sets), str(tmp_path / "in.bin"), str(tmp_path / "out.bin")],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
+    got = np.fromfile(str(tmp_path / "out.bin"), dtype=np.float64).reshape(sets, H, W)
+    for s in range(sets):
+        assert np.array_equal(got[s], oracle.pipeline(spec, planes[s], None, want=("z",))["z"], equal_nan=True), s

@@ -7,7 +7,7 @@ for C in $1; do
   for L in $2 $3 $2 $3; do
     cp tmp_ab/libslx_$L.so $P || exit 1
     echo "== $C $L"
-    AB_CONFIG=$C AB_SETS=$([ $C = C5 ] && echo 4 || echo 32) timeout -k 10 120 python tools/ab.py ${AB_ARMS:-2} 2>&1 | grep median || exit 1
+    AB_CONFIG=$C AB_SETS=$([ $C = C5 ] && echo 4 || ([ $C = C3 ] && echo 16 || echo 32)) timeout -k 10 120 python tools/ab.py ${AB_ARMS:-2} 2>&1 | grep median || exit 1
   done
 done
 cp /tmp/libslx_keep.so $P
