@@ -161,6 +161,8 @@ def parse_args(argv=None):
                     help="how ranks split the batch in the headline (decode-only) region: whole frame-sets (default), or a row tile of every "
                          "frame-set (north_star's wording); the per-GPU bytes are the same.  with_gather always reports both")
     ap.add_argument("--gather-chunk", type=int, default=8, help="frame-sets per pipelined decode+gather chunk")
+    ap.add_argument("--gather-timeout", type=float, default=240.0,
+                    help="N > 1: seconds the whole with_gather phase may take before the line is printed without it (a stuck collective must not cost the decode-only result)")
     ap.add_argument("--backend", default=None, help="nccl (= RCCL, default on GPUs) or gloo (one-GPU rehearsal of the multi-rank path)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="allow --gpus N on a box with fewer GPUs: the ranks share GPU 0 and talk over gloo (RCCL refuses two ranks on one device)")
@@ -371,12 +373,48 @@ def run_rank(args):
     fence()
     t_max, kernel_ms_max = max_over_ranks([t_local, kernel_ms])
 
+    def make_result(gather, cpu_single=None, cpu_multi=None, parity=None, other=None):
+        achieved = bytes_per_launch / (kernel_ms_max * 1e-3) / 1e9
+        traffic, traffic_source = traffic_entry(args.config, n_sets)
+        return {
+            "metric": "depth_frames_per_sec", "value": world * args.sets_per_gpu * args.steps / t_max, "unit": "frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": t_max / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32+f64", "data": "synthetic",
+            "config": {"workload": "%s: %dx%d, %d-frequency x %d-step temporal unwrap%s + triangulation, %d frame-sets per GPU per step"
+                                   % (args.config, W, full_h, spec["n_freq"], spec["n_steps"], " + %d-bit Gray mask" % spec["gray_bits"] if n_gray else "", args.sets_per_gpu),
+                       "periods": spec["periods"], "sharding": ("by frame-set" if args.shard == "framesets" or world == 1 else "by row tile (%d rows of %d per GPU, %d frame-sets)" % (H, full_h, n_sets)) + ", no data-path collective",
+                       "kernel_variant": args.variant, "settle_launches": settle, "tuning": tune or None},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
+                         "kernel": kernel_name(spec, args.variant), "launch_ms": kernel_ms_max,
+                         "algorithmic_bytes_per_launch": bytes_per_launch},
+            "achieved_hbm_gbps_per_gpu": achieved,
+            "rccl_world_size": (dist.get_world_size() if world > 1 else 1), "collective_backend": (backend if world > 1 else None),
+            "cpu_baseline": cpu_single, "cpu_baseline_all_cores": cpu_multi,
+            "parity_vs_oracle": parity, "other_configs": other, "with_gather": gather,
+        }
+
     # ------------------------------------------------------------------ N > 1: decode + gather, both ways of cutting the batch
     gather = None
+    watchdog = None
     if world > 1 and not args.no_gather:
-        gather = {"rccl_world_size": dist.get_world_size(), "backend": "RCCL (libslx slx_decode_gather: grouped ncclSend/ncclRecv)" if backend == "nccl"
+        import threading
+        gather = {}
+
+        def gather_stuck():
+            # the collective phase hangs (a rank died, a fabric problem): the decode-only measurement above is complete and is
+            # reported; this process leaves without waiting for the device
+            if rank == 0:
+                g = dict(gather)
+                g["error"] = "the with_gather phase did not finish within %.0f s and was abandoned" % args.gather_timeout
+                print(json.dumps(make_result(g)), flush=True)
+            os._exit(0)
+        watchdog = threading.Timer(args.gather_timeout, gather_stuck)
+        watchdog.daemon = True
+        watchdog.start()
+        gather.update({"rccl_world_size": dist.get_world_size(), "backend": "RCCL (libslx slx_decode_gather: grouped ncclSend/ncclRecv)" if backend == "nccl"
                   else "%s via torch.distributed (one-GPU rehearsal, depth maps staged through the host)" % backend,
-                  "chunk_sets": args.gather_chunk, "root": 0}
+                  "chunk_sets": args.gather_chunk, "root": 0})
         comm = None
         try:
             if backend == "nccl":
@@ -479,6 +517,7 @@ def run_rank(args):
                 if gctx is not None:
                     gctx.close()
             gather[split] = res
+        watchdog.cancel()
 
     if rank == 0:
         cpu_single = cpu_multi = None
@@ -529,30 +568,17 @@ def run_rank(args):
                     del oph, ogr, oz
                 except Exception as e:
                     other[name] = {"error": "%s: %s" % (type(e).__name__, e)}
-        achieved = bytes_per_launch / (kernel_ms_max * 1e-3) / 1e9
-        traffic, traffic_source = traffic_entry(args.config, n_sets)
-        result = {
-            "metric": "depth_frames_per_sec", "value": world * args.sets_per_gpu * args.steps / t_max, "unit": "frames/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": t_max / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32+f64", "data": "synthetic",
-            "config": {"workload": "%s: %dx%d, %d-frequency x %d-step temporal unwrap%s + triangulation, %d frame-sets per GPU per step"
-                                   % (args.config, W, full_h, spec["n_freq"], spec["n_steps"], " + %d-bit Gray mask" % spec["gray_bits"] if n_gray else "", args.sets_per_gpu),
-                       "periods": spec["periods"], "sharding": ("by frame-set" if args.shard == "framesets" or world == 1 else "by row tile (%d rows of %d per GPU, %d frame-sets)" % (H, full_h, n_sets)) + ", no data-path collective",
-                       "kernel_variant": args.variant, "settle_launches": settle, "tuning": tune or None},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
-                         "kernel": kernel_name(spec, args.variant), "launch_ms": kernel_ms_max,
-                         "algorithmic_bytes_per_launch": bytes_per_launch},
-            "achieved_hbm_gbps_per_gpu": achieved,
-            "rccl_world_size": (dist.get_world_size() if world > 1 else 1), "collective_backend": (backend if world > 1 else None),
-            "cpu_baseline": cpu_single, "cpu_baseline_all_cores": cpu_multi,
-            "parity_vs_oracle": parity, "other_configs": other, "with_gather": gather,
-        }
+        result = make_result(gather, cpu_single, cpu_multi, parity, other)
         print(json.dumps(result), flush=True)
     ctx.close()
     if world > 1:
+        import threading
+        bye = threading.Timer(60.0, lambda: os._exit(0))       # the result is out: a peer that never reaches the barrier must not hang the job
+        bye.daemon = True
+        bye.start()
         dist.barrier()
         dist.destroy_process_group()
+        bye.cancel()
 
 
 def selftest_rank(args):
