@@ -418,11 +418,13 @@ def run_rank(args):
         comm = None
         try:
             if backend == "nccl":
+                # ONE communicator for both splits (a unique id makes one communicator); torch.distributed only carries the id
                 ids = [api.comm_unique_id() if rank == 0 else None]
                 dist.broadcast_object_list(ids, src=0)
+                comm = api.Comm(ctx, ids[0], world, rank)
         except Exception as e:
-            ids = None
-            gather["error"] = "unique id: %s: %s" % (type(e).__name__, e)
+            comm = None
+            gather["error"] = "communicator: %s: %s" % (type(e).__name__, e)
         total = world * args.sets_per_gpu
         reps = max(3, min(20, args.steps // 15))
         for split in ("framesets", "rows"):
@@ -445,16 +447,15 @@ def run_rank(args):
                 scratch = None if rank == 0 else torch.empty((gn, grows, W), dtype=torch.float64, device=device)
                 torch.cuda.synchronize()
                 if backend == "nccl":
-                    if ids is None:
-                        raise RuntimeError(gather.get("error", "no unique id"))
-                    comm = api.Comm(gctx, ids[0], world, rank)
+                    if comm is None:
+                        raise RuntimeError(gather.get("error", "no communicator"))
 
                     def decode_only():
                         gctx.decode_batch_ex(gn, gphase, ggray, z=(full[set0:, row0:] if rank == 0 else scratch),
                                              plane_stride=(full_h * W if rank == 0 else 0), stream=sh)
 
                     def decode_and_gather():
-                        comm.decode_gather(table, full_h, args.gather_chunk, gphase, ggray, scratch, full, root=0, stream=sh)
+                        comm.decode_gather(table, full_h, args.gather_chunk, gphase, ggray, scratch, full, root=0, stream=sh, ctx=gctx)
 
                     def drain():
                         comm.synchronize()
@@ -508,15 +509,19 @@ def run_rank(args):
             except Exception as e:      # the decode-only line above must still be reported
                 res = {"error": "%s: %s" % (type(e).__name__, e)}
             finally:
-                if comm is not None:
-                    try:
-                        comm.close()
-                    except Exception:
-                        pass
-                    comm = None
                 if gctx is not None:
+                    if comm is not None:
+                        try:
+                            comm.synchronize()          # nothing of this split may still be in flight when its buffers go
+                        except Exception:
+                            pass
                     gctx.close()
             gather[split] = res
+        if comm is not None:
+            try:
+                comm.close()
+            except Exception:
+                pass
         watchdog.cancel()
 
     if rank == 0:

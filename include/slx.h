@@ -271,7 +271,8 @@ typedef struct slx_shard { int set0, n_sets, row0, rows; } slx_shard;
 #define SLX_COMM_ID_BYTES 128
 /* Rank 0 makes an id (ncclGetUniqueId) and hands the 128 bytes to the other ranks by any means (a file, MPI, a socket ...). */
 int slx_comm_unique_id(void *id, size_t id_bytes);
-/* Collective over all `world` ranks: ncclCommInitRank on the context's device.  The comm owns a gather stream. */
+/* Collective over all `world` ranks: ncclCommInitRank on the context's device.  The comm owns a gather stream; it serves every
+ * context of that device (a unique id makes ONE communicator: do not reuse it for a second slx_comm_create). */
 int slx_comm_create(slx_ctx *ctx, const void *id, size_t id_bytes, int world, int rank, slx_comm **out);
 /* Wraps a communicator the host already has (an ncclComm_t whose device is the context's); it is not destroyed with the wrapper. */
 int slx_comm_adopt(slx_ctx *ctx, void *nccl_comm, slx_comm **out);

@@ -482,8 +482,9 @@ class Comm:
         self._check(lib().slx_gather_depth(self._h, shard_table(shards), int(height), int(width), None if local is None else local.data_ptr(),
                                            int(local_plane_stride), None if full is None else full.data_ptr(), int(root), stream))
 
-    def decode_gather(self, shards, full_height, chunk_sets, phase, gray, scratch, full, root=0, stream=None, row_stride=None):
-        """slx_decode_gather: this rank's shard decoded chunk by chunk, every chunk gathered while the next decodes."""
+    def decode_gather(self, shards, full_height, chunk_sets, phase, gray, scratch, full, root=0, stream=None, row_stride=None, ctx=None):
+        """slx_decode_gather: this rank's shard decoded chunk by chunk, every chunk gathered while the next decodes.
+        ctx: the context that decodes (default: the one the communicator was created with; any context of that device will do)."""
         def base(t):
             if t is None:
                 return None, 0
@@ -493,7 +494,7 @@ class Comm:
         gb, gs = base(gray)
         ref = phase if phase is not None else gray
         rs = ref.stride(-2) if row_stride is None else row_stride
-        self._check(lib().slx_decode_gather(self._h, self._ctx._h, shard_table(shards), int(full_height), int(chunk_sets), pb, ps, gb, gs, rs,
+        self._check(lib().slx_decode_gather(self._h, (ctx or self._ctx)._h, shard_table(shards), int(full_height), int(chunk_sets), pb, ps, gb, gs, rs,
                                             None if scratch is None else scratch.data_ptr(), None if full is None else full.data_ptr(),
                                             int(root), stream))
 

@@ -271,7 +271,7 @@ int slx_decode_gather(slx_comm *c, slx_ctx *ctx, const slx_shard *shards, int fu
                       double *full, int root, void *stream)
 {
     if (!c || !ctx) return SLX_ERR_INVALID_ARG;
-    if (ctx != c->ctx) return cfail(c, SLX_ERR_INVALID_ARG, "the communicator was created for another context");
+    if (slx_internal_device(ctx) != c->device) return cfail(c, SLX_ERR_INVALID_ARG, "the communicator lives on device %d, the context on device %d", c->device, slx_internal_device(ctx));
     if (chunk_sets < 1) return cfail(c, SLX_ERR_INVALID_ARG, "chunk_sets must be positive (got %d)", chunk_sets);
     int width = 0, tile_rows = 0;
     slx_internal_tile(ctx, &width, &tile_rows);

@@ -878,6 +878,15 @@ def test_native_gather_world_of_one(api, oracle, synth, shard, torch_cuda, split
         assert np.array_equal(full.cpu().numpy(), want, equal_nan=True)
         with pytest.raises(api.SlxError):
             comm.gather_depth([(0, n_sets, 0, H + 1)], H, W, local, full)          # a shard taller than the frame
+        # the communicator belongs to the device, not to one context: a second context (another tuning, as bench.py's second
+        # split would be another tile) decodes through it too
+        with api.Context(spec) as other:
+            other.set_tuning(strip_rows=4)
+            full.fill_(-1.0)
+            torch.cuda.synchronize()
+            comm.decode_gather(table, H, 3, phase, None, None, full, root=root, ctx=other)
+            comm.synchronize()
+            assert np.array_equal(full.cpu().numpy(), want, equal_nan=True)
         comm.close()
 
 

@@ -30,8 +30,9 @@ n_sets = int(os.environ.get("AB_SETS", "32"))
 spec = synth.make_spec(cfg)
 H, W = spec["height"], spec["width"]
 n_phase, n_gray = synth.n_planes(spec)
-phase = torch.randint(0, 256, (n_sets, n_phase, H, W), dtype=torch.uint8, device="cuda") if n_phase else None
-gray = torch.randint(0, 256, (n_sets, n_gray, H, W), dtype=torch.uint8, device="cuda") if n_gray else None
+pitch = W + int(os.environ.get("AB_PAD", "0"))           # AB_PAD: extra bytes per image row (moves the planes' relative alignment)
+phase = torch.randint(0, 256, (n_sets, n_phase, H, pitch), dtype=torch.uint8, device="cuda")[..., :W] if n_phase else None
+gray = torch.randint(0, 256, (n_sets, n_gray, H, pitch), dtype=torch.uint8, device="cuda")[..., :W] if n_gray else None
 z = torch.empty((n_sets, H, W), dtype=torch.float64, device="cuda")
 s = torch.cuda.Stream(); torch.cuda.set_stream(s)
 ctxs = {}
