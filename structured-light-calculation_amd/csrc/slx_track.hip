@@ -227,6 +227,31 @@ __global__ __launch_bounds__(kTile) void slx_track_fused_kernel(const uint8_t *c
     const bool col_in = c >= 0 && c < W;
     const bool col_interior = c >= HW && c < W - HW;                 // valSum is 0 elsewhere
     const int ha = ra > HW ? ra : HW, hb = ra + RR < H - HW ? ra + RR : H - HW;   // interior rows of the tile: [ha, hb)
+    const bool scans = tx >= HW && tx < kTile - HW;
+    const bool owns_col = tx >= HW + 1 && tx < kTile - HW - 1 && c < W;
+    // Everything a workgroup reads besides the image is asked for up front -- the previous frame's strips for all ten rows here,
+    // U and z two rows ahead of their use below -- so that those latencies pass behind the sums and the scans: all workgroups of
+    // a frame are resident at once, and a workgroup's own dependent chain is what the launch lasts.
+    float pB[RR], pW[RR];
+#pragma unroll
+    for (int j = 0; j < RR; j++) {
+        const int h = ra + j;
+        const bool need = scans && col_in && h >= 0 && h < H;
+        const size_t o = (size_t)(need ? h : 0) * W + (need ? c : 0);
+        pB[j] = need ? prevB[o] : 0.f;
+        pW[j] = need ? prevW[o] : 0.f;
+    }
+    double Uq[kFusedRows + 1], zq[kFusedRows + 1];
+    auto fetch_row = [&](int j) {                                    // inputs of output row j (tile row j, image row ra + j)
+        const int v = ra + j;
+        const bool need = owns_col && v < r1;
+        const size_t i = (size_t)(need ? v : 0) * W + (need ? c : 0);
+        Uq[j] = need ? U[i] : 0.0;
+        zq[j] = need ? z[i] : 0.0;
+    };
+    fetch_row(1);
+    fetch_row(2);
+    fetch_row(3);
     if (ha < hb) {
         uint32_t b[RR + 2 * HW];
 #pragma unroll
@@ -244,15 +269,12 @@ __global__ __launch_bounds__(kTile) void slx_track_fused_kernel(const uint8_t *c
         }
     }
     __syncthreads();
-    const bool scans = tx >= HW && tx < kTile - HW;
-    const bool owns_col = tx >= HW + 1 && tx < kTile - HW - 1 && c < W;
     // strips and deltaP selection of tile row j (image row ra + j) -> rawt[j]
     auto scan_row = [&](int j) {
         const int h = ra + j;
         float r = 0.f;
         if (scans && col_in && h >= 0 && h < H) {
             const size_t o = (size_t)h * W + c;
-            const float pB = prevB[o], pW = prevW[o];                // issued first: their latency hides behind the scan
             float mxi = 0.f, mni = 0.f;
             if (col_interior && h >= ha && h < hb) {
                 const uint32_t *row = &sums[h - ha][tx];
@@ -273,7 +295,7 @@ __global__ __launch_bounds__(kTile) void slx_track_fused_kernel(const uint8_t *c
                 stripB[o] = mni;
                 stripW[o] = mxi;
             }
-            const float dB = pB - mni, dW = pW - mxi;                // R/CCalculation.cpp:602-617
+            const float dB = pB[j] - mni, dW = pW[j] - mxi;          // R/CCalculation.cpp:602-617
             r = (__builtin_fabsf(dB) < __builtin_fabsf(dW)) ? dB : dW;
         }
         rawt[j][tx] = r;
@@ -292,11 +314,8 @@ __global__ __launch_bounds__(kTile) void slx_track_fused_kernel(const uint8_t *c
         const int v = ra + j;                                        // uniform over the workgroup
         if (v >= r1) break;
         const size_t i = (size_t)v * W + (owns_col ? c : 0);
-        double Uin = 0.0, zin = 0.0;
-        if (owns_col) {                                              // this row's inputs, in flight during the scan below
-            Uin = U[i];
-            zin = z[i];
-        }
+        if (j + 3 <= kFusedRows) fetch_row(j + 3);                   // three rows ahead
+        const double Uin = Uq[j], zin = zq[j];
         scan_row(j + 1);
         __syncthreads();                                             // rows j-1 .. j+1 of rawt are complete; no row is ever rewritten
         if (!owns_col) continue;
