@@ -288,6 +288,13 @@ int slx_comm_synchronize(slx_comm *comm);
  * gather stream); asynchronous. */
 int slx_gather_depth(slx_comm *comm, const slx_shard *shards, int height, int width,
                      const double *local, size_t local_plane_stride, double *full, int root, void *stream);
+/* The messages one group of the gather consists of for `rank`, without posting them (no GPU needed): the frame-sets
+ * [first, first+count) counted within every shard, receives first, then sends, in posting order.  offset is in doubles into
+ * `full` for a receive and into this rank's `local` for a send.  *n_out receives the number of messages (also when it exceeds
+ * `capacity`).  For inspection and for checking the schedule of a world of N ranks on a machine without N GPUs. */
+typedef struct slx_msg { int peer, send; unsigned long long offset, count; } slx_msg;
+int slx_gather_plan(const slx_shard *shards, int world, int rank, int height, int width, int first, int count,
+                    size_t local_plane_stride, int root, slx_msg *out, int capacity, int *n_out);
 /* Decode + gather of this rank's shard, pipelined: the shard's frame-sets are decoded `chunk_sets` at a time on `stream`
  * (NULL: the context's) and every finished chunk is gathered on the comm's stream while the next one decodes.  Inputs as
  * slx_decode_batch (this rank's shards[rank].n_sets frame-sets, tile height shards[rank].rows = the context's height).

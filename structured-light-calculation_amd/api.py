@@ -32,7 +32,7 @@ SYMBOLS = [
     "slx_get_depth", "slx_get_point_cloud", "slx_track_begin", "slx_track_next", "slx_output_device_ptr", "slx_get_calibration", "slx_enable_timing",
     "slx_last_decode_ms", "slx_debug_stamps", "slx_set_variant", "slx_set_tuning", "slx_read_bmp_gray", "slx_read_pgm_gray", "slx_read_calibration_yaml", "slx_version",
     "slx_decode_batch_ex", "slx_comm_unique_id", "slx_comm_create", "slx_comm_adopt", "slx_comm_destroy", "slx_comm_info", "slx_comm_last_error",
-    "slx_comm_synchronize", "slx_gather_depth", "slx_decode_gather",
+    "slx_comm_synchronize", "slx_gather_depth", "slx_decode_gather", "slx_gather_plan",
     "slx_pipe_create", "slx_pipe_destroy", "slx_pipe_layout", "slx_pipe_acquire", "slx_pipe_submit", "slx_pipe_collect", "slx_pipe_last_error",
 ]
 
@@ -56,6 +56,10 @@ class SlxBatchOut(C.Structure):
 
 class SlxShard(C.Structure):
     _fields_ = [("set0", C.c_int), ("n_sets", C.c_int), ("row0", C.c_int), ("rows", C.c_int)]
+
+
+class SlxMsg(C.Structure):
+    _fields_ = [("peer", C.c_int), ("send", C.c_int), ("offset", C.c_ulonglong), ("count", C.c_ulonglong)]
 
 
 COMM_ID_BYTES = 128
@@ -111,6 +115,8 @@ def lib():
         L.slx_comm_synchronize.argtypes = [vp]
         L.slx_gather_depth.argtypes = [vp, C.POINTER(SlxShard), C.c_int, C.c_int, vp, sz, vp, C.c_int, vp]
         L.slx_decode_gather.argtypes = [vp, vp, C.POINTER(SlxShard), C.c_int, C.c_int, vp, sz, vp, sz, sz, vp, vp, C.c_int, vp]
+        L.slx_gather_plan.argtypes = [C.POINTER(SlxShard), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, sz, C.c_int, C.POINTER(SlxMsg), C.c_int,
+                                      C.POINTER(C.c_int)]
         L.slx_synchronize.argtypes = [vp]
         L.slx_get_output.argtypes = [vp, C.c_int, vp, sz, C.c_int]
         L.slx_get_depth.argtypes = [vp, vp, C.c_int]
@@ -434,6 +440,20 @@ def comm_unique_id():
     if rc != OK:
         raise SlxError(rc, lib().slx_comm_last_error(None).decode())
     return buf.raw
+
+
+def gather_plan(shards, rank, height, width, first, count, local_plane_stride=0, root=0):
+    """slx_gather_plan: [(peer, send, offset, count)] -- the messages rank `rank` posts for one group (no GPU needed)."""
+    n = C.c_int(0)
+    t = shard_table(shards)
+    rc = lib().slx_gather_plan(t, len(shards), rank, height, width, first, count, local_plane_stride, root, None, 0, C.byref(n))
+    if rc != OK:
+        raise SlxError(rc, "slx_gather_plan")
+    buf = (SlxMsg * max(n.value, 1))()
+    rc = lib().slx_gather_plan(t, len(shards), rank, height, width, first, count, local_plane_stride, root, buf, n.value, C.byref(n))
+    if rc != OK:
+        raise SlxError(rc, "slx_gather_plan")
+    return [(m.peer, m.send, m.offset, m.count) for m in buf[: n.value]]
 
 
 def shard_table(shards):

@@ -77,13 +77,13 @@ int check_shards(slx_comm *c, const slx_shard *shards, int height, int width, in
     return SLX_OK;
 }
 
-// One group of sends / receives for the frame-sets [first, first + count) of every rank's shard, counted within the shard
-// (chunk c of a pipelined gather = sets [c * chunk, (c+1) * chunk) of each shard).  `local` addresses this rank's shard as
-// documented at slx_gather_depth.
-int gather_range(slx_comm *c, const slx_shard *shards, int height, int width, int first, int count, const double *local,
-                 size_t local_plane_stride, double *full, int root, hipStream_t s)
+// The messages of one group, as data: what gather_range below posts, in the order it posts them (receives first, then sends).
+// Kept apart from the posting so that the schedule can be checked without a GPU: tests/test_gather_plan.py plays every rank's
+// plan against the others' for worlds of 2..8 -- every send must meet a receive of the same length, in the same order per
+// pair of ranks, and the replayed copies must reassemble [set][H][W].
+int plan_range(const slx_shard *shards, int world, int me, int height, int width, int first, int count, size_t local_plane_stride, int root,
+               std::vector<slx_msg> &out, std::string &why)
 {
-    const int me = c->rank;
     const bool i_receive = root < 0 || root == me;
     const size_t W = (size_t)width, H = (size_t)height;
     auto clip = [&](const slx_shard &sh, int &lo, int &n) {          // sets of the shard that fall into the range
@@ -94,37 +94,64 @@ int gather_range(slx_comm *c, const slx_shard *shards, int height, int width, in
     const size_t lstride = local_plane_stride ? local_plane_stride : (size_t)mine.rows * W;
     int my_lo, my_n;
     clip(mine, my_lo, my_n);
-    const bool in_place = i_receive && local == full + ((size_t)mine.set0 * H + (size_t)mine.row0) * W && lstride == H * W;
     // whole-frame shards travel as ONE message per peer (the receiver posts one receive for the run of sets), so they must be dense
-    if ((size_t)mine.rows == H && lstride != H * W) return cfail(c, SLX_ERR_INVALID_ARG, "a whole-frame shard must be dense (plane stride %zu, frame %zu pixels)", lstride, H * W);
-
-    SLXC_NCCL(c, ncclGroupStart());
-    ncclResult_t r = ncclSuccess;
-    if (i_receive && full) {
-        for (int p = 0; p < c->world && r == ncclSuccess; p++) {
+    if ((size_t)mine.rows == H && lstride != H * W) {
+        why = "a whole-frame shard must be dense";
+        return SLX_ERR_INVALID_ARG;
+    }
+    if (i_receive) {
+        for (int p = 0; p < world; p++) {
             if (p == me) continue;
             const slx_shard &sh = shards[p];
             int lo, n;
             clip(sh, lo, n);
             if (n <= 0 || sh.rows == 0) continue;
             if ((size_t)sh.rows == H) {                              // whole frames: the peer's sets are one contiguous run
-                r = ncclRecv(full + (size_t)(sh.set0 + lo) * H * W, (size_t)n * H * W, ncclDouble, p, c->comm, s);
+                out.push_back({p, 0, (unsigned long long)((size_t)(sh.set0 + lo) * H * W), (unsigned long long)((size_t)n * H * W)});
             } else {
-                for (int k = 0; k < n && r == ncclSuccess; k++)
-                    r = ncclRecv(full + ((size_t)(sh.set0 + lo + k) * H + (size_t)sh.row0) * W, (size_t)sh.rows * W, ncclDouble, p, c->comm, s);
+                for (int k = 0; k < n; k++)
+                    out.push_back({p, 0, (unsigned long long)(((size_t)(sh.set0 + lo + k) * H + (size_t)sh.row0) * W), (unsigned long long)((size_t)sh.rows * W)});
             }
         }
     }
-    if (r == ncclSuccess && my_n > 0 && mine.rows > 0 && local) {
-        for (int d = 0; d < c->world && r == ncclSuccess; d++) {
+    if (my_n > 0 && mine.rows > 0) {
+        for (int d = 0; d < world; d++) {
             if (d == me || !(root < 0 || root == d)) continue;
             if ((size_t)mine.rows == H) {
-                r = ncclSend(local + (size_t)my_lo * lstride, (size_t)my_n * H * W, ncclDouble, d, c->comm, s);
+                out.push_back({d, 1, (unsigned long long)((size_t)my_lo * lstride), (unsigned long long)((size_t)my_n * H * W)});
             } else {
-                for (int k = 0; k < my_n && r == ncclSuccess; k++)
-                    r = ncclSend(local + (size_t)(my_lo + k) * lstride, (size_t)mine.rows * W, ncclDouble, d, c->comm, s);
+                for (int k = 0; k < my_n; k++)
+                    out.push_back({d, 1, (unsigned long long)((size_t)(my_lo + k) * lstride), (unsigned long long)((size_t)mine.rows * W)});
             }
         }
+    }
+    return SLX_OK;
+}
+
+// One group of sends / receives for the frame-sets [first, first + count) of every rank's shard, counted within the shard
+// (chunk c of a pipelined gather = sets [c * chunk, (c+1) * chunk) of each shard).  `local` addresses this rank's shard as
+// documented at slx_gather_depth.
+int gather_range(slx_comm *c, const slx_shard *shards, int height, int width, int first, int count, const double *local,
+                 size_t local_plane_stride, double *full, int root, hipStream_t s)
+{
+    const int me = c->rank;
+    const bool i_receive = root < 0 || root == me;
+    const size_t W = (size_t)width, H = (size_t)height;
+    const slx_shard &mine = shards[me];
+    const size_t lstride = local_plane_stride ? local_plane_stride : (size_t)mine.rows * W;
+    const int my_lo = std::min(first, mine.n_sets), my_n = std::min(first + count, mine.n_sets) - my_lo;
+    const bool in_place = i_receive && local == full + ((size_t)mine.set0 * H + (size_t)mine.row0) * W && lstride == H * W;
+    std::vector<slx_msg> plan;
+    std::string why;
+    int rc = plan_range(shards, c->world, me, height, width, first, count, local_plane_stride, root, plan, why);
+    if (rc != SLX_OK) return cfail(c, rc, "%s", why.c_str());
+
+    SLXC_NCCL(c, ncclGroupStart());
+    ncclResult_t r = ncclSuccess;
+    for (const slx_msg &m : plan) {
+        if (r != ncclSuccess) break;
+        if (m.send) r = ncclSend(local + m.offset, (size_t)m.count, ncclDouble, m.peer, c->comm, s);
+        else r = ncclRecv(full + m.offset, (size_t)m.count, ncclDouble, m.peer, c->comm, s);
     }
     const ncclResult_t rg = ncclGroupEnd();
     if (r != ncclSuccess) return cfail(c, SLX_ERR_HIP, "ncclSend/ncclRecv: %s", ncclGetErrorString(r));
@@ -224,6 +251,20 @@ int slx_comm_adopt(slx_ctx *ctx, void *nccl_comm, slx_comm **out)
     if (dev != c->device) return bail(cfail(c, SLX_ERR_INVALID_ARG, "the communicator lives on device %d, the context on device %d", dev, c->device));
     int rc = finish_create(c, out);
     return rc == SLX_OK ? rc : bail(rc);
+}
+
+int slx_gather_plan(const slx_shard *shards, int world, int rank, int height, int width, int first, int count, size_t local_plane_stride,
+                    int root, slx_msg *out, int capacity, int *n_out)
+{
+    if (!shards || !n_out || world < 1 || rank < 0 || rank >= world || height <= 0 || width <= 0 || root < -1 || root >= world) return SLX_ERR_INVALID_ARG;
+    std::vector<slx_msg> plan;
+    std::string why;
+    const int rc = plan_range(shards, world, rank, height, width, first, count, local_plane_stride, root, plan, why);
+    if (rc != SLX_OK) return rc;
+    *n_out = (int)plan.size();
+    if (out)
+        for (int i = 0; i < (int)plan.size() && i < capacity; i++) out[i] = plan[(size_t)i];
+    return SLX_OK;
 }
 
 int slx_comm_info(const slx_comm *c, int *world, int *rank)
