@@ -138,8 +138,7 @@ int slx_set_frame(slx_ctx *ctx, int group, int idx, const uint8_t *data, size_t 
 /* One frame-set: every stage of the mode, fused, on `stream` (a hipStream_t, or NULL for the
  * context's own stream, which is non-blocking: it does not order itself against work the caller has
  * queued on other streams, the legacy default stream included).  Asynchronous; outputs are read with
- * slx_get_output.  A caller's stream must stay alive until the context is next read (slx_get_*),
- * synchronised or destroyed: the library waits for the decode by recording an event on it then. */
+ * slx_get_output. */
 int slx_decode(slx_ctx *ctx, void *stream);
 
 /* n_sets frame-sets resident in device memory, one launch.  Plane p of set s starts at

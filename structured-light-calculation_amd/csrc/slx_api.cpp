@@ -40,15 +40,11 @@ struct slx_ctx {
     bool timed = false;
     // Completion of the most recent work that wrote the context's outputs or read its staged inputs, on whatever stream it
     // ran (the context's own or a caller's): what a later host copy / staging overwrite / launch on another stream waits for.
-    // No event is recorded per launch (a record costs a packet between dependent launches: 2 us of a 290-us step): the stream
-    // of the most recent work is remembered, and ev_done is recorded on it only when something has to wait for that work --
-    // a later record on the same stream still marks the end of everything queued before it.  A caller's stream must therefore
-    // stay alive until the context is next read, synchronised or destroyed (if recording on it fails, the whole device is
-    // waited for instead).
+    // Work on the context's own stream needs no event: the stream itself can be waited for, and an event is recorded on it
+    // only when another stream has to be ordered behind it (a per-launch record would cost a packet between dependent launches).
     hipEvent_t ev_done = nullptr;
-    hipStream_t ev_stream = nullptr;           // the caller stream of the most recent work
-    bool ev_pending = false;                   // the most recent work ran on a caller's stream
-    bool ev_recorded = false;                  // ... and ev_done has been recorded behind it
+    hipStream_t ev_stream = nullptr;           // the caller stream ev_done was recorded on
+    bool ev_pending = false;                   // the most recent work ran on a caller's stream and ev_done marks its end
     bool own_pending = false;                  // the most recent work ran on the context's own stream
     std::vector<int16_t> lut;
     int16_t *d_lut = nullptr;
@@ -239,31 +235,21 @@ bool ptr_aligned(const void *p, size_t a) { return (reinterpret_cast<uintptr_t>(
 // The three uses of ev_done (see slx_ctx).
 int mark_done(slx_ctx *ctx, hipStream_t s)
 {
-    ctx->own_pending = s == ctx->stream;       // (ordered behind any earlier caller-stream work by order_after_done)
-    ctx->ev_pending = s != ctx->stream;
-    ctx->ev_recorded = false;
-    ctx->ev_stream = s;
-    return SLX_OK;
-}
-// ev_done behind the caller-stream work, if that has not been done yet; false: the work is already known to be complete
-bool caller_event(slx_ctx *ctx)
-{
-    if (!ctx->ev_pending) return false;
-    if (!ctx->ev_recorded) {
-        if (hipEventRecord(ctx->ev_done, ctx->ev_stream) != hipSuccess) {   // the stream is gone: its work still completes
-            (void)hipGetLastError();
-            (void)hipDeviceSynchronize();
-            ctx->ev_pending = false;
-            return false;
-        }
-        ctx->ev_recorded = true;
+    if (s == ctx->stream) {
+        ctx->own_pending = true;               // (ordered behind any earlier caller-stream work by order_after_done)
+        ctx->ev_pending = false;
+        return SLX_OK;
     }
-    return true;
+    SLX_HIP(ctx, hipEventRecord(ctx->ev_done, s));
+    ctx->ev_stream = s;
+    ctx->ev_pending = true;
+    ctx->own_pending = false;
+    return SLX_OK;
 }
 int wait_done_host(slx_ctx *ctx)
 {
     if (ctx->own_pending) SLX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    else if (caller_event(ctx)) SLX_HIP(ctx, hipEventSynchronize(ctx->ev_done));
+    else if (ctx->ev_pending) SLX_HIP(ctx, hipEventSynchronize(ctx->ev_done));
     return SLX_OK;
 }
 int order_after_done(slx_ctx *ctx, hipStream_t s)
@@ -273,7 +259,7 @@ int order_after_done(slx_ctx *ctx, hipStream_t s)
         SLX_HIP(ctx, hipEventRecord(ctx->ev_done, ctx->stream));
         SLX_HIP(ctx, hipStreamWaitEvent(s, ctx->ev_done, 0));
     } else if (ctx->ev_pending && s != ctx->ev_stream) {
-        if (caller_event(ctx)) SLX_HIP(ctx, hipStreamWaitEvent(s, ctx->ev_done, 0));
+        SLX_HIP(ctx, hipStreamWaitEvent(s, ctx->ev_done, 0));
     }
     return SLX_OK;
 }
@@ -306,7 +292,7 @@ void slx_destroy(slx_ctx *ctx)
     for (void *o : ctx->out)
         if (o) (void)hipFree(o);
     if (ctx->d_lut) (void)hipFree(ctx->d_lut);
-    if (ctx->ev_done && caller_event(ctx)) (void)hipEventSynchronize(ctx->ev_done);
+    if (ctx->ev_pending) (void)hipEventSynchronize(ctx->ev_done);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
     for (void *q : {(void *)ctx->d_cloud_counts, (void *)ctx->d_cloud_offsets, (void *)ctx->d_cloud, (void *)ctx->d_stripW_prev,

@@ -18,7 +18,6 @@ phase = torch.randint(0, 256, (n_sets, n_phase, H, W), dtype=torch.uint8, device
 gray = torch.randint(0, 256, (n_sets, n_gray, H, W), dtype=torch.uint8, device="cuda") if n_gray else None
 z = torch.empty((n_sets, H, W), dtype=torch.float64, device="cuda")
 s = torch.cuda.Stream(); torch.cuda.set_stream(s)
-OWN = os.environ.get("GAP_OWN_STREAM") == "1"       # decode on the context's own stream (no completion event per launch)
 ctxs, stamps = [], []
 for i in range(2):
     c = api.Context(spec); c.set_variant(2)
@@ -26,7 +25,7 @@ for i in range(2):
     ctxs.append(c); stamps.append(st)
 for _ in range(150):
     for c in ctxs:
-        c.decode_batch(n_sets, phase, gray, z, stream=None if OWN else s.cuda_stream)
+        c.decode_batch(n_sets, phase, gray, z, stream=s.cuda_stream)
 torch.cuda.synchronize()
 for c, st in zip(ctxs, stamps):
     c.debug_stamps(st)
@@ -34,7 +33,7 @@ e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=Tr
 e0.record(s)
 for _ in range(20):
     for c in ctxs:
-        c.decode_batch(n_sets, phase, gray, z, stream=None if OWN else s.cuda_stream)
+        c.decode_batch(n_sets, phase, gray, z, stream=s.cuda_stream)
 e1.record(s)
 torch.cuda.synchronize()
 print("event-timed launch (stamps on): %.1f us" % (e0.elapsed_time(e1) * 1000 / 40))
