@@ -341,24 +341,28 @@ def run_rank(args):
     ctx = api.Context(spec, device=dev_index)
     ctx.set_variant(args.variant)
     ctx.set_tuning(**tune)
-    stream = torch.cuda.Stream(device=device)      # an explicit stream: the library treats NULL as "my own stream"
-    torch.cuda.set_stream(stream)
-    sh = stream.cuda_stream
-    assert sh != 0
+    # The decode runs on the context's own stream (slx_decode*(…, NULL)), the library's default; the timing events are recorded
+    # on that same stream, wrapped for torch (a launch on a caller's stream would make the library record a completion event
+    # per launch: 2 us between dependent launches, tools/own_stream_test.py).
+    def own_stream(c):
+        return torch.cuda.ExternalStream(c.stream_handle(), device=device)
+    stream = own_stream(ctx)
+    assert stream.cuda_stream != 0
 
-    def timed(fn, n):
+    def timed(fn, n, on=None):
         """n calls of fn bracketed by HIP events on the launch stream: (host seconds, ms per call by the events)."""
+        on = on or stream
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
-        ev0.record(stream)
+        ev0.record(on)
         for _ in range(n):
             fn()
-        ev1.record(stream)
+        ev1.record(on)
         torch.cuda.synchronize()
         return time.perf_counter() - t0, ev0.elapsed_time(ev1) / n
 
     def step():
-        ctx.decode_batch(n_sets, phase, gray, z, stream=sh)
+        ctx.decode_batch(n_sets, phase, gray, z)
 
     # The chip needs ~100 launches of this kernel after an idle spell before its clock settles (tools/ramp.py).  When the
     # caller asks for fewer warm-up steps than that, the difference runs here, untimed and reported as "settle_launches",
@@ -443,6 +447,7 @@ def run_rank(args):
                 set0, gn, row0, grows = table[rank]
                 gctx = api.Context(gspec, device=dev_index)
                 gctx.set_variant(args.variant)
+                gstream = own_stream(gctx)
                 full = torch.empty((total, full_h, W), dtype=torch.float64, device=device) if rank == 0 else None
                 scratch = None if rank == 0 else torch.empty((gn, grows, W), dtype=torch.float64, device=device)
                 torch.cuda.synchronize()
@@ -452,10 +457,10 @@ def run_rank(args):
 
                     def decode_only():
                         gctx.decode_batch_ex(gn, gphase, ggray, z=(full[set0:, row0:] if rank == 0 else scratch),
-                                             plane_stride=(full_h * W if rank == 0 else 0), stream=sh)
+                                             plane_stride=(full_h * W if rank == 0 else 0))
 
                     def decode_and_gather():
-                        comm.decode_gather(table, full_h, args.gather_chunk, gphase, ggray, scratch, full, root=0, stream=sh, ctx=gctx)
+                        comm.decode_gather(table, full_h, args.gather_chunk, gphase, ggray, scratch, full, root=0, ctx=gctx)
 
                     def drain():
                         comm.synchronize()
@@ -464,7 +469,7 @@ def run_rank(args):
                     holder = {}
 
                     def decode_only():
-                        gctx.decode_batch(gn, gphase, ggray, local, stream=sh)
+                        gctx.decode_batch(gn, gphase, ggray, local)
 
                     def decode_and_gather():
                         decode_only()
@@ -477,7 +482,7 @@ def run_rank(args):
                     decode_and_gather()
                 drain()
                 fence()
-                tk, _ = timed(decode_only, reps)
+                tk, _ = timed(decode_only, reps, on=gstream)
                 fence()
                 t0g = time.perf_counter()
                 for _ in range(reps):
@@ -555,12 +560,12 @@ def run_rank(args):
                         octx.set_variant(args.variant)
 
                         def ostep():
-                            octx.decode_batch(sets, oph, ogr, oz, stream=sh)
+                            octx.decode_batch(sets, oph, ogr, oz)
                         for _ in range(60):
                             ostep()
                         torch.cuda.synchronize()
                         n_launch = max(50, min(args.steps, 100))
-                        _, oms = timed(ostep, n_launch)
+                        _, oms = timed(ostep, n_launch, on=own_stream(octx))
                     obytes = sets * ospec["height"] * ospec["width"] * synth.algorithmic_bytes_per_pixel(ospec)
                     oref = O.pipeline(ospec, oph[0].cpu().numpy(), None if ogr is None else ogr[0].cpu().numpy(), want=("z",),
                                       threads=min(len(os.sched_getaffinity(0)), 16))["z"]

@@ -171,6 +171,11 @@ int slx_decode_batch_ex(slx_ctx *ctx, int n_sets,
 
 int slx_synchronize(slx_ctx *ctx);
 
+/* The context's own stream (a hipStream_t), what slx_decode(ctx, NULL) and the tracker run on: for a host that wants to
+ * record its own events on it or make other streams wait for it.  Launches on this stream need no completion event of the
+ * library's own (a launch on a caller's stream records one: about 2 us between dependent launches). */
+int slx_get_stream(slx_ctx *ctx, void **stream);
+
 /* Copies an output of the last slx_decode (waits for it).  dst_bytes must be at least the
  * size listed at enum slx_output. */
 int slx_get_output(slx_ctx *ctx, int which, void *dst, size_t dst_bytes, int mem_kind);

@@ -28,7 +28,7 @@ OUT_NAMES = {"z": OUT_Z, "x": OUT_X, "y": OUT_Y, "U": OUT_U, "pix": OUT_PIX, "gr
 # every symbol include/slx.h declares
 SYMBOLS = [
     "slx_validate_config", "slx_create", "slx_destroy", "slx_last_error", "slx_set_gray_lut",
-    "slx_set_frame", "slx_decode", "slx_decode_batch", "slx_synchronize", "slx_get_output",
+    "slx_set_frame", "slx_decode", "slx_decode_batch", "slx_synchronize", "slx_get_stream", "slx_get_output",
     "slx_get_depth", "slx_get_point_cloud", "slx_track_begin", "slx_track_next", "slx_output_device_ptr", "slx_get_calibration", "slx_enable_timing",
     "slx_last_decode_ms", "slx_debug_stamps", "slx_set_variant", "slx_set_tuning", "slx_read_bmp_gray", "slx_read_pgm_gray", "slx_read_calibration_yaml", "slx_version",
     "slx_decode_batch_ex", "slx_comm_unique_id", "slx_comm_create", "slx_comm_adopt", "slx_comm_destroy", "slx_comm_info", "slx_comm_last_error",
@@ -118,6 +118,7 @@ def lib():
         L.slx_gather_plan.argtypes = [C.POINTER(SlxShard), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, sz, C.c_int, C.POINTER(SlxMsg), C.c_int,
                                       C.POINTER(C.c_int)]
         L.slx_synchronize.argtypes = [vp]
+        L.slx_get_stream.argtypes = [vp, C.POINTER(vp)]
         L.slx_get_output.argtypes = [vp, C.c_int, vp, sz, C.c_int]
         L.slx_get_depth.argtypes = [vp, vp, C.c_int]
         L.slx_get_point_cloud.argtypes = [vp, vp, sz, C.POINTER(sz), C.c_int]
@@ -290,6 +291,12 @@ class Context:
 
     def synchronize(self):
         self._check(lib().slx_synchronize(self._h))
+
+    def stream_handle(self):
+        """The context's own hipStream_t as an integer (wrap it with torch.cuda.ExternalStream to record events on it)."""
+        p = C.c_void_p()
+        self._check(lib().slx_get_stream(self._h, C.byref(p)))
+        return p.value
 
     def output_shape(self, which):
         H, W, F = self.spec["height"], self.spec["width"], self.spec.get("n_freq", 1)

@@ -589,6 +589,13 @@ int slx_synchronize(slx_ctx *ctx)
     return SLX_OK;
 }
 
+int slx_get_stream(slx_ctx *ctx, void **stream)
+{
+    if (!ctx || !stream) return SLX_ERR_INVALID_ARG;
+    *stream = (void *)ctx->stream;
+    return SLX_OK;
+}
+
 int slx_output_device_ptr(slx_ctx *ctx, int which, void **ptr)
 {
     if (!ctx || !ptr) return SLX_ERR_INVALID_ARG;
