@@ -44,6 +44,7 @@ struct SlxKParams {
     const uint8_t *plane_base;                  // lowest plane address: the buffer descriptor's base
     unsigned phase_first, phase_step;
     unsigned gray_first, gray_step;             // only when the Gray planes ride the ring
+    int dma_imm;                                // planes are >= 256 bytes apart: the DMAs of a chunk share one M0 and step by the immediate offset
     long long gray_set_delta;                   // gray_set_stride - phase_set_stride (the descriptor's base advances by phase_set_stride)
     double inv_period[SLX_MAX_FREQ];            // RN(1/T_f)
     double half_biased[SLX_MAX_FREQ];           // 0.5 + 2^-30/T_f

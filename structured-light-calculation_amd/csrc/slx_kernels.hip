@@ -17,6 +17,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <type_traits>
 
 #include "slx_device.h"
 #include "slx_kernels.h"
@@ -603,6 +604,17 @@ __device__ __forceinline__ uint32_t swar_gray_to_binary_u8(uint32_t g)
     return g;
 }
 
+// f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>): a loop whose index is a constant expression inside the
+// body (the immediate offset of a buffer load must be one)
+template <int N, int K = 0, typename Fn>
+__device__ __forceinline__ void static_for(Fn &&f)
+{
+    if constexpr (K < N) {
+        f(std::integral_constant<int, K>{});
+        static_for<N, K + 1>(f);
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // Fast path: waves walking column strips, fringe stack staged through LDS.
 //
@@ -790,19 +802,36 @@ __global__ __launch_bounds__(256) void slx_strip_kernel(const SlxKParams p)
         // every byte is read once: nontemporal loads (+1.6 % on config 4) -- except in the Gray-mask mode, whose halo
         // quads are re-read by the neighbouring wave out of L2 (-10 % with nt there)
         constexpr int POLICY = MASKED ? 0 : 2;
+        // The LDS address of a DMA is M0 + the instruction's immediate offset + 4 lane, and the immediate is added to the global
+        // address as well: with the immediate stepping through the chunk's planes in LDS (256 k) and 256 taken off the running
+        // global offset per plane, M0 is written once per chunk instead of once per load (dma_imm: planes >= 256 bytes apart).
         if (GRAY_CHUNK && cc == 1) {
             unsigned so = gray_first;
+            if (p.dma_imm) {
+                static_for<NGR>([&](auto k) {
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void *)dst, 4, voff, so, decltype(k)::value * 256, POLICY);
+                    if (decltype(k)::value + 1 < NGR) next_plane(so, p.gray_step - 256u);
+                });
+            } else {
 #pragma unroll
-            for (int k = 0; k < NGR; k++) {
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void *)(dst + k * 64), 4, voff, so, 0, POLICY);
-                if (k + 1 < NGR) next_plane(so, p.gray_step);
+                for (int k = 0; k < NGR; k++) {
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void *)(dst + k * 64), 4, voff, so, 0, POLICY);
+                    if (k + 1 < NGR) next_plane(so, p.gray_step);
+                }
             }
         } else {
             unsigned so = p.phase_first + (NS == 4 ? 0u : (unsigned)cc * NPH * p.phase_step);
+            if (p.dma_imm) {
+                static_for<NPH>([&](auto k) {
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void *)dst, 4, voff, so, decltype(k)::value * 256, POLICY);
+                    if (decltype(k)::value + 1 < NPH) next_plane(so, p.phase_step - 256u);
+                });
+            } else {
 #pragma unroll
-            for (int k = 0; k < NPH; k++) {
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void *)(dst + k * 64), 4, voff, so, 0, POLICY);
-                if (k + 1 < NPH) next_plane(so, p.phase_step);
+                for (int k = 0; k < NPH; k++) {
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void *)(dst + k * 64), 4, voff, so, 0, POLICY);
+                    if (k + 1 < NPH) next_plane(so, p.phase_step);
+                }
             }
         }
     };
@@ -1412,6 +1441,7 @@ int slx_launch_fused(const SlxKParams &kp_in, int mode, bool aux, int n_sets, in
     kp.phase_first = 0;
     kp.phase_step = kp.n_freq * kp.n_steps > 1 ? (unsigned)(kp.phase[1] - kp.phase[0]) : 0u;
     kp.gray_first = kp.gray_step = 0;
+    kp.dma_imm = (kp.n_freq * kp.n_steps == 1 || kp.phase_step >= 256u) ? 1 : 0;
     // geometry: `interleave` rows end to end fill whole waves; an item is 64 quads x rows_per_lane rows
     const unsigned QR = kp.quads_per_row;
     unsigned g = QR, h = 64;
@@ -1458,6 +1488,7 @@ int slx_launch_fused(const SlxKParams &kp_in, int mode, bool aux, int n_sets, in
             kp.gray_first = (unsigned)g_first;
             kp.gray_step = (unsigned)gstep;
             kp.gray_set_delta = delta;
+            if (gstep < 256) kp.dma_imm = 0;
         }
     }
     // LDS per wave: 2 ring slots (max(4 n_freq, 2 gb) planes with 4 steps, 8 planes with 8 steps, 256 B each) + 2 KiB of depth staging
