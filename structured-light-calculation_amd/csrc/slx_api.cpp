@@ -73,7 +73,6 @@ struct slx_ctx {
     bool decoded = false;
     int variant = 0;
     SlxTuning tune{};
-    bool lean_checked = false;                 // the lean evaluation's certificate has been computed (ctx->kp.lean says with what outcome)
     std::string err;
 };
 
@@ -463,60 +462,6 @@ int slx_set_gray_lut(slx_ctx *ctx, const int16_t *lut, size_t n)
     return SLX_OK;
 }
 
-// The certificate and the margins of the lean evaluation of the coarser frequencies (slx_kernels.hip: wrapped_pix_lean),
-// once per context: E_f = the largest |lean - exact| over all 511 x 511 inputs of a1 at period T_f, measured on this device;
-// M_f bounds what separates the f32 value s = (U' - pix)/T_f from the exact one:
-//     the two pix errors (E), the error carried by U' (E of the previous stage + one f32 rounding of a value below Umag),
-//     and the f32 roundings of the subtraction, of 1/T_f and of the product (3 * 2^-24 * Umag / T_f)
-// taken twice over.  A configuration whose margins would flag more than a few rows in a thousand keeps the exact kernel.
-int ensure_lean(slx_ctx *ctx)
-{
-    if (ctx->lean_checked) return SLX_OK;
-    ctx->lean_checked = true;
-    SlxKParams &kp = ctx->kp;
-    kp.lean = 0;
-    const slx_config &c = ctx->cfg;
-    const int F = c.n_freq;
-    if (!(c.mode == SLX_MODE_MULTIFREQ || c.mode == SLX_MODE_MULTIFREQ_GRAYMASK) || c.n_steps != 4 || F < 2) return SLX_OK;
-    for (int f = 0; f < F; f++)
-        if (c.period[f] > (1 << 14)) return SLX_OK;
-    unsigned *d_word = nullptr;
-    SLX_HIP(ctx, hipMalloc((void **)&d_word, SLX_MAX_FREQ * sizeof(unsigned)));
-    hipError_t e = hipMemsetAsync(d_word, 0, SLX_MAX_FREQ * sizeof(unsigned), ctx->stream);
-    for (int f = 0; f + 1 < F && e == hipSuccess; f++) {
-        kp.lean_t360[f] = (float)c.period[f] * (1.0f / 360.0f);
-        e = (hipError_t)slx_launch_lean_error((float)c.period[f], kp.lean_t360[f], d_word + f, ctx->stream);
-    }
-    unsigned bits[SLX_MAX_FREQ] = {};
-    if (e == hipSuccess) e = hipMemcpyAsync(bits, d_word, sizeof bits, hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    (void)hipFree(d_word);
-    if (e != hipSuccess) return hip_fail(ctx, e, "lean-evaluation certificate");
-    double E[SLX_MAX_FREQ] = {};
-    for (int f = 0; f + 1 < F; f++) {
-        float m;
-        std::memcpy(&m, &bits[f], sizeof m);
-        if (!(m >= 0.f) || !std::isfinite(m)) return SLX_OK;          // no usable bound: the exact kernel stays
-        E[f] = (double)m * (1.0 + 0x1p-10) + 0x1p-30;                  // strictly above the measured maximum
-    }
-    const double Umag = 2.0 * (double)c.period[0] + 2.0;               // |U|, |U - pix| stay below this
-    double H = E[0], worst = 0.0;
-    for (int f = 1; f < F; f++) {
-        const double T = (double)c.period[f], Ef = f + 1 < F ? E[f] : 0.0;
-        const double B = (H + Ef + 0x1p-24 * Umag) / T + 3.0 * 0x1p-24 * (Umag / T + 1.0) + 0x1p-23 * (Umag / T + 1.0);
-        const double M = 2.0 * B + 0x1p-20;
-        worst = std::max(worst, M);
-        kp.lean_invT[f] = 1.0f / (float)c.period[f];
-        const double hm = 0.5 - M;
-        kp.lean_hm2[f] = std::nextafterf((float)(hm * hm), 0.f);       // rounded down: flags a pixel sooner, never later
-        H = Ef + 0x1p-24 * Umag;
-    }
-    for (int f = 0; f + 1 < F; f++) kp.lean_E2[f] = std::nextafterf((float)(E[f] * E[f]), INFINITY);
-    // flagged pixels per row of 256: about 512 (M_1 + ... ) + 512 sum(E_f / T_f); keep that below a few per cent
-    if (worst < 0x1p-12 && Umag / (double)c.period[F - 1] < 0x1p20) kp.lean = 1;
-    return SLX_OK;
-}
-
 static int launch(slx_ctx *ctx, SlxKParams &kp, int n_sets, bool aux, void *stream)
 {
     const slx_config &c = ctx->cfg;
@@ -540,14 +485,6 @@ static int launch(slx_ctx *ctx, SlxKParams &kp, int n_sets, bool aux, void *stre
     kp.aligned = al ? 1 : 0;
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
     SLX_HIP(ctx, hipSetDevice(ctx->device));
-    if (!aux && ctx->tune.lean != 1 && !ctx->lean_checked && (ctx->variant == SLX_VARIANT_AUTO || ctx->variant == SLX_VARIANT_STRIP)) {
-        if (int rc2 = ensure_lean(ctx)) return rc2;
-        kp.lean = ctx->kp.lean;                 // kp is the caller's copy of ctx->kp, taken before the certificate existed
-        std::memcpy(kp.lean_t360, ctx->kp.lean_t360, sizeof kp.lean_t360);
-        std::memcpy(kp.lean_E2, ctx->kp.lean_E2, sizeof kp.lean_E2);
-        std::memcpy(kp.lean_invT, ctx->kp.lean_invT, sizeof kp.lean_invT);
-        std::memcpy(kp.lean_hm2, ctx->kp.lean_hm2, sizeof kp.lean_hm2);
-    }
     if (ctx->variant == SLX_VARIANT_STRIP && !slx_strip_eligible(kp, c.mode, aux))
         return fail(ctx, SLX_ERR_UNAVAILABLE, "variant %d (strip kernel) cannot run this configuration or these operands", ctx->variant);
     if (ctx->variant == SLX_VARIANT_GENERIC_FAST && !(mode_has_depth(c.mode) && slx_fast_arith_ok(kp)))
@@ -1109,8 +1046,7 @@ int slx_set_tuning(slx_ctx *ctx, int key, int value)
     struct Range { int *field; int lo, hi; };
     SlxTuning &t = ctx->tune;
     const Range r[SLX_TUNE_COUNT] = {{&t.strip_rows, 0, 32}, {&t.tail_pct, -1, 99}, {&t.tail_rows, 0, 32}, {&t.gray_plain, 0, 1},
-                                     {&t.strip_waves, 0, 4}, {&t.lds_pad_kib, 0, 128}, {&t.plain_order, 0, 1}, {&t.tiers, 0, SLX_MAX_TIERS},
-                                     {&t.lean, 0, 1}};
+                                     {&t.strip_waves, 0, 4}, {&t.lds_pad_kib, 0, 128}, {&t.plain_order, 0, 1}, {&t.tiers, 0, SLX_MAX_TIERS}};
     if (key < 0 || key >= SLX_TUNE_COUNT) return fail(ctx, SLX_ERR_INVALID_ARG, "unknown tuning key %d", key);
     if (value < r[key].lo || value > r[key].hi) return fail(ctx, SLX_ERR_INVALID_ARG, "tuning key %d takes values in [%d,%d] (got %d)", key, r[key].lo, r[key].hi, value);
     *r[key].field = value;

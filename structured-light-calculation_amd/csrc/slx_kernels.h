@@ -61,13 +61,6 @@ struct SlxKParams {
     unsigned tier_items_per_set[SLX_MAX_TIERS]; // row groups of the tier * chunks_per_group
     unsigned tier_items[SLX_MAX_TIERS];         // tier_items_per_set * frame-sets of the launch
     unsigned tier_first_wg[SLX_MAX_TIERS], tier_wgs[SLX_MAX_TIERS];
-    // the lean evaluation of the coarser frequencies (slx_kernels.hip: wrapped_pix_lean): set by the host once the measured
-    // error bounds E_f (slx_launch_lean_error) and the margins derived from them are in place
-    int lean;
-    float lean_t360[SLX_MAX_FREQ];              // T_f * RN(1/360)
-    float lean_E2[SLX_MAX_FREQ];                // E_f^2, rounded up: distance from the wrap decision a lean pix must keep
-    float lean_invT[SLX_MAX_FREQ];              // RN(1/T_f)
-    float lean_hm2[SLX_MAX_FREQ];               // (0.5 - M_f)^2, rounded down: distance from a half-integer an order's s must keep
     int fast_arith;                             // generic kernel: use the bit-identical cheap unwrap / in-range division (host-checked)
     int plain_order;                            // Gray-mask strip kernel: items in plain order instead of XCD-grouped (slx_set_tuning, A/B only)
     unsigned long long *stamps;                 // diagnostics: 4 words per work item (s_memtime / s_memrealtime at start, end) or null
@@ -117,7 +110,6 @@ struct SlxTuning {
     int tail_pct;        // share of every frame-set's rows that goes into the shorter tiers, 1..99 (-1: none, one tier)
     int tail_rows;       // rows per item of the second tier (the following tiers quarter it again)
     int tiers;           // number of tiers, 1..SLX_MAX_TIERS
-    int lean;            // 1: never the lean evaluation of the coarser frequencies (A/B runs, tests of the exact kernel)
     int gray_plain;      // 1: Gray planes by ordinary loads instead of the DMA ring
     int strip_waves;     // waves per workgroup, 1..4
     int lds_pad_kib;     // extra LDS per workgroup (lowers the occupancy), 0..128
@@ -132,10 +124,6 @@ int slx_launch_fused(const SlxKParams &kp, int mode, bool aux, int n_sets, int v
 extern "C" int slx_internal_device(const slx_ctx *ctx);
 extern "C" void *slx_internal_stream(const slx_ctx *ctx);
 extern "C" void slx_internal_tile(const slx_ctx *ctx, int *width, int *height);
-
-// Largest |lean - exact| pre-wrap pix over all 511 x 511 inputs of a1 for one period, as the bit pattern of a float, max-ed
-// into *device_word (zero it first).  Returns 0 or a hipError_t.
-int slx_launch_lean_error(float Tf, float t360, unsigned *device_word, void *stream);
 
 // Number of distinct variants slx_launch_fused understands.
 int slx_num_variants(void);

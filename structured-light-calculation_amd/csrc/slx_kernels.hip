@@ -113,7 +113,6 @@ __device__ __forceinline__ F32x2x2 operator+(F32x2x2 x, float y) { return {x.a +
 __device__ __forceinline__ F32x2x2 operator-(F32x2x2 x, float y) { return {x.a - y, x.b - y}; }
 __device__ __forceinline__ F32x2x2 operator-(float x, F32x2x2 y) { return {x - y.a, x - y.b}; }
 __device__ __forceinline__ F32x2x2 operator-(F32x2x2 x) { return {-x.a, -x.b}; }
-__device__ __forceinline__ F32x2x2 operator-(F32x2x2 x, F32x2x2 y) { return {x.a - y.a, x.b - y.b}; }
 __device__ __forceinline__ F32x2x2 operator*(F32x2x2 x, F32x2x2 y) { return {x.a * y.a, x.b * y.b}; }
 __device__ __forceinline__ F32x2x2 operator*(F32x2x2 x, float y) { return {x.a * y, x.b * y}; }
 __device__ __forceinline__ F32x2x2 operator*(float x, F32x2x2 y) { return {x * y.a, x * y.b}; }
@@ -155,7 +154,7 @@ __device__ __forceinline__ F32x2x2 v_mul_sat(F32x2x2 x, float s) { return {v_mul
 // or far above 2^-60), and fma(1 - 2m, a, 180 m) is a where m = 0 and RN(180 - a) where m = 1 -- the same single rounding as
 // the subtraction.  Likewise m = sat((pix - T) * 2^60) is 1 exactly where pix > T (the smallest positive difference is
 // an ulp) and fma(-T, m, pix) is RN(pix - T) or pix.  mc, ms: 1 where the cosine / sine term is negative.
-template <typename V, bool WRAP = true>
+template <typename V>
 __device__ __forceinline__ V pix_from_octant_angle(V a, V mc, V ms, float Tf)
 {
     a = v_fma(v_fma(-2.f, mc, 1.f), a, mc * 180.f);
@@ -164,7 +163,6 @@ __device__ __forceinline__ V pix_from_octant_angle(V a, V mc, V ms, float Tf)
     const V d = v_fma(v_fma(-360.f, d0, a), kInv360, d0);          // RN(a / 360), see the identities above
     V pix = d * Tf;
     pix = pix + 0.5f;
-    if constexpr (!WRAP) return pix;                                // the value the wrap decision is taken on (slx_lean_error_kernel)
     const V mw = v_mul_sat(pix - Tf, 0x1p60f);
     return v_fma(-Tf, mw, pix);
 }
@@ -174,7 +172,7 @@ __device__ __forceinline__ V pix_from_octant_angle(V a, V mc, V ms, float Tf)
 // under a power-of-two scale that stays inside the normal range -- max/min/compare, v_rcp_f32 (a function of the
 // mantissa), the quotient and its residual, the sign tests -- so the result is the same bit for bit; only the
 // 0/0 guard and the saturation factor of the sign tests move with the scale.
-template <bool SCALED, typename V, bool WRAP = true>
+template <bool SCALED, typename V>
 __device__ __forceinline__ V wrapped_pix_from_diffs(V s2, V c2, float Tf)
 {
     constexpr float kGuard = SCALED ? 0x1p-23f : 1.0f;
@@ -189,69 +187,9 @@ __device__ __forceinline__ V wrapped_pix_from_diffs(V s2, V c2, float Tf)
     a = v_sel_gt(as, ac, 90.f - a, a);
     const V mc = SCALED ? v_mul_sat(c2, -0x1p60f) : v_neg_sat(c2);
     const V ms = SCALED ? v_mul_sat(s2, -0x1p60f) : v_neg_sat(s2);
-    return pix_from_octant_angle<V, WRAP>(a, mc, ms, Tf);
+    return pix_from_octant_angle(a, mc, ms, Tf);
 }
 
-// ---- the lean evaluation of the coarser frequencies -----------------------------------------------------------------
-// Only the FINEST frequency's pix enters the projector column U = pix_F + k_F T_F; the coarser ones decide fringe orders
-// and nothing else.  For those, the steps of a1 that exist for bit-exactness alone are left out -- no residual correction of
-// the two divisions, the Horner form with fused multiply-adds, one multiply for /360 * T -- which gives the same value to
-// within E_f, a bound that is MEASURED, not estimated: the inputs of a1 are the 511 x 511 pairs of byte differences, and
-// slx_lean_error_kernel evaluates both sequences on every one of them for the period in question (before the wrap).
-// The fringe orders are then formed in f32 and every pixel PROVES that its orders equal the oracle's:
-//   * |pix' - T| > E_f before the wrap  =>  the exact value lies on the same side of T, both wrap alike, |pix' - pix| <= E_f;
-//   * the distance of s = (U' - pix)/T from the nearest half-integer exceeds M_f, a bound on everything that separates s
-//     from the exact (U - pix)/T: E of the two frequencies involved and the f32 roundings of the few operations in between
-//     (slx_lean_margins)  =>  floor(s + 0.5) is the oracle's k.
-// A pixel that cannot prove it sets the sign bit of `risk`; one ballot per row, and a row with any such pixel is redone by
-// the exact sequence.  With the orders proven, U = fma(k, T, pix_F) in f64 is the oracle's U bit for bit.
-__device__ __forceinline__ void or_bits(f32x2 &acc, f32x2 x)
-{
-    acc.x = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, acc.x) | __builtin_bit_cast(unsigned, x.x));
-    acc.y = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, acc.y) | __builtin_bit_cast(unsigned, x.y));
-}
-__device__ __forceinline__ void or_bits(F32x2x2 &acc, F32x2x2 x)
-{
-    or_bits(acc.a, x.a);
-    or_bits(acc.b, x.b);
-}
-__device__ __forceinline__ f32x2 v_splat(f32x2, float x) { return {x, x}; }
-__device__ __forceinline__ F32x2x2 v_splat(F32x2x2, float x) { return {f32x2{x, x}, f32x2{x, x}}; }
-
-// s2, c2: the differences times 2^-23 (as in wrapped_pix_from_diffs<true>).  t360 = Tf * RN(1/360).  E2 = E_f^2.
-template <typename V, bool WRAP = true>
-__device__ __forceinline__ V wrapped_pix_lean(V s2, V c2, float Tf, float t360, float E2, V &risk)
-{
-    const V as = v_abs(s2), ac = v_abs(c2);
-    const V mx = v_max3(as, ac, 0x1p-23f);
-    const V mn = v_min(as, ac);
-    const V c = mn * v_rcp(mx);
-    const V cc = c * c;
-    V a = v_fma(kP7, cc, kP5);
-    a = v_fma(a, cc, v_splat(a, kP3));
-    a = v_fma(a, cc, v_splat(a, kP1)) * c;
-    a = v_sel_gt(as, ac, 90.f - a, a);
-    const V mc = v_mul_sat(c2, -0x1p60f), ms = v_mul_sat(s2, -0x1p60f);
-    a = v_fma(v_fma(-2.f, mc, 1.f), a, mc * 180.f);
-    a = v_fma(v_fma(-2.f, ms, 1.f), a, ms * 360.f);
-    const V pix = v_fma(t360, a, 0.5f);
-    if constexpr (!WRAP) return pix;
-    const V w = pix - Tf;
-    or_bits(risk, v_fma(w, w, v_splat(w, -E2)));                     // negative: closer to the wrap decision than E
-    return v_fma(-Tf, v_mul_sat(w, 0x1p60f), pix);
-}
-
-// One fringe order in f32 (see above): s = (Uprev - pf) / T; k = the integer nearest to s, by the 1.5 * 2^23 addition;
-// risk |= sign of (0.5 - M)^2 - (s - k)^2.  Returns k as a float.
-template <typename V>
-__device__ __forceinline__ V lean_order(V Uprev, V pf, float invT, float hm2, V &risk)
-{
-    const V s = (Uprev - pf) * invT;
-    const V k = (s + 0x1.8p23f) - 0x1.8p23f;
-    const V e = s - k;
-    or_bits(risk, v_fma(-e, e, v_splat(e, hm2)));
-    return k;
-}
 // a2 literally (any float inputs): used by the x1 path, N != 4.
 __device__ __forceinline__ float fast_atan2_deg(float y, float x)
 {
@@ -748,12 +686,9 @@ __device__ __forceinline__ StripPos strip_locate(const SlxKParams &p, unsigned i
 // the lanes that own the pixels (16 / 4 contiguous bytes per lane).  Planes that were not asked for are "stored" against an
 // empty buffer descriptor, so every step issues the same number of memory instructions -- which the counted s_waitcnt
 // immediates of the DMA ring rely on.
-// LEAN: the coarser frequencies by the lean sequence, fringe orders in f32, every pixel proving its orders (see
-// wrapped_pix_lean); a row with a pixel that cannot is redone exactly.  4 steps, at least 2 frequencies, depth only.
-template <int MODE, int F, int GB, int NS, bool AUX, bool LEAN = false>
+template <int MODE, int F, int GB, int NS, bool AUX>
 __global__ __launch_bounds__(256) void slx_strip_kernel(const SlxKParams p)
 {
-    static_assert(!LEAN || (NS == 4 && F >= 2 && !AUX && MODE != SLX_MODE_GRAY_PHASE), "the lean evaluation covers the 4-step multi-frequency modes");
     constexpr bool MASKED = MODE == SLX_MODE_MULTIFREQ_GRAYMASK;
     constexpr bool HAS_GRAY = MODE == SLX_MODE_GRAY_PHASE || MASKED;
     // The ring moves CHUNKS: with 4 steps a chunk is a whole row of the fringe stack, with 8 steps it is one
@@ -961,8 +896,6 @@ __global__ __launch_bounds__(256) void slx_strip_kernel(const SlxKParams p)
         const unsigned row = pos.row + i * step_rows;
         float pix[F][SLX_QUAD];
         uint32_t gw[GB > 0 ? 2 * GB : 1];
-        uint32_t wraw[LEAN ? (F - 1) * 4 : 1];                          // LEAN: the coarser frequencies' dwords, for a row that has to be redone
-        F32x2x2 risk = {f32x2{0.f, 0.f}, f32x2{0.f, 0.f}};
 #pragma unroll
         for (int c = 0; c < CPR; c++) {
             const unsigned g = i * CPR + c;
@@ -1028,15 +961,9 @@ __global__ __launch_bounds__(256) void slx_strip_kernel(const SlxKParams p)
                     const uint32_t w2 = src[(f * 4 + 2) * 64], w3 = src[(f * 4 + 3) * 64];
                     // differences as denormals (x 2^-149), rescaled to x 2^-23 by one packed multiply per pair
                     const f32x2 kUp = {0x1p126f, 0x1p126f};
-                    const F32x2x2 sd = {f32x2{byte_diff_denorm<0>(w0, w2), byte_diff_denorm<1>(w0, w2)} * kUp, f32x2{byte_diff_denorm<2>(w0, w2), byte_diff_denorm<3>(w0, w2)} * kUp};
-                    const F32x2x2 cd = {f32x2{byte_diff_denorm<0>(w1, w3), byte_diff_denorm<1>(w1, w3)} * kUp, f32x2{byte_diff_denorm<2>(w1, w3), byte_diff_denorm<3>(w1, w3)} * kUp};
-                    F32x2x2 px;
-                    if (LEAN && f + 1 < F) {
-                        px = wrapped_pix_lean(sd, cd, Tf[f], p.lean_t360[f], p.lean_E2[f], risk);
-                        wraw[(LEAN ? f : 0) * 4 + 0] = w0, wraw[(LEAN ? f : 0) * 4 + 1] = w1, wraw[(LEAN ? f : 0) * 4 + 2] = w2, wraw[(LEAN ? f : 0) * 4 + 3] = w3;
-                    } else {
-                        px = wrapped_pix_from_diffs<true>(sd, cd, Tf[f]);
-                    }
+                    const F32x2x2 px = wrapped_pix_from_diffs<true>(
+                        F32x2x2{f32x2{byte_diff_denorm<0>(w0, w2), byte_diff_denorm<1>(w0, w2)} * kUp, f32x2{byte_diff_denorm<2>(w0, w2), byte_diff_denorm<3>(w0, w2)} * kUp},
+                        F32x2x2{f32x2{byte_diff_denorm<0>(w1, w3), byte_diff_denorm<1>(w1, w3)} * kUp, f32x2{byte_diff_denorm<2>(w1, w3), byte_diff_denorm<3>(w1, w3)} * kUp}, Tf[f]);
                     pix[f][0] = px.a.x;
                     pix[f][1] = px.a.y;
                     pix[f][2] = px.b.x;
@@ -1130,52 +1057,16 @@ __global__ __launch_bounds__(256) void slx_strip_kernel(const SlxKParams p)
                     U[j] = grayv + ph;
                 }
             } else {
-                bool exact_unwrap = true;
-                if constexpr (LEAN) {
-                    // the fringe orders in f32, proven per pixel; U = k T + pix of the finest frequency, exact in f64
-                    F32x2x2 Up = {f32x2{pix[0][0], pix[0][1]}, f32x2{pix[0][2], pix[0][3]}}, kv = Up;
+#pragma unroll
+                for (int j = 0; j < SLX_QUAD; j++) {
+                    double Uf = (double)pix[0][j];
 #pragma unroll
                     for (int f = 1; f < F; f++) {
-                        const F32x2x2 pf = {f32x2{pix[f][0], pix[f][1]}, f32x2{pix[f][2], pix[f][3]}};
-                        kv = lean_order(Up, pf, p.lean_invT[f], p.lean_hm2[f], risk);
-                        if (f + 1 < F) Up = v_fma(kv, Tf[f], pf);
+                        int k;
+                        Uf = unwrap_stage<true>(Uf, (double)pix[f][j], p.period[f], kinvT[f], hb[f], k);
+                        if constexpr (AUX && NK > 0) kf[f - 1][j] = k;
                     }
-                    const unsigned bits = __builtin_bit_cast(unsigned, risk.a.x) | __builtin_bit_cast(unsigned, risk.a.y) |
-                                          __builtin_bit_cast(unsigned, risk.b.x) | __builtin_bit_cast(unsigned, risk.b.y);
-                    exact_unwrap = __builtin_amdgcn_ballot_w64((int)bits < 0) != 0ull;          // uniform over the wave
-                    if (!exact_unwrap) {
-                        const double Tl = (double)p.period[F - 1];
-                        const float kq[SLX_QUAD] = {kv.a.x, kv.a.y, kv.b.x, kv.b.y};
-#pragma unroll
-                        for (int j = 0; j < SLX_QUAD; j++) U[j] = __builtin_fma((double)kq[j], Tl, (double)pix[F - 1][j]);
-                    } else {
-                        // some pixel of this row could not prove its fringe orders: the coarser frequencies again, exactly
-#pragma unroll
-                        for (int f = 0; f + 1 < F; f++) {
-                            const uint32_t w0 = wraw[(LEAN ? f : 0) * 4 + 0], w1 = wraw[(LEAN ? f : 0) * 4 + 1], w2 = wraw[(LEAN ? f : 0) * 4 + 2], w3 = wraw[(LEAN ? f : 0) * 4 + 3];
-                            const f32x2 kUp = {0x1p126f, 0x1p126f};
-                            const F32x2x2 px = wrapped_pix_from_diffs<true>(
-                                F32x2x2{f32x2{byte_diff_denorm<0>(w0, w2), byte_diff_denorm<1>(w0, w2)} * kUp, f32x2{byte_diff_denorm<2>(w0, w2), byte_diff_denorm<3>(w0, w2)} * kUp},
-                                F32x2x2{f32x2{byte_diff_denorm<0>(w1, w3), byte_diff_denorm<1>(w1, w3)} * kUp, f32x2{byte_diff_denorm<2>(w1, w3), byte_diff_denorm<3>(w1, w3)} * kUp}, Tf[f]);
-                            pix[f][0] = px.a.x;
-                            pix[f][1] = px.a.y;
-                            pix[f][2] = px.b.x;
-                            pix[f][3] = px.b.y;
-                        }
-                    }
-                }
-                if (exact_unwrap) {
-#pragma unroll
-                    for (int j = 0; j < SLX_QUAD; j++) {
-                        double Uf = (double)pix[0][j];
-#pragma unroll
-                        for (int f = 1; f < F; f++) {
-                            int k;
-                            Uf = unwrap_stage<true>(Uf, (double)pix[f][j], p.period[f], kinvT[f], hb[f], k);
-                            if constexpr (AUX && NK > 0) kf[f - 1][j] = k;
-                        }
-                        U[j] = Uf;
-                    }
+                    U[j] = Uf;
                 }
             }
             if constexpr (MASKED) {                                     // x3, stripe agreement of this lane's pixels
@@ -1394,27 +1285,6 @@ __global__ __launch_bounds__(256) void slx_cloud_write_kernel(const double *z, c
     }
 }
 
-// The certificate of the lean evaluation: the largest distance between the two sequences' pre-wrap pix over ALL inputs of
-// a1 -- the 511 x 511 pairs of byte differences -- for one period.  One lane per input pair; the maximum leaves as the
-// bit pattern of a non-negative float (atomicMax on unsigned keeps float order).
-__global__ __launch_bounds__(256) void slx_lean_error_kernel(float Tf, float t360, unsigned *max_bits)
-{
-    const unsigned i = blockIdx.x * 256u + threadIdx.x;
-    float err = 0.f;
-    if (i < 511u * 511u) {
-        const float ds = (float)((int)(i / 511u) - 255) * 0x1p-23f, dc = (float)((int)(i % 511u) - 255) * 0x1p-23f;
-        const f32x2 S = {ds, ds}, C = {dc, dc};
-        f32x2 risk = {0.f, 0.f};
-        const f32x2 exact = wrapped_pix_from_diffs<true, f32x2, false>(S, C, Tf);
-        const f32x2 lean = wrapped_pix_lean<f32x2, false>(S, C, Tf, t360, 0.f, risk);
-        err = __builtin_fabsf(exact.x - lean.x);
-        if (!(err == err)) err = __builtin_inff();                   // never expected; a NaN must not pass as "small"
-    }
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) err = __builtin_fmaxf(err, __shfl_xor(err, d));
-    if ((threadIdx.x & 63u) == 0u) atomicMax(max_bits, __builtin_bit_cast(unsigned, err));
-}
-
 typedef void (*kernel_fn)(const SlxKParams);
 
 template <int MODE, int F>
@@ -1448,17 +1318,6 @@ kernel_fn pick(int mode, int F, bool n4, bool aux)
     return nullptr;
 }
 
-template <int MODE, int GB>
-kernel_fn pick_strip_lean(int F)
-{
-    switch (F) {
-    case 2: return slx_strip_kernel<MODE, 2, GB, 4, false, true>;
-    case 3: return slx_strip_kernel<MODE, 3, GB, 4, false, true>;
-    case 4: return slx_strip_kernel<MODE, 4, GB, 4, false, true>;
-    }
-    return nullptr;
-}
-
 template <int MODE, int GB, int NS = 4>
 kernel_fn pick_strip(int F, bool aux)
 {
@@ -1474,12 +1333,6 @@ kernel_fn pick_strip(int F, bool aux)
 }  // namespace
 
 int slx_num_variants(void) { return 4; }
-
-int slx_launch_lean_error(float Tf, float t360, unsigned *device_word, void *stream)
-{
-    hipLaunchKernelGGL(slx_lean_error_kernel, dim3((511u * 511u + 255u) / 256u), dim3(256), 0, (hipStream_t)stream, Tf, t360, device_word);
-    return (int)hipGetLastError();
-}
 
 int slx_cloud_entries(int width, int height) { return width * ((height + kCloudTile - 1) / kCloudTile); }
 
@@ -1700,11 +1553,6 @@ int slx_launch_fused(const SlxKParams &kp_in, int mode, bool aux, int n_sets, in
                    : mode == SLX_MODE_MULTIFREQ_GRAYMASK
                        ? (gb ? pick_strip<SLX_MODE_MULTIFREQ_GRAYMASK, 6>(kp.n_freq, aux) : pick_strip<SLX_MODE_MULTIFREQ_GRAYMASK, 0>(kp.n_freq, aux))
                        : (gb ? pick_strip<SLX_MODE_GRAY_PHASE, 6>(1, aux) : pick_strip<SLX_MODE_GRAY_PHASE, 0>(1, aux));
-    // the lean evaluation of the coarser frequencies, when the context holds its certificate (slx_api.cpp: ensure_lean)
-    const bool lean = kp.lean && !aux && kp.n_steps == 4 && kp.n_freq >= 2 && mode != SLX_MODE_GRAY_PHASE && tn.lean != 1;
-    if (lean)
-        fn = mode == SLX_MODE_MULTIFREQ ? pick_strip_lean<SLX_MODE_MULTIFREQ, 0>(kp.n_freq)
-             : (gb ? pick_strip_lean<SLX_MODE_MULTIFREQ_GRAYMASK, 6>(kp.n_freq) : pick_strip_lean<SLX_MODE_MULTIFREQ_GRAYMASK, 0>(kp.n_freq));
     if (!fn) return (int)hipErrorInvalidValue;
     size_t lds = (size_t)waves_per_wg * lds_wave + lds_shared;
     if (tn.lds_pad_kib > 0 && tn.lds_pad_kib <= 128) lds += (size_t)tn.lds_pad_kib * 1024u;   // experiments: lower the occupancy
