@@ -1063,3 +1063,52 @@ def test_cpp_gather_host_loop(tmp_path, oracle, synth, split):
     got = np.fromfile(str(tmp_path / "out.bin"), dtype=np.float64).reshape(sets, H, W)
     for s in range(sets):
         assert np.array_equal(got[s], oracle.pipeline(spec, planes[s], None, want=("z",))["z"], equal_nan=True), s
+
+
+# ------------------------------------------------------------------ multi-frequency: every input of a coarser frequency
+@pytest.mark.parametrize("periods", [[1920, 240, 30], [4096, 512, 64, 8], [1000, 37], [16384, 9], [777, 333, 111]])
+def test_coarse_frequencies_exhaustive_inputs(api, oracle, synth, periods):
+    """The coarser frequencies only decide fringe orders; every one of the 511 x 511 inputs of a coarser frequency, for each
+    coarser frequency in turn, against unstructured bytes in the others: depth through the strip kernel equals the oracle's."""
+    F = len(periods)
+    planes = exhaustive_planes(512)
+    spec = dict(synth.make_spec("C4"), width=512, height=511, periods=periods, n_freq=F)
+    spec["calib"] = synth.scaled_calibration(512, 511, 1920)
+    spec["fov_min"], spec["fov_max"] = -1e300, 1e300
+    rng = np.random.default_rng(F * 1000 + periods[0])
+    for sweep in range(F - 1):
+        ph = rng.integers(0, 256, size=(F * 4, 511, 512), dtype=np.uint8)
+        ph[sweep * 4:sweep * 4 + 4] = planes
+        ref = oracle.pipeline(spec, ph, None, want=("z",), threads=8)["z"]
+        got = api.decode_frameset(spec, ph, None, want=("z",), variant=api.VARIANT_STRIP)["z"]
+        assert np.array_equal(got, ref, equal_nan=True), (periods, sweep, int((got != ref).sum()))
+
+
+def test_fringe_order_ties_and_wrap_edges(api, oracle, synth, torch_cuda):
+    """Inputs that sit ON the decisions of the temporal unwrap: exact ties (quarter-turn phases) and coarse phases at the wrap
+    of pix (angles just below 360 degrees and at 0), mixed with unstructured bytes, as a batch."""
+    torch = torch_cuda
+    spec = small_spec(synth, "C4", 256, 64)
+    spec["fov_min"], spec["fov_max"] = -1e300, 1e300
+    sets = [quadrant_tie_planes(spec)]
+    rng = np.random.default_rng(5)
+    for amp in (255, 200, 3):
+        ph = rng.integers(0, 256, size=(12, 64, 256), dtype=np.uint8)
+        for f in (0, 1):                                               # sine term -1, 0, +1 against a large cosine term: 360-, 0, 0+
+            s = rng.integers(-1, 2, size=(64, 256))
+            ph[f * 4 + 0] = 128 + np.maximum(s, 0)
+            ph[f * 4 + 2] = 128 + np.maximum(-s, 0)
+            ph[f * 4 + 1] = amp
+            ph[f * 4 + 3] = 0
+        sets.append(ph)
+    ref = [oracle.pipeline(spec, ph, None, want=("z",))["z"] for ph in sets]
+    phase = torch.from_numpy(np.stack(sets)).cuda()
+    z = torch.empty((len(sets), 64, 256), dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    with api.Context(spec) as ctx:
+        ctx.set_variant(api.VARIANT_STRIP)
+        ctx.decode_batch(len(sets), phase, None, z)
+        ctx.synchronize()
+    got = z.cpu().numpy()
+    for i in range(len(sets)):
+        assert np.array_equal(got[i], ref[i], equal_nan=True), (i, int((got[i] != ref[i]).sum()))
