@@ -21,6 +21,10 @@
  *        R/CCalculation.cpp:525-592, :666-785            -> slx_decode / slx_decode_batch
  *   CDecode*::GetResult, m_x/y/zMat, m_ProjectorU
  *        R/CDecodePhase.cpp:99, R/CCalculation.h:29-38    -> slx_get_output / slx_get_depth
+ *   m_xMat / m_yMat / m_ProjectorU of a whole batch
+ *        R/CCalculation.cpp:756-771, :589                 -> slx_decode_batch_ex (slx_batch_out)
+ *   (no counterpart: the reference is one process)        -> slx_comm_*, slx_gather_depth, slx_decode_gather:
+ *                                                           one rank per GPU, the final depth-map gather over RCCL
  *   cv::FileStorage (calibration) R/CCalculation.cpp:124  -> slx_read_calibration_yaml
  *   cv::imread (CSensor)          R/CSensorV.cpp:111      -> slx_read_bmp_gray / slx_read_pgm_gray (+ slx::CSensor, csrc/sensor.hpp)
  *   CSensor::GetCamPicture loop   R/CSensorV.cpp:171      -> slx_pipe_* (pinned host slots, copy/decode overlap)
