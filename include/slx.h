@@ -201,6 +201,12 @@ int slx_get_point_cloud(slx_ctx *ctx, double *xyz, size_t capacity_points, size_
  * until the call's work has completed; slx_synchronize). */
 int slx_track_begin(slx_ctx *ctx, const uint8_t *image, size_t stride_bytes, int mem_kind, int window);
 int slx_track_next(slx_ctx *ctx, const uint8_t *image, size_t stride_bytes, int mem_kind);
+/* The pinned buffer (height x width bytes, *stride_bytes = width) the NEXT slx_track_begin / slx_track_next with a host
+ * image stages through, for a host that can let its camera SDK or image reader (CSensor::GetCamFrame, R/CSensor.cpp) write
+ * there: passing exactly this pointer and stride back as the SLX_MEM_HOST image skips the library's own copy into it.
+ * The call returns once the transfer that last used the buffer (two frames ago) has left it; the pointer is valid for one
+ * slx_track_* call and belongs to the context. */
+int slx_track_image_buffer(slx_ctx *ctx, uint8_t **buffer, size_t *stride_bytes);
 
 /* Device pointer of an output buffer owned by the context (valid until slx_destroy). */
 int slx_output_device_ptr(slx_ctx *ctx, int which, void **ptr);

@@ -29,7 +29,7 @@ OUT_NAMES = {"z": OUT_Z, "x": OUT_X, "y": OUT_Y, "U": OUT_U, "pix": OUT_PIX, "gr
 SYMBOLS = [
     "slx_validate_config", "slx_create", "slx_destroy", "slx_last_error", "slx_set_gray_lut",
     "slx_set_frame", "slx_decode", "slx_decode_batch", "slx_synchronize", "slx_get_stream", "slx_get_output",
-    "slx_get_depth", "slx_get_point_cloud", "slx_track_begin", "slx_track_next", "slx_output_device_ptr", "slx_get_calibration", "slx_enable_timing",
+    "slx_get_depth", "slx_get_point_cloud", "slx_track_begin", "slx_track_next", "slx_track_image_buffer", "slx_output_device_ptr", "slx_get_calibration", "slx_enable_timing",
     "slx_last_decode_ms", "slx_debug_stamps", "slx_set_variant", "slx_set_tuning", "slx_read_bmp_gray", "slx_read_pgm_gray", "slx_read_calibration_yaml", "slx_version",
     "slx_decode_batch_ex", "slx_comm_unique_id", "slx_comm_create", "slx_comm_adopt", "slx_comm_destroy", "slx_comm_info", "slx_comm_last_error",
     "slx_comm_synchronize", "slx_gather_depth", "slx_decode_gather", "slx_gather_plan",
@@ -124,6 +124,7 @@ def lib():
         L.slx_get_point_cloud.argtypes = [vp, vp, sz, C.POINTER(sz), C.c_int]
         L.slx_track_begin.argtypes = [vp, vp, sz, C.c_int, C.c_int]
         L.slx_track_next.argtypes = [vp, vp, sz, C.c_int]
+        L.slx_track_image_buffer.argtypes = [vp, C.POINTER(vp), C.POINTER(sz)]
         L.slx_output_device_ptr.argtypes = [vp, C.c_int, C.POINTER(vp)]
         L.slx_get_calibration.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.slx_enable_timing.argtypes = [vp, C.c_int]
@@ -336,6 +337,17 @@ class Context:
         assert image.is_cuda and image.dim() == 2 and image.stride(1) == 1
         self._borrowed.append(image)
         return image.data_ptr(), image.stride(0), MEM_DEVICE
+
+    def track_image_buffer(self):
+        """The pinned staging buffer of the next host-fed track call as a numpy uint8 [H, W] view: fill it and hand it back
+        to track_begin / track_next, which then skips its own copy."""
+        p, stride = C.c_void_p(), C.c_size_t()
+        self._check(lib().slx_track_image_buffer(self._h, C.byref(p), C.byref(stride)))
+        views = self.__dict__.setdefault("_track_views", {})         # two slots: build each numpy view once
+        if p.value not in views:
+            H, W = self.spec["height"], self.spec["width"]
+            views[p.value] = np.ctypeslib.as_array((C.c_uint8 * (H * W)).from_address(p.value)).reshape(H, W)
+        return views[p.value]
 
     def track_begin(self, image, window=21):
         """StripRegression(0) on the first dynamic camera image (numpy uint8 [H,W] or a CUDA tensor)."""

@@ -80,12 +80,13 @@ struct SlxKParams {
 bool slx_fast_arith_ok(const SlxKParams &kp);
 
 // Point cloud compaction (R/CCalculation.cpp:323-357 order: column outer, row inner) over 64 x 64 tiles.
-// counts/offsets: device arrays of slx_cloud_entries(width, height) + 1 unsigned; xyz: device, 3 doubles per point.
-// offsets[entries] is the number of points.  Returns 0 or a hipError_t.
+// counts: device array of slx_cloud_entries(width, height) unsigned; tiles: slx_cloud_tiles(width, height) unsigned;
+// xyz: device, 3 doubles per point, or NULL to learn the number of points only.
 int slx_cloud_entries(int width, int height);
-int slx_launch_cloud_count(const SlxKParams &kp, const double *z, unsigned *counts, void *stream);
-int slx_launch_cloud_scan(int n_entries, const unsigned *counts, unsigned *offsets, void *stream);
-int slx_launch_cloud_write(const SlxKParams &kp, const double *z, const unsigned *offsets, double *xyz, void *stream);
+int slx_cloud_tiles(int width, int height);
+int slx_launch_cloud_count(const SlxKParams &kp, const double *z, unsigned *counts, unsigned *tiles, void *stream);
+int slx_launch_cloud_write(const SlxKParams &kp, const double *z, const unsigned *counts, const unsigned *tiles, double *xyz, unsigned *total_dev,
+                           unsigned *total_host, void *stream);   // total_host: pinned host word or NULL
 
 // Dynamic-frame tracker (slx_track.hip).  Device pointers; 0 or a hipError_t.
 // prevW / prevB / raw non-null: also raw = the deltaP selection between the previous frame's strips and the new ones

@@ -1168,12 +1168,16 @@ __global__ __launch_bounds__(256) void slx_strip_kernel(const SlxKParams p)
 // ------------------------------------------------------------------------------------------
 // Point cloud (CCalculation::Result, R/CCalculation.cpp:323-357): the reference walks u outer / v inner and
 // writes "x y z" for every depth inside the FOV.  Here the depth map is cut into 64 x 64 tiles; the cloud's order
-// (column, then row) is the order of the entries (column u, row block rb = v / 64) laid out as u * RB + rb, so:
-//   count:  entry (u, rb) = kept depths of column u in rows [64 rb, 64 rb + 64)       -- rows read coalesced
-//   scan:   exclusive prefix sum over the entries (one workgroup), entry n = the total
-//   write:  the tile goes through LDS (coalesced rows in, columns out); a wave takes a column, lane = row, the
-//           kept lanes' rank (ballot + popcount below the lane) is the point's place after the entry's offset, and a
-//           column's points leave as one contiguous run of 24-byte records.
+// (column, then row) is the order of the entries (column u, row block rb = v / 64) laid out as u * RB + rb, so a strip of
+// 64 columns (tile column bx) owns the contiguous entries [64 bx RB, 64 (bx + 1) RB).  Two launches, no scan kernel:
+//   count:  entry (u, rb) = kept depths of column u in rows [64 rb, 64 rb + 64) -- rows read coalesced -- and the tile's
+//           total, tiles[bx RB + rb]
+//   write:  a tile's workgroup finds its 64 offsets itself: the tile totals of the strips before it (a few hundred
+//           values, every workgroup sums them), the column totals of its own strip before each column, and the column's
+//           entries above its row block.  The tile then goes through LDS (coalesced rows in, columns out); a wave takes a
+//           column, lane = row, the kept lanes' rank (ballot + popcount below the lane) places the point in the column's
+//           run, the run is packed in LDS and leaves as contiguous doubles, 512 bytes per store.
+// (A single-workgroup scan kernel between the two cost 14-18 us whatever its shape: one workgroup fetching cold code.)
 constexpr int kCloudTile = 64;
 
 __device__ __forceinline__ bool cloud_keep(double zz, double fov_min, double fov_max)
@@ -1181,107 +1185,129 @@ __device__ __forceinline__ bool cloud_keep(double zz, double fov_min, double fov
     return !((zz < fov_min) || (zz > fov_max));                     // the reference's `continue` test, negated
 }
 
-__global__ __launch_bounds__(256) void slx_cloud_count_kernel(const double *z, unsigned *counts, int W, int H, int RB, double fov_min, double fov_max)
+__global__ __launch_bounds__(256) void slx_cloud_count_kernel(const double *z, unsigned *counts, unsigned *tiles, int W, int H, int RB, double fov_min,
+                                                             double fov_max)
 {
     __shared__ unsigned part[4][kCloudTile];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int u = blockIdx.x * kCloudTile + lane, rb = blockIdx.y;
+    const int uu = u < W ? u : W - 1;
+    double zz[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) {                                  // all 16 rows in flight: clamped addresses, masked below
+        const int v = rb * kCloudTile + wave * 16 + k;
+        zz[k] = z[(size_t)(v < H ? v : H - 1) * W + uu];
+    }
     unsigned n = 0;
-    if (u < W) {
-#pragma unroll 4
-        for (int k = 0; k < 16; k++) {
-            const int v = rb * kCloudTile + wave * 16 + k;
-            if (v < H) n += cloud_keep(z[(size_t)v * W + u], fov_min, fov_max) ? 1u : 0u;
-        }
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const int v = rb * kCloudTile + wave * 16 + k;
+        n += (v < H && u < W && cloud_keep(zz[k], fov_min, fov_max)) ? 1u : 0u;
     }
     part[wave][lane] = n;
     __syncthreads();
-    if (wave == 0 && u < W) counts[(size_t)u * RB + rb] = part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane];
+    if (wave == 0) {
+        unsigned col = part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane];
+        if (u < W) counts[(size_t)u * RB + rb] = col;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) col += __shfl_xor(col, d);
+        if (lane == 0) tiles[(size_t)blockIdx.x * RB + rb] = col;
+    }
 }
 
-// offsets[i] = sum of counts[0..i), offsets[n] = total.  One workgroup of 16 waves; n is a few tens of thousands.
-// Each wave owns a contiguous chunk: a first pass sums it, the 16 chunk sums give every wave its base, and a second
-// pass scans the chunk 256 entries at a time -- four consecutive entries per lane, wave shuffles across the lanes.
-__global__ __launch_bounds__(1024) void slx_cloud_scan_kernel(const unsigned *counts, unsigned *offsets, int n)
+// FAST: x and y by slx_div_item_const (fu, fv checked on the host to sit inside its range) -- the same quotient bits.
+// total_dev / total_host: where workgroup (0, 0) leaves the number of points (a device word and a pinned host word).
+template <bool FAST>
+__global__ __launch_bounds__(256) void slx_cloud_write_kernel(const double *z, const unsigned *counts, const unsigned *tiles, double *xyz,
+                                                             unsigned *total_dev, unsigned *total_host, int W, int H, int GX, int RB, int row_offset,
+                                                             double fov_min, double fov_max, double cx, double cy, double fu, double fv)
 {
-    __shared__ unsigned wave_total[16];
+    __shared__ double tile[kCloudTile][kCloudTile + 1];
+    __shared__ double run[4][3 * kCloudTile];                       // a column's records, packed, one wave each
+    __shared__ unsigned col_part[4][kCloudTile], above_part[4][kCloudTile], col_off[kCloudTile], red[8];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int chunk = ((n + 15) / 16 + 255) & ~255;                 // entries per wave, a multiple of 256
-    const int lo = wave * chunk, hi = lo + chunk < n ? lo + chunk : n;
-    auto load4 = [&](int i, unsigned v[4]) {                        // entries i .. i+3, zeros past the chunk
-        if (i + 3 < hi) {
-            const uint4 q = *reinterpret_cast<const uint4 *>(counts + i);   // i is a multiple of 4, hipMalloc aligns the base
-            v[0] = q.x, v[1] = q.y, v[2] = q.z, v[3] = q.w;
-        } else {
+    const int u0 = blockIdx.x * kCloudTile, rb = blockIdx.y, v0 = rb * kCloudTile;
+    const int u = u0 + lane, uu = u < W ? u : W - 1;
+    double zz[16];
 #pragma unroll
-            for (int j = 0; j < 4; j++) v[j] = i + j < hi ? counts[i + j] : 0u;
+    for (int k = 0; k < 16; k++) {                                  // rows in, 512 contiguous bytes per wave, all in flight
+        const int v = v0 + wave * 16 + k;
+        zz[k] = z[(size_t)(v < H ? v : H - 1) * W + uu];
+    }
+    // offsets, while those loads fly.  (1) points before this strip, and all points:
+    const int n_tiles = GX * RB, before = (int)blockIdx.x * RB;
+    unsigned s_before = 0, s_all = 0;
+    for (int i = threadIdx.x; i < n_tiles; i += 256) {
+        const unsigned t = tiles[i];
+        s_all += t;
+        s_before += i < before ? t : 0u;
+    }
+    // (2) this strip: column lane's total and its entries above row block rb, a quarter of the row blocks per wave
+    unsigned c_all = 0, c_above = 0;
+    if (u < W) {
+        const unsigned *col = counts + (size_t)u * RB;
+        for (int r = wave; r < RB; r += 4) {
+            const unsigned t = col[r];
+            c_all += t;
+            c_above += r < rb ? t : 0u;
         }
-    };
-    unsigned sum = 0;
-    for (int i = lo + 4 * lane; i < hi; i += 256) {
-        unsigned v[4];
-        load4(i, v);
-        sum += (v[0] + v[1]) + (v[2] + v[3]);
     }
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) sum += __shfl_xor(sum, d);
-    if (lane == 0) wave_total[wave] = sum;
+    for (int d = 32; d >= 1; d >>= 1) {
+        s_before += __shfl_xor(s_before, d);
+        s_all += __shfl_xor(s_all, d);
+    }
+    if (lane == 0) red[wave] = s_before, red[4 + wave] = s_all;
+    col_part[wave][lane] = c_all;
+    above_part[wave][lane] = c_above;
+#pragma unroll
+    for (int k = 0; k < 16; k++) tile[wave * 16 + k][lane] = zz[k];  // rows / columns past the image: masked by v < H, u < W below
     __syncthreads();
-    unsigned run = 0;
-    for (int w = 0; w < wave; w++) run += wave_total[w];
-    for (int i0 = lo; i0 < hi; i0 += 256) {
-        const int i = i0 + 4 * lane;
-        unsigned v[4];
-        load4(i, v);
-        const unsigned mine = (v[0] + v[1]) + (v[2] + v[3]);
+    if (wave == 0) {
+        const unsigned mine = col_part[0][lane] + col_part[1][lane] + col_part[2][lane] + col_part[3][lane];
         unsigned incl = mine;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
             const unsigned t = __shfl_up(incl, d);
             if (lane >= d) incl += t;
         }
-        unsigned o = run + incl - mine;                             // exclusive offset of this lane's first entry
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            if (i + j < hi) offsets[i + j] = o;
-            o += v[j];
+        col_off[lane] = (red[0] + red[1] + red[2] + red[3]) + (incl - mine) + (above_part[0][lane] + above_part[1][lane] + above_part[2][lane] + above_part[3][lane]);
+        if (blockIdx.x == 0 && blockIdx.y == 0 && lane == 0) {
+            const unsigned total = red[4] + red[5] + red[6] + red[7];
+            *total_dev = total;
+            if (total_host) *total_host = total;
         }
-        run += __shfl(incl, 63);
-    }
-    if (threadIdx.x == 1023) {
-        unsigned total = 0;
-        for (int w = 0; w < 16; w++) total += wave_total[w];
-        offsets[n] = total;
-    }
-}
-
-__global__ __launch_bounds__(256) void slx_cloud_write_kernel(const double *z, const unsigned *offsets, double *xyz, int W, int H, int RB, int row_offset,
-                                                             double fov_min, double fov_max, double cx, double cy, double fu, double fv)
-{
-    __shared__ double tile[kCloudTile][kCloudTile + 1];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int u0 = blockIdx.x * kCloudTile, rb = blockIdx.y, v0 = rb * kCloudTile;
-    for (int k = 0; k < 16; k++) {                                  // rows in, 512 contiguous bytes per wave
-        const int r = wave * 16 + k, v = v0 + r, u = u0 + lane;
-        tile[r][lane] = (v < H && u < W) ? z[(size_t)v * W + u] : __builtin_nan("");   // NaN passes the reference's test: masked by v < H below
     }
     __syncthreads();
+    if (!xyz) return;                                               // count only: the caller wanted the number of points
     const int v = v0 + lane;
     const double vc = (double)(v + row_offset) - cy;                // R/CCalculation.cpp:763
+    const double ru = FAST ? slx_refined_rcp_f64(fu) : 0.0, rv = FAST ? slx_refined_rcp_f64(fv) : 0.0;
+    double *mine = run[wave];
     for (int k = 0; k < 16; k++) {
-        const int c = wave * 16 + k, u = u0 + c;
-        if (u >= W) break;                                          // uniform over the wave
-        const double zz = tile[lane][c];
-        const bool keep = v < H && cloud_keep(zz, fov_min, fov_max);
+        const int c = wave * 16 + k, uc_i = u0 + c;
+        if (uc_i >= W) break;                                       // uniform over the wave
+        const double zc = tile[lane][c];
+        const bool keep = v < H && cloud_keep(zc, fov_min, fov_max);
         const unsigned long long m = __builtin_amdgcn_ballot_w64(keep);
         if (keep) {
             const unsigned rank = (unsigned)__builtin_popcountll(m & ((1ull << lane) - 1ull));
-            const size_t o = ((size_t)offsets[(size_t)u * RB + rb] + rank) * 3;
-            const double uc = (double)u - cx;                       // :762
-            xyz[o + 0] = zz * uc / fu;                              // :766
-            xyz[o + 1] = zz * vc / fv;                              // :767
-            xyz[o + 2] = zz;
+            const double uc = (double)uc_i - cx;                    // :762
+            mine[3 * rank + 0] = FAST ? slx_div_item_const(zc * uc, fu, ru) : zc * uc / fu;   // :766
+            mine[3 * rank + 1] = FAST ? slx_div_item_const(zc * vc, fv, rv) : zc * vc / fv;   // :767
+            mine[3 * rank + 2] = zc;
         }
+        // the column's records leave as one contiguous run of doubles, 512 bytes per store (a wave's LDS accesses
+        // execute in order: the reads below see the writes above, and the next column's writes come after these reads)
+        __builtin_amdgcn_wave_barrier();
+        const unsigned words = 3u * (unsigned)__builtin_popcountll(m);
+        double *dst = xyz + (size_t)col_off[c] * 3;
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            const unsigned w = (unsigned)lane + 64u * j;
+            if (w < words) dst[w] = mine[w];
+        }
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -1336,25 +1362,26 @@ int slx_num_variants(void) { return 4; }
 
 int slx_cloud_entries(int width, int height) { return width * ((height + kCloudTile - 1) / kCloudTile); }
 
-int slx_launch_cloud_count(const SlxKParams &kp, const double *z, unsigned *counts, void *stream)
+int slx_cloud_tiles(int width, int height) { return ((width + kCloudTile - 1) / kCloudTile) * ((height + kCloudTile - 1) / kCloudTile); }
+
+int slx_launch_cloud_count(const SlxKParams &kp, const double *z, unsigned *counts, unsigned *tiles, void *stream)
 {
     const int RB = (kp.height + kCloudTile - 1) / kCloudTile;
-    hipLaunchKernelGGL(slx_cloud_count_kernel, dim3((kp.width + kCloudTile - 1) / kCloudTile, RB), dim3(256), 0, (hipStream_t)stream, z, counts, kp.width,
-                       kp.height, RB, kp.fov_min, kp.fov_max);
+    hipLaunchKernelGGL(slx_cloud_count_kernel, dim3((kp.width + kCloudTile - 1) / kCloudTile, RB), dim3(256), 0, (hipStream_t)stream, z, counts, tiles,
+                       kp.width, kp.height, RB, kp.fov_min, kp.fov_max);
     return (int)hipGetLastError();
 }
 
-int slx_launch_cloud_scan(int n_entries, const unsigned *counts, unsigned *offsets, void *stream)
-{
-    hipLaunchKernelGGL(slx_cloud_scan_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, counts, offsets, n_entries);
-    return (int)hipGetLastError();
-}
-
-int slx_launch_cloud_write(const SlxKParams &kp, const double *z, const unsigned *offsets, double *xyz, void *stream)
+int slx_launch_cloud_write(const SlxKParams &kp, const double *z, const unsigned *counts, const unsigned *tiles, double *xyz, unsigned *total_dev,
+                           unsigned *total_host, void *stream)
 {
     const int RB = (kp.height + kCloudTile - 1) / kCloudTile;
-    hipLaunchKernelGGL(slx_cloud_write_kernel, dim3((kp.width + kCloudTile - 1) / kCloudTile, RB), dim3(256), 0, (hipStream_t)stream, z, offsets, xyz,
-                       kp.width, kp.height, RB, kp.row_offset, kp.fov_min, kp.fov_max, kp.cx, kp.cy, kp.fu, kp.fv);
+    auto in_range = [](double d) { return __builtin_fabs(d) > 0x1p-90 && __builtin_fabs(d) < 0x1p90; };
+    auto fn = in_range(kp.fu) && in_range(kp.fv) ? slx_cloud_write_kernel<true> : slx_cloud_write_kernel<false>;
+    const int GX = (kp.width + kCloudTile - 1) / kCloudTile;
+    // without a target only the number of points is wanted: workgroup (0, 0) alone sums the tile totals
+    hipLaunchKernelGGL(fn, xyz ? dim3(GX, RB) : dim3(1, 1), dim3(256), 0, (hipStream_t)stream, z, counts, tiles, xyz, total_dev,
+                       total_host, kp.width, kp.height, GX, RB, kp.row_offset, kp.fov_min, kp.fov_max, kp.cx, kp.cy, kp.fu, kp.fv);
     return (int)hipGetLastError();
 }
 

@@ -596,6 +596,50 @@ def test_dynamic_frames_device_images_full_size(api, oracle, synth, torch_cuda):
             sw0, sb0, z_prev = sw1, sb1, tri["z"]
 
 
+def test_dynamic_frames_fed_through_the_pinned_buffer(api, oracle, synth):
+    """slx_track_image_buffer: images written straight into the staging slot (no library copy), mixed with ordinary host
+    images and a strided one, give the oracle's frames; the two slots alternate."""
+    h, w = 64, 200
+    spec = small_spec(synth, "C1x4", w, h)
+    ph, gr, _ = synth.render(spec, "tilted", noise_sigma=2.0)
+    ref0 = oracle.pipeline(spec, ph, gr, want=("z", "U"))
+    imgs = dyna_images(h, w, 8, seed=77)
+    with api.Context(spec, aux=("U",)) as ctx:
+        ctx.set_frames(ph, gr)
+        ctx.decode()
+        buf = ctx.track_image_buffer()
+        assert buf.shape == (h, w) and buf.dtype == np.uint8
+        buf[:] = imgs[0]
+        ctx.track_begin(buf)
+        seen = {buf.ctypes.data}
+        sw0, sb0 = oracle.strip_regression(imgs[0])
+        U = ref0["U"]
+        for f in range(1, 8):
+            if f % 3 == 0:
+                ctx.track_next(imgs[f])                              # the library copies
+            elif f == 4:
+                wide = np.zeros((h, w + 24), dtype=np.uint8)
+                wide[:, :w] = imgs[f]
+                ctx.track_next(wide[:, :w])                          # strided host image
+            else:
+                buf = ctx.track_image_buffer()
+                again = ctx.track_image_buffer()                     # asking twice hands out the same slot
+                assert again.ctypes.data == buf.ctypes.data
+                seen.add(buf.ctypes.data)
+                buf[:] = imgs[f]
+                ctx.track_next(buf)
+            sw1, sb1 = oracle.strip_regression(imgs[f])
+            U = U + oracle.delta_p(sw0, sb0, sw1, sb1).astype(np.float64)
+            assert np.array_equal(ctx.get_output("U"), U), f
+            assert np.array_equal(ctx.get_depth(), oracle.triangulate(spec, U)["z"], equal_nan=True), f
+            sw0, sb0 = sw1, sb1
+        assert len(seen) == 2
+    with api.Context(spec) as ctx:                                   # no U plane: no tracker, no buffer
+        with pytest.raises(api.SlxError) as e:
+            ctx.track_image_buffer()
+        assert e.value.code == api.ERR_UNAVAILABLE
+
+
 # ------------------------------------------------------------------ sharding on the device
 def test_row_tiles_and_frameset_shards_on_gpu(api, oracle, synth, shard):
     spec = small_spec(synth, "C3", 128, 50)

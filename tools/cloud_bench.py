@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Time of the point-cloud compaction (slx_get_point_cloud into device memory: count, scan, write + the 4-byte
-point count read back) on the GPU box.  Usage: tools/cloud_bench.py [--config C4] [--reps 50]"""
+"""Time of the point-cloud compaction (slx_get_point_cloud into device memory: count, write, one stream wait; the
+point count arrives in a pinned host word) on the GPU box.  Usage: tools/cloud_bench.py [--config C4] [--reps 50]"""
 import argparse
 import ctypes as C
 import importlib
