@@ -30,6 +30,7 @@
  *   CSensor::GetCamPicture loop   R/CSensorV.cpp:171      -> slx_pipe_* (pinned host slots, copy/decode overlap)
  *   CCalculation::Result          R/CCalculation.cpp:323  -> slx_get_point_cloud (+ slx::CCalculation::Result text writer)
  *   CCalculation::CalculateOther  R/CCalculation.cpp:208  -> slx_track_begin / slx_track_next (+ slx::CCalculation::CalculateOther)
+ *   the Mat GetCamPicture returns R/CSensorV.cpp:171-179  -> slx_track_image_buffer (the deep copy lands in the pinned slot directly)
  *   ~CCalculation / ReleaseSpace  R/CCalculation.cpp:30   -> slx_destroy
  *   ErrorHandling(msg)            R/GlobalFunction.cpp:3  -> int status + slx_last_error
  *                                                           (never prints, never blocks)
@@ -202,7 +203,7 @@ int slx_get_point_cloud(slx_ctx *ctx, double *xyz, size_t capacity_points, size_
 int slx_track_begin(slx_ctx *ctx, const uint8_t *image, size_t stride_bytes, int mem_kind, int window);
 int slx_track_next(slx_ctx *ctx, const uint8_t *image, size_t stride_bytes, int mem_kind);
 /* The pinned buffer (height x width bytes, *stride_bytes = width) the NEXT slx_track_begin / slx_track_next with a host
- * image stages through, for a host that can let its camera SDK or image reader (CSensor::GetCamFrame, R/CSensor.cpp) write
+ * image stages through, for a host that can let its camera SDK or image reader (CSensor::GetCamPicture's deep copy, R/CSensorV.cpp:171-179) write
  * there: passing exactly this pointer and stride back as the SLX_MEM_HOST image skips the library's own copy into it.
  * The call returns once the transfer that last used the buffer (two frames ago) has left it; the pointer is valid for one
  * slx_track_* call and belongs to the context. */
