@@ -28,7 +28,7 @@
  *   cv::FileStorage (calibration) R/CCalculation.cpp:124  -> slx_read_calibration_yaml
  *   cv::imread (CSensor)          R/CSensorV.cpp:111      -> slx_read_bmp_gray / slx_read_pgm_gray (+ slx::CSensor, csrc/sensor.hpp)
  *   CSensor::GetCamPicture loop   R/CSensorV.cpp:171      -> slx_pipe_* (pinned host slots, copy/decode overlap)
- *   CCalculation::Result          R/CCalculation.cpp:323  -> slx_get_point_cloud (+ slx::CCalculation::Result text writer)
+ *   CCalculation::Result          R/CCalculation.cpp:323  -> slx_get_point_cloud / slx_point_cloud_of_depth (+ slx::CCalculation::Result text writer)
  *   CCalculation::CalculateOther  R/CCalculation.cpp:208  -> slx_track_begin / slx_track_next (+ slx::CCalculation::CalculateOther)
  *   the Mat GetCamPicture returns R/CSensorV.cpp:171-179  -> slx_track_image_buffer (the deep copy lands in the pinned slot directly)
  *   ~CCalculation / ReleaseSpace  R/CCalculation.cpp:30   -> slx_destroy
@@ -192,6 +192,10 @@ int slx_get_depth(slx_ctx *ctx, double *z, int mem_kind);
  * xyz: room for `capacity_points` triples (host or device per mem_kind); *n_points receives the number of valid points
  * (also when it exceeds the capacity, in which case SLX_ERR_INVALID_ARG is returned and nothing is copied). */
 int slx_get_point_cloud(slx_ctx *ctx, double *xyz, size_t capacity_points, size_t *n_points, int mem_kind);
+/* The same for any depth map of the context's geometry in device memory (height x width f64, contiguous): one plane of
+ * slx_decode_batch's output, so that a batch host loop gets CCalculation::Result's data per frame-set without another
+ * decode.  Ordered after the context's last launch (whatever stream it ran on); `depth` is borrowed until the call returns. */
+int slx_point_cloud_of_depth(slx_ctx *ctx, const double *depth, double *xyz, size_t capacity_points, size_t *n_points, int mem_kind);
 
 /* Dynamic frames, CCalculation::CalculateOther (R/CCalculation.cpp:208-320).  The context must be a depth mode created
  * with SLX_OUT_U in aux_outputs and hold a decoded frame 0.

@@ -29,7 +29,7 @@ OUT_NAMES = {"z": OUT_Z, "x": OUT_X, "y": OUT_Y, "U": OUT_U, "pix": OUT_PIX, "gr
 SYMBOLS = [
     "slx_validate_config", "slx_create", "slx_destroy", "slx_last_error", "slx_set_gray_lut",
     "slx_set_frame", "slx_decode", "slx_decode_batch", "slx_synchronize", "slx_get_stream", "slx_get_output",
-    "slx_get_depth", "slx_get_point_cloud", "slx_track_begin", "slx_track_next", "slx_track_image_buffer", "slx_output_device_ptr", "slx_get_calibration", "slx_enable_timing",
+    "slx_get_depth", "slx_get_point_cloud", "slx_point_cloud_of_depth", "slx_track_begin", "slx_track_next", "slx_track_image_buffer", "slx_output_device_ptr", "slx_get_calibration", "slx_enable_timing",
     "slx_last_decode_ms", "slx_debug_stamps", "slx_set_variant", "slx_set_tuning", "slx_read_bmp_gray", "slx_read_pgm_gray", "slx_read_calibration_yaml", "slx_version",
     "slx_decode_batch_ex", "slx_comm_unique_id", "slx_comm_create", "slx_comm_adopt", "slx_comm_destroy", "slx_comm_info", "slx_comm_last_error",
     "slx_comm_synchronize", "slx_gather_depth", "slx_decode_gather", "slx_gather_plan",
@@ -122,6 +122,7 @@ def lib():
         L.slx_get_output.argtypes = [vp, C.c_int, vp, sz, C.c_int]
         L.slx_get_depth.argtypes = [vp, vp, C.c_int]
         L.slx_get_point_cloud.argtypes = [vp, vp, sz, C.POINTER(sz), C.c_int]
+        L.slx_point_cloud_of_depth.argtypes = [vp, vp, vp, sz, C.POINTER(sz), C.c_int]
         L.slx_track_begin.argtypes = [vp, vp, sz, C.c_int, C.c_int]
         L.slx_track_next.argtypes = [vp, vp, sz, C.c_int]
         L.slx_track_image_buffer.argtypes = [vp, C.POINTER(vp), C.POINTER(sz)]
@@ -329,6 +330,20 @@ class Context:
         a = np.empty((n.value, 3), dtype=np.float64)
         self._check(lib().slx_get_point_cloud(self._h, a.ctypes.data, n.value, C.byref(n), MEM_HOST))
         return a
+
+    def point_cloud_of_depth(self, depth, out=None):
+        """Cloud of a depth plane in device memory (a CUDA f64 tensor [H, W], e.g. one frame-set of decode_batch's z).
+        out: a CUDA f64 tensor [H*W, 3] to fill (returns the number of points), or None for a numpy array [n, 3]."""
+        H, W = self.spec["height"], self.spec["width"]
+        assert depth.is_cuda and depth.is_contiguous() and tuple(depth.shape) == (H, W) and depth.element_size() == 8
+        n = C.c_size_t(0)
+        if out is not None:
+            assert out.is_cuda and out.is_contiguous() and out.element_size() == 8 and out.numel() % 3 == 0
+            self._check(lib().slx_point_cloud_of_depth(self._h, depth.data_ptr(), out.data_ptr(), out.numel() // 3, C.byref(n), MEM_DEVICE))
+            return n.value
+        a = np.empty((H * W, 3), dtype=np.float64)
+        self._check(lib().slx_point_cloud_of_depth(self._h, depth.data_ptr(), a.ctypes.data, H * W, C.byref(n), MEM_HOST))
+        return a[:n.value].copy()
 
     def _image_args(self, image):
         if isinstance(image, np.ndarray):

@@ -632,9 +632,18 @@ int slx_get_depth(slx_ctx *ctx, double *z, int mem_kind)
 int slx_get_point_cloud(slx_ctx *ctx, double *xyz, size_t capacity_points, size_t *n_points, int mem_kind)
 {
     if (!ctx || !n_points) return SLX_ERR_INVALID_ARG;
+    if (!mode_has_depth(ctx->cfg.mode)) return fail(ctx, SLX_ERR_UNAVAILABLE, "mode %d produces no depth", ctx->cfg.mode);
+    if (!ctx->decoded) return fail(ctx, SLX_ERR_NOT_DECODED, "no decode has run yet");
+    return slx_point_cloud_of_depth(ctx, (const double *)ctx->out[SLX_OUT_Z], xyz, capacity_points, n_points, mem_kind);
+}
+
+int slx_point_cloud_of_depth(slx_ctx *ctx, const double *depth, double *xyz, size_t capacity_points, size_t *n_points, int mem_kind)
+{
+    if (!ctx || !n_points) return SLX_ERR_INVALID_ARG;
     const slx_config &c = ctx->cfg;
     if (!mode_has_depth(c.mode)) return fail(ctx, SLX_ERR_UNAVAILABLE, "mode %d produces no depth", c.mode);
-    if (!ctx->decoded) return fail(ctx, SLX_ERR_NOT_DECODED, "no decode has run yet");
+    if (!depth) return fail(ctx, SLX_ERR_INVALID_ARG, "depth is NULL");
+    if ((uintptr_t)depth % sizeof(double)) return fail(ctx, SLX_ERR_INVALID_ARG, "depth is not aligned to 8 bytes");
     if (mem_kind != SLX_MEM_HOST && mem_kind != SLX_MEM_DEVICE) return fail(ctx, SLX_ERR_INVALID_ARG, "unknown mem_kind %d", mem_kind);
     SLX_HIP(ctx, hipSetDevice(ctx->device));
     if (int rc = order_after_done(ctx, ctx->stream)) return rc;   // the decode may have run on a caller stream: device-side wait only
@@ -643,7 +652,7 @@ int slx_get_point_cloud(slx_ctx *ctx, double *xyz, size_t capacity_points, size_
     if (!ctx->d_cloud_tiles) SLX_HIP(ctx, hipMalloc((void **)&ctx->d_cloud_tiles, ((size_t)n_tiles + 1) * sizeof(unsigned)));   // + the total
     if (!ctx->h_cloud_total) SLX_HIP(ctx, hipHostMalloc((void **)&ctx->h_cloud_total, sizeof(unsigned), hipHostMallocDefault));
     unsigned *total_dev = ctx->d_cloud_tiles + n_tiles;
-    const double *z = (const double *)ctx->out[SLX_OUT_Z];
+    const double *z = depth;
     int e = slx_launch_cloud_count(ctx->kp, z, ctx->d_cloud_counts, ctx->d_cloud_tiles, ctx->stream);
     if (e != 0) return hip_fail(ctx, (hipError_t)e, "point-cloud count");
     // The write kernel can follow at once when its target cannot overflow (a device buffer for every pixel, or the

@@ -640,6 +640,53 @@ def test_dynamic_frames_fed_through_the_pinned_buffer(api, oracle, synth):
         assert e.value.code == api.ERR_UNAVAILABLE
 
 
+@pytest.mark.parametrize("shape", [(70, 200), (64, 64), (129, 65), (5, 700)])
+def test_point_cloud_of_a_batch_plane(api, oracle, synth, torch_cuda, shape):
+    """slx_point_cloud_of_depth: the cloud (CCalculation::Result's data) of every frame-set of a batch decode, straight from
+    the batch's depth planes, into host memory and into a device buffer; a context that never ran a single-set decode;
+    tiles ragged in both directions; a plane with no point inside the FOV; refused inputs."""
+    torch = torch_cuda
+    h, w = shape
+    spec = small_spec(synth, "C4", w, h)
+    sets = [synth.render(spec, kind, seed=5 + i, noise_sigma=2.0)[:2] for i, kind in enumerate(("tilted", "sphere", "tilted"))]
+    zs = oracle.pipeline(spec, *sets[0], want=("z",))["z"]
+    spec["fov_min"], spec["fov_max"] = float(np.percentile(zs[zs > 0], 20)), float(np.percentile(zs[zs > 0], 85))   # a partial cloud
+    want = [oracle.pipeline(spec, ph, gr, want=("z",))["z"] for ph, gr in sets]
+    phase = torch.from_numpy(np.stack([ph for ph, _ in sets])).cuda()
+    z = torch.full((4, h, w), -1.0, dtype=torch.float64, device="cuda")      # plane 3: never decoded, every depth outside the FOV
+    z[3] = spec["fov_max"] + 1.0
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    with api.Context(spec) as ctx:
+        ctx.decode_batch(3, phase, None, z[:3], stream=side.cuda_stream)     # the cloud orders itself after this launch
+        dev = torch.full((h * w, 3), np.nan, dtype=torch.float64, device="cuda")
+        for i in range(3):
+            ref = oracle.point_cloud(spec, want[i])
+            got = ctx.point_cloud_of_depth(z[i])
+            assert got.shape == ref.shape and np.array_equal(got, ref), i
+            n = ctx.point_cloud_of_depth(z[i], out=dev)
+            assert n == len(ref) and np.array_equal(dev[:n].cpu().numpy(), ref), i
+        assert 0 < len(oracle.point_cloud(spec, want[0])) < h * w
+        assert ctx.point_cloud_of_depth(z[3]).shape == (0, 3)
+        small = torch.empty((1, 3), dtype=torch.float64, device="cuda")
+        if len(oracle.point_cloud(spec, want[0])) > 1:
+            with pytest.raises(api.SlxError) as e:
+                ctx.point_cloud_of_depth(z[0], out=small)                   # too small: refused, the count is still reported
+            assert e.value.code == api.ERR_INVALID_ARG
+        n = C_size(0)
+        assert api.lib().slx_point_cloud_of_depth(ctx._h, None, None, 0, n, api.MEM_DEVICE) == api.ERR_INVALID_ARG
+        assert api.lib().slx_point_cloud_of_depth(ctx._h, z.data_ptr() + 4, None, 0, n, api.MEM_DEVICE) == api.ERR_INVALID_ARG
+    pspec = {"width": w, "height": h, "mode": synth.MODE_PHASE_ONLY, "n_freq": 1, "n_steps": 4, "periods": [40]}   # no depth, no cloud
+    with api.Context(pspec) as ctx:
+        n = C_size(0)
+        assert api.lib().slx_point_cloud_of_depth(ctx._h, z.data_ptr(), None, 0, n, api.MEM_DEVICE) == api.ERR_UNAVAILABLE
+
+
+def C_size(v):
+    import ctypes
+    return ctypes.byref(ctypes.c_size_t(v))
+
+
 # ------------------------------------------------------------------ sharding on the device
 def test_row_tiles_and_frameset_shards_on_gpu(api, oracle, synth, shard):
     spec = small_spec(synth, "C3", 128, 50)
