@@ -154,7 +154,7 @@ def parse_args(argv=None):
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE", help="slx_set_tuning override (tools only), e.g. --tune strip_rows=8")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-other-configs", action="store_true", help="N = 1: skip the short C3 / C5 timings reported under other_configs")
+    ap.add_argument("--no-other-configs", action="store_true", help="N = 1: skip the short timings of the other configurations reported under other_configs")
     ap.add_argument("--no-gather", action="store_true",
                     help="N > 1: skip the gather timings (decode + RCCL gather of the depth maps to rank 0, reported as with_gather)")
     ap.add_argument("--shard", choices=("framesets", "rows"), default="framesets",
@@ -343,7 +343,7 @@ def run_rank(args):
     ctx.set_tuning(**tune)
     # The decode runs on the context's own stream (slx_decode*(…, NULL)), the library's default; the timing events are recorded
     # on that same stream, wrapped for torch (a launch on a caller's stream would make the library record a completion event
-    # per launch: 2 us between dependent launches, tools/own_stream_test.py).
+    # per launch: 2 us between dependent launches, tools/own_stream_bench.py).
     def own_stream(c):
         return torch.cuda.ExternalStream(c.stream_handle(), device=device)
     stream = own_stream(ctx)
@@ -545,39 +545,54 @@ def run_rank(args):
             if not parity:
                 raise SystemExit("bench: frame-set 0 differs from the oracle -- refusing to report a number")
         if world == 1 and not args.no_other_configs:
-            # the other single-GPU BASELINE configurations, >= 50 launches each after a short settle, so that every one of
-            # them has a number taken by this run's clock; parity of frame-set 0 against the oracle for each
+            # every other configuration the boundary serves, >= 50 launches each after a short settle, so that each has a
+            # number taken by this run's clock, and parity of frame-set 0 against the oracle for each:
+            #   C3, C5, C2   the other single-GPU BASELINE configurations
+            #   REF          the reference's own compiled-in case (x4: 1280x1024, 6-bit Gray + 4-step), 24 B/px
+            #   C4+xyUk      slx_decode_batch_ex with x, y, U, k beside z -- what the reference computes for every frame
+            #                (R/CCalculation.cpp:756-771); its OWN bytes, 20 + 24 + 8 = 52 B/px, never mixed into the 20 B/px figure
+            #   C4x1, REFx1  ONE frame-set per launch: the call the reference makes (CCalculation::CalculateFirst)
             other = {}
-            for name, sets in (("C3", 16), ("C5", 4)):
-                if name == args.config:
+            threads = min(len(os.sched_getaffinity(0)), 16)
+            for label, name, sets, aux in (("C3", "C3", 16, ()), ("C5", "C5", 4, ()), ("REF", "REF", 32, ()), ("C2", "C2", 32, ()),
+                                           ("C4+xyUk", "C4", 16, ("x", "y", "U", "k")), ("C4x1", "C4", 1, ()), ("REFx1", "REF", 1, ())):
+                if label == args.config:
                     continue
                 try:
                     ospec = synth.make_spec(name)
-                    oph, ogr = make_batch(torch, synth, ospec, sets, device, seed=0x5EED + int(name[1]))
-                    oz = torch.empty((sets, ospec["height"], ospec["width"]), dtype=torch.float64, device=device)
+                    oH, oW = ospec["height"], ospec["width"]
+                    oph, ogr = make_batch(torch, synth, ospec, sets, device, seed=0x5EED + sum(map(ord, label)))
+                    outs = {"z": torch.empty((sets, oH, oW), dtype=torch.float64, device=device)}
+                    for p in aux:
+                        outs[p] = (torch.empty((sets, ospec["n_freq"] - 1, oH, oW), dtype=torch.int32, device=device) if p == "k"
+                                   else torch.empty((sets, oH, oW), dtype=torch.float64, device=device))
+                    aux_bpp = sum(4 * (ospec["n_freq"] - 1) if p == "k" else 8 for p in aux)
                     torch.cuda.synchronize()
                     with api.Context(ospec, device=dev_index) as octx:
                         octx.set_variant(args.variant)
 
                         def ostep():
-                            octx.decode_batch(sets, oph, ogr, oz)
+                            octx.decode_batch_ex(sets, oph, ogr, **outs)
                         for _ in range(60):
                             ostep()
                         torch.cuda.synchronize()
-                        n_launch = max(50, min(args.steps, 100))
+                        n_launch = max(50, min(args.steps, 100)) * (4 if sets == 1 else 1)
                         _, oms = timed(ostep, n_launch, on=own_stream(octx))
-                    obytes = sets * ospec["height"] * ospec["width"] * synth.algorithmic_bytes_per_pixel(ospec)
-                    oref = O.pipeline(ospec, oph[0].cpu().numpy(), None if ogr is None else ogr[0].cpu().numpy(), want=("z",),
-                                      threads=min(len(os.sched_getaffinity(0)), 16))["z"]
-                    otraffic, osource = traffic_entry(name, sets)
-                    other[name] = {"value": sets / (oms * 1e-3), "unit": "frames/s", "sets_per_launch": sets, "launches": n_launch, "launch_ms": oms,
-                                   "roofline": {"bound": "hbm", "achieved": obytes / (oms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                                                "frac": obytes / (oms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "traffic": otraffic, "traffic_source": osource,
-                                                "kernel": kernel_name(ospec, args.variant), "algorithmic_bytes_per_launch": obytes},
-                                   "parity_vs_oracle": bool(np.array_equal(oz[0].cpu().numpy(), oref, equal_nan=True))}
-                    del oph, ogr, oz
+                    obytes = sets * oH * oW * (synth.algorithmic_bytes_per_pixel(ospec) + aux_bpp)
+                    oref = O.pipeline(ospec, oph[0].cpu().numpy(), None if ogr is None else ogr[0].cpu().numpy(), want=("z",) + tuple(aux), threads=threads)
+                    ok = all(bool(np.array_equal(outs[p][0].cpu().numpy(), oref[p], equal_nan=True)) for p in ("z",) + tuple(aux))
+                    otraffic, osource = (None, "not measured") if aux or sets == 1 else traffic_entry(name, sets)
+                    other[label] = {"value": sets / (oms * 1e-3), "unit": "frames/s", "sets_per_launch": sets, "launches": n_launch, "launch_ms": oms,
+                                    "outputs": ["z"] + list(aux), "bytes_per_pixel": synth.algorithmic_bytes_per_pixel(ospec) + aux_bpp,
+                                    "roofline": {"bound": "hbm", "achieved": obytes / (oms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                                 "frac": obytes / (oms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "traffic": otraffic, "traffic_source": osource,
+                                                 "kernel": kernel_name(ospec, args.variant), "algorithmic_bytes_per_launch": obytes},
+                                    "parity_vs_oracle": ok}
+                    if sets == 1:
+                        other[label]["note"] = "back-to-back dependent launches: launch_ms includes the gap between two launches"
+                    del oph, ogr, outs
                 except Exception as e:
-                    other[name] = {"error": "%s: %s" % (type(e).__name__, e)}
+                    other[label] = {"error": "%s: %s" % (type(e).__name__, e)}
         result = make_result(gather, cpu_single, cpu_multi, parity, other)
         print(json.dumps(result), flush=True)
     ctx.close()

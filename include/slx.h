@@ -143,7 +143,12 @@ int slx_set_frame(slx_ctx *ctx, int group, int idx, const uint8_t *data, size_t 
 /* One frame-set: every stage of the mode, fused, on `stream` (a hipStream_t, or NULL for the
  * context's own stream, which is non-blocking: it does not order itself against work the caller has
  * queued on other streams, the legacy default stream included).  Asynchronous; outputs are read with
- * slx_get_output. */
+ * slx_get_output.
+ * Ordering between launches of ONE context: every launch (slx_decode, slx_decode_batch*, the tracker, the point cloud) is
+ * ordered on the device behind the context's previous launch, whichever streams the two ran on -- also two batch decodes
+ * on two caller streams whose buffers have nothing in common.  A context is one in-order queue of work; a host that wants
+ * two decodes to overlap uses two contexts (they share nothing).  The library keeps no handle of a caller's stream beyond
+ * the call: the stream may be destroyed as soon as the call has returned. */
 int slx_decode(slx_ctx *ctx, void *stream);
 
 /* n_sets frame-sets resident in device memory, one launch.  Plane p of set s starts at

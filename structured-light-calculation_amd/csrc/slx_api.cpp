@@ -43,8 +43,9 @@ struct slx_ctx {
     // ran (the context's own or a caller's): what a later host copy / staging overwrite / launch on another stream waits for.
     // Work on the context's own stream needs no event: the stream itself can be waited for, and an event is recorded on it
     // only when another stream has to be ordered behind it (a per-launch record would cost a packet between dependent launches).
+    // No handle of a caller's stream is ever kept: the caller may destroy the stream right after the call (and a new stream
+    // may get the same handle value), so nothing here records on, waits on or compares against a remembered caller stream.
     hipEvent_t ev_done = nullptr;
-    hipStream_t ev_stream = nullptr;           // the caller stream ev_done was recorded on
     bool ev_pending = false;                   // the most recent work ran on a caller's stream and ev_done marks its end
     bool own_pending = false;                  // the most recent work ran on the context's own stream
     std::vector<int16_t> lut;
@@ -243,7 +244,6 @@ int mark_done(slx_ctx *ctx, hipStream_t s)
         return SLX_OK;
     }
     SLX_HIP(ctx, hipEventRecord(ctx->ev_done, s));
-    ctx->ev_stream = s;
     ctx->ev_pending = true;
     ctx->own_pending = false;
     return SLX_OK;
@@ -260,7 +260,10 @@ int order_after_done(slx_ctx *ctx, hipStream_t s)
         if (s == ctx->stream) return SLX_OK;   // same stream: already ordered
         SLX_HIP(ctx, hipEventRecord(ctx->ev_done, ctx->stream));
         SLX_HIP(ctx, hipStreamWaitEvent(s, ctx->ev_done, 0));
-    } else if (ctx->ev_pending && s != ctx->ev_stream) {
+    } else if (ctx->ev_pending) {
+        // always through the event, also when s looks like the stream it was recorded on: the runtime knows whether the
+        // event's queue is this stream's (and then enqueues nothing); a remembered handle value would not -- the caller may
+        // have destroyed that stream and been handed the same value for a new one while the old work is still in flight
         SLX_HIP(ctx, hipStreamWaitEvent(s, ctx->ev_done, 0));
     }
     return SLX_OK;
@@ -288,15 +291,16 @@ void slx_destroy(slx_ctx *ctx)
 {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
+    // first every wait -- work on a caller's stream (through its event: the stream itself may be gone by now), the context's
+    // own streams -- and only then the frees
+    if (ctx->ev_pending) (void)hipEventSynchronize(ctx->ev_done);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
     if (ctx->phase_slab) (void)hipFree(ctx->phase_slab);
     if (ctx->gray_slab) (void)hipFree(ctx->gray_slab);
     for (void *o : ctx->out)
         if (o) (void)hipFree(o);
     if (ctx->d_lut) (void)hipFree(ctx->d_lut);
-    if (ctx->ev_pending) (void)hipEventSynchronize(ctx->ev_done);
-    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-    if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
     for (void *q : {(void *)ctx->d_cloud_counts, (void *)ctx->d_cloud_tiles, (void *)ctx->d_cloud, (void *)ctx->d_stripW_prev,
                     (void *)ctx->d_stripB_prev, (void *)ctx->d_deltaP_raw, (void *)ctx->d_track_img[0], (void *)ctx->d_track_img[1]})
         if (q) (void)hipFree(q);

@@ -117,6 +117,9 @@ struct SlxTuning {
     int plain_order;     // 1: Gray-mask items in plain order instead of XCD-grouped
 };
 
+// Rows per work item the strip kernel's launcher picks (host-side model, exported for the CPU tests).
+extern "C" unsigned slx_strip_rows_model(unsigned height, unsigned interleave, unsigned chunks_per_group, unsigned n_sets, unsigned slots_per_cu, unsigned preferred);
+
 // Launches the fused kernel for `n_sets` frame-sets on `stream` (hipStream_t).
 // Returns 0, or a hipError_t value.  `variant` selects a kernel variant, `tune` (may be null) the item geometry.
 int slx_launch_fused(const SlxKParams &kp, int mode, bool aux, int n_sets, int variant, void *stream, const SlxTuning *tune = nullptr);

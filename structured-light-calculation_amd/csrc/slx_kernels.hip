@@ -1451,6 +1451,43 @@ static int launch_generic(const SlxKParams &kp, int mode, bool aux, int n_sets, 
     return (int)hipGetLastError();
 }
 
+// Rows per work item of the strip kernel, from the measured sweeps of tools/single_set.py (profiles/r03_rows_sweep.json):
+//  * a launch that fills the chip several times over (>= 15 360 items = 3.75 per resident wave slot) takes the kernel's
+//    preferred item: 16 rows for the Gray-free 4-step kernels (VALU-bound; 16 rows amortise an item's start-up best and
+//    the tiers below cut the drain), 3 rows where the Gray planes ride the ring (REF 166 vs 176 us at 8 rows and 220 at 16,
+//    C3 218 vs 226 / 238: those kernels wait for their DMA, and short items keep the waves of a SIMD out of step), 10 rows
+//    for 8 steps (C5: 368 vs 407 us at 16);
+//  * a launch of the VALU-bound kernels too small for that gets ONE round of items when items of <= 10 rows can cover it -- the smallest item count
+//    that fits the resident wave slots, so every slot works from the first cycle to the last and nothing is left for a
+//    thinly filled second round: one 1920x1200 frame-set (9 000 wave-rows for 4 096 slots; the call the reference makes,
+//    R/CCalculation.cpp:171-206) runs as 3 000 items of 3 rows in 13.2 us, against 14.7 us as 9 000 items of one row;
+//  * in between, the largest item that still gives 15 360 items.
+unsigned slx_strip_rows_model(unsigned height, unsigned interleave, unsigned chunks_per_group, unsigned n_sets, unsigned slots_per_cu, unsigned preferred)
+{
+    const unsigned long long slots = 256ull * std::max(1u, slots_per_cu), many = 256ull * 20ull * 3ull;
+    auto items = [&](unsigned r) {
+        const unsigned long long rows_group = (unsigned long long)interleave * r;
+        return ((height + rows_group - 1) / rows_group) * chunks_per_group * (unsigned long long)n_sets;
+    };
+    const unsigned cand[] = {16, 12, 10, 8, 6, 5, 4, 3, 2, 1};
+    if (preferred < 1 || preferred > 16) preferred = 16;
+    if (items(preferred) >= many) return preferred;
+    if (preferred <= 3) {
+        // the DMA-bound Gray kernels like short items whatever the launch: 3 rows while that gives 1.5 items per slot
+        // (4 frame-sets of the reference's size: 27.1 us, against 29.6 us as one round of 6-row items), else 2, else 1
+        // (one frame-set at 1280x1024: 2 560 items of 2 rows; C3's single frame-set 20.6 us at 2 rows, 21.7 at 3)
+        if (items(3) * 2 >= slots * 3) return 3;
+        return items(2) * 2 >= slots ? 2 : 1;
+    }
+    unsigned one_round = 0;                                          // smallest item that covers the launch in one round
+    for (unsigned r : cand)
+        if (items(r) <= slots) one_round = r;
+    if (one_round >= 1 && one_round <= 10) return one_round;
+    for (unsigned r : cand)
+        if (r <= preferred && items(r) >= many) return r;
+    return 1;
+}
+
 int slx_launch_fused(const SlxKParams &kp_in, int mode, bool aux, int n_sets, int variant, void *stream, const SlxTuning *tune)
 {
     const SlxTuning none{};
@@ -1476,20 +1513,7 @@ int slx_launch_fused(const SlxKParams &kp_in, int mode, bool aux, int n_sets, in
     kp.interleave = 64u / g;
     kp.chunks_per_group = mode == SLX_MODE_MULTIFREQ_GRAYMASK ? (kp.interleave * QR + 61u) / 62u   // 62 quads + 2 halo lanes per wave
                                                              : kp.interleave * QR / 64u;
-    // rows per item: 16 amortises the item start-up (locate, column constants, ring fill: ~2 % of 16 rows);
-    // smaller launches take smaller items so that the chip still sees ~3 waves per wave slot
-    unsigned rb = 16;
-    {
-        const unsigned long long want_waves = 256ull * 20ull * 3ull;
-        auto waves_at = [&](unsigned r) {
-            const unsigned long long rows_group = (unsigned long long)kp.interleave * r;
-            return (((unsigned)kp.height + rows_group - 1) / rows_group) * kp.chunks_per_group * (unsigned long long)n_sets;
-        };
-        while (rb > 1 && waves_at(rb) < want_waves) rb /= 2;
-    }
     kp.plain_order = tn.plain_order ? 1 : 0;
-    // <= 32 rows: slx_strip_eligible bounds the 32-bit output offsets for interleave (<= 64) x 32 rows past the tile
-    if (tn.strip_rows >= 1 && tn.strip_rows <= 32) rb = (unsigned)tn.strip_rows;
     // Gray planes ride the DMA ring when there are 6 bits of them (the reference's and config 3's count) and every
     // plane, in every frame-set of the launch, sits within 2 GiB above the lowest plane; otherwise the kernel reads
     // them with ordinary loads
@@ -1521,6 +1545,13 @@ int slx_launch_fused(const SlxKParams &kp_in, int mode, bool aux, int n_sets, in
     // LDS per wave: 2 ring slots (max(4 n_freq, 2 gb) planes with 4 steps, 8 planes with 8 steps, 256 B each) + 2 KiB of depth staging
     const unsigned ring_planes = kp.n_steps == 4 ? std::max((unsigned)kp.n_freq * 4u, 2u * (unsigned)gb) : 8u;
     const unsigned lds_wave = 2u * ring_planes * 256u + 2048u + (aux ? 2048u : 0u);      // + the optional planes' staging area
+    // rows per item (slx_strip_rows_model): the kernel's preferred item for a launch that fills the chip many times over,
+    // one round of items for a small one
+    const unsigned slots_per_cu = std::min(16u, 160u * 1024u / lds_wave);
+    const unsigned preferred = kp.n_steps == 8 ? 10u : gb ? 3u : 16u;
+    unsigned rb = slx_strip_rows_model((unsigned)kp.height, kp.interleave, kp.chunks_per_group, (unsigned)n_sets, slots_per_cu, preferred);
+    // <= 32 rows: slx_strip_eligible bounds the 32-bit output offsets for interleave (<= 64) x 32 rows past the tile
+    if (tn.strip_rows >= 1 && tn.strip_rows <= 32) rb = (unsigned)tn.strip_rows;
     // Tiers: the head of every frame-set in items of rb rows, then shorter items (a quarter of the previous tier's rows)
     // for the last tail_pct % of the rows; with more than two tiers each takes 60 % of what is left, the last one all of
     // it.  Short items run last and cut the end of the launch, where the chip drains for about one item's lifetime.
@@ -1530,7 +1561,7 @@ int slx_launch_fused(const SlxKParams &kp_in, int mode, bool aux, int n_sets, in
     if (tn.tiers >= 1 && tn.tiers <= SLX_MAX_TIERS) tiers = (unsigned)tn.tiers;
     const unsigned rows_group = kp.interleave * rb;
     const unsigned groups = ((unsigned)kp.height + rows_group - 1) / rows_group;
-    if (!(rb >= 8 && tail_rb >= 1 && tail_rb < rb && tail_pct > 0 && tail_pct < 100 && groups >= 4)) tiers = 1;
+    if (!(rb >= 8 && tail_rb >= 1 && tail_rb < rb && tail_pct > 0 && tail_pct < 100 && groups >= 4)) tiers = 1;   // (tiers below 8 rows: tried on REF and C3 at 3 rows, no gain)
     // waves per workgroup: as many as keep the most waves resident in the CU's 160 KiB of LDS (16 at most: 4 per SIMD)
     const unsigned lds_shared = 0u;                                     // nothing is shared between the waves of a workgroup
     unsigned waves_per_wg = 4u;

@@ -445,6 +445,72 @@ def test_decode_on_caller_stream_and_timing(api, oracle, synth, torch_cuda):
         assert np.array_equal(z[0].cpu().numpy(), ref, equal_nan=True)
 
 
+def _hip_runtime():
+    """The HIP runtime already loaded into this process, for a stream the test itself creates and destroys (a torch stream comes
+    from torch's pool and is never destroyed)."""
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipStreamCreateWithFlags.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_uint]
+    hip.hipStreamDestroy.argtypes = [ctypes.c_void_p]
+    hip.hipStreamSynchronize.argtypes = [ctypes.c_void_p]
+    return hip, ctypes
+
+
+def test_caller_stream_destroyed_right_after_the_decode(api, oracle, synth, torch_cuda):
+    """Round-2 fault (a lazily recorded event on a stream the caller had destroyed crashed slx_destroy): the library keeps no
+    handle of a caller's stream.  Decode on a stream of our own, destroy the stream at once, then read, decode on a NEW stream
+    (which may get the old handle value), read again, close."""
+    torch = torch_cuda
+    hip, ctypes = _hip_runtime()
+    spec = small_spec(synth, "C2", 256, 64)
+    sets = [synth.random_planes(spec, seed=70 + i)[0] for i in range(3)]
+    refs = [oracle.pipeline(spec, p, None, want=("z",))["z"] for p in sets]
+    devs = [torch.from_numpy(p).cuda() for p in sets]
+    torch.cuda.synchronize()
+    ctx = api.Context(spec)
+    for i in range(3):
+        s = ctypes.c_void_p()
+        assert hip.hipStreamCreateWithFlags(ctypes.byref(s), 1) == 0          # hipStreamNonBlocking
+        ctx.set_frames(devs[i], None)
+        ctx.decode(stream=s.value)
+        assert hip.hipStreamDestroy(s) == 0                                    # pending work completes, the handle is dead
+        assert np.array_equal(ctx.get_depth(), refs[i], equal_nan=True), i
+    # the last launch ran on a stream that no longer exists: the own-stream launch that follows is ordered through the event
+    ctx.set_frames(devs[0], None)
+    ctx.decode()
+    assert np.array_equal(ctx.get_depth(), refs[0], equal_nan=True)
+    s = ctypes.c_void_p()
+    assert hip.hipStreamCreateWithFlags(ctypes.byref(s), 1) == 0
+    ctx.set_frames(devs[1], None)
+    ctx.decode(stream=s.value)
+    assert hip.hipStreamDestroy(s) == 0
+    ctx.close()                                                                # waits through the event, then frees
+
+
+def test_pipe_destroyed_before_its_context(api, oracle, synth):
+    """The pipe's decode stream is a caller's stream to the context: destroying the pipe (and its streams) first, then reading
+    from and destroying the context, must neither crash nor lose the ordering."""
+    spec = small_spec(synth, "C2", 128, 40)
+    ph, _ = synth.random_planes(spec, seed=77)
+    ref = oracle.pipeline(spec, ph, None, want=("z",))["z"]
+    ctx = api.Context(spec)
+    pipe = api.Pipe(ctx, slots=2, sets_per_slot=1, host_result=True)
+    W = spec["width"]
+    buf = pipe.acquire()
+    buf[0, :, :, :W] = ph
+    pipe.submit(1)
+    got = np.array(pipe.collect()[0], copy=True)
+    buf = pipe.acquire()
+    buf[0, :, :, :W] = ph
+    pipe.submit(1)                      # still in flight when the pipe goes
+    pipe.close()
+    ctx.set_frames(ph, None)
+    ctx.decode()
+    assert np.array_equal(ctx.get_depth(), ref, equal_nan=True)
+    ctx.close()
+    assert np.array_equal(got.reshape(ref.shape), ref, equal_nan=True)
+
+
 def test_error_paths_on_device(api, synth):
     spec = small_spec(synth, "C1x4", 32, 8)
     ph, gr = synth.random_planes(spec, seed=1)

@@ -1,0 +1,90 @@
+#!/usr/bin/env python3
+"""Small launches of the decode -- the call the reference actually makes (CCalculation::CalculateFirst decodes ONE frame-set,
+R/CCalculation.cpp:171-206) and the 150-row tile of an 8-way row split -- timed warm, per rows-per-item choice.
+Usage: tools/single_set.py [--work C4x1,REFx1,REFx1+xyU,X4x1+xyU,C4tile32,C3x1,C5x1] [--rows 0,1,2,3,4,6,8] [--launches 200]
+rows = 0 is the library's own choice.  Two numbers per arm: `kernel_us` = event-to-event time around single launches (what a
+kernel trace calls the duration, plus the events' own cost), `back_to_back_us` = N dependent launches / N."""
+import argparse, importlib, json, os, statistics, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+synth = importlib.import_module("structured-light-calculation_amd.synth")
+api = importlib.import_module("structured-light-calculation_amd.api")
+shard = importlib.import_module("structured-light-calculation_amd.shard")
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--work", default="C4x1,REFx1,REFx1+xyU,X4x1+xyU,C4tile32")
+ap.add_argument("--rows", default="0,1,2,3,4,6,8")
+ap.add_argument("--launches", type=int, default=200)
+ap.add_argument("--rounds", type=int, default=5)
+ap.add_argument("--extra", default="", help="more tuning keys for every arm, e.g. tail_pct=-1")
+a = ap.parse_args()
+extra = {k: int(v) for k, v in (e.split("=") for e in a.extra.split(",") if e)}
+
+
+def workload(name):
+    """spec, n_sets, aux planes"""
+    aux = ()
+    if name.endswith("+xyU"):
+        name, aux = name[:-4], ("x", "y", "U")
+    if name.endswith("+xyUk"):
+        name, aux = name[:-5], ("x", "y", "U", "k")
+    if name.startswith("X4x"):                      # the reference's own mode at 1920 x 1200
+        spec = dict(synth.make_spec("REF"))
+        spec["width"], spec["height"] = 1920, 1200
+        spec["calib"] = synth.scaled_calibration(1920, 1200, spec["proj_width"])
+        return spec, int(name[3:]), aux
+    if "tile" in name:                              # rank 0's tile of an 8-way row split, n frame-sets
+        cfg, n = name.split("tile")
+        spec, _, _ = shard.row_tile_spec(synth.make_spec(cfg), 8, 0)
+        return spec, int(n), aux
+    cfg, n = name.split("x")
+    return synth.make_spec(cfg), int(n), aux
+
+
+for wname in a.work.split(","):
+    spec, n_sets, aux = workload(wname)
+    H, W = spec["height"], spec["width"]
+    n_phase, n_gray = synth.n_planes(spec)
+    phase = torch.randint(0, 256, (n_sets, n_phase, H, W), dtype=torch.uint8, device="cuda") if n_phase else None
+    gray = torch.randint(0, 256, (n_sets, n_gray, H, W), dtype=torch.uint8, device="cuda") if n_gray else None
+    outs = {"z": torch.empty((n_sets, H, W), dtype=torch.float64, device="cuda")}
+    for p in aux:
+        outs[p] = (torch.empty((n_sets, spec["n_freq"] - 1, H, W), dtype=torch.int32, device="cuda") if p == "k"
+                   else torch.empty((n_sets, H, W), dtype=torch.float64, device="cuda"))
+    bytes_ = n_sets * H * W * (n_phase + n_gray + 8 + sum(4 * (spec["n_freq"] - 1) if p == "k" else 8 for p in aux))
+    torch.cuda.synchronize()
+    # every arm gets its own context; the arms run round-robin (a box's clock drifts: interleaving keeps the arms comparable)
+    arms = []
+    for rows in (int(r) for r in a.rows.split(",")):
+        ctx = api.Context(spec)
+        ctx.set_variant(2)
+        ctx.set_tuning(strip_rows=rows, **extra)
+        arms.append((rows, ctx, torch.cuda.ExternalStream(ctx.stream_handle()), [], []))
+
+    def launch(ctx):
+        ctx.decode_batch_ex(n_sets, phase, gray, **outs)
+    for _, ctx, _, _, _ in arms:
+        for _ in range(60):
+            launch(ctx)
+        ctx.synchronize()
+    per_round = max(10, a.launches // a.rounds)
+    for _ in range(a.rounds):
+        for rows, ctx, st, single, b2b in arms:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ctx.enable_timing(False)
+            e0.record(st)
+            for _ in range(per_round):
+                launch(ctx)
+            e1.record(st)
+            ctx.synchronize()
+            b2b.append(e0.elapsed_time(e1) * 1e3 / per_round)
+            ctx.enable_timing(True)
+            for _ in range(per_round):
+                launch(ctx)
+                single.append(ctx.last_decode_ms() * 1e3)
+    for rows, ctx, st, single, b2b in arms:
+        k, b = statistics.median(single), statistics.median(b2b)
+        print(json.dumps({"work": wname, "rows": rows, "kernel_us": round(k, 2), "kernel_us_min": round(min(single), 2), "back_to_back_us": round(b, 2),
+                          "bytes": bytes_, "frac_kernel": round(bytes_ / k / 8e6, 3), "frac_b2b": round(bytes_ / b / 8e6, 3)}), flush=True)
+        ctx.close()
