@@ -157,9 +157,10 @@ def parse_args(argv=None):
     ap.add_argument("--no-other-configs", action="store_true", help="N = 1: skip the short timings of the other configurations reported under other_configs")
     ap.add_argument("--no-gather", action="store_true",
                     help="N > 1: skip the gather timings (decode + RCCL gather of the depth maps to rank 0, reported as with_gather)")
-    ap.add_argument("--shard", choices=("framesets", "rows"), default="framesets",
-                    help="how ranks split the batch in the headline (decode-only) region: whole frame-sets (default), or a row tile of every "
-                         "frame-set (north_star's wording); the per-GPU bytes are the same.  with_gather always reports both")
+    ap.add_argument("--shard", choices=("framesets", "rows"), default=None,
+                    help="how ranks split the batch in the decode-only region (kernel_only, roofline): a row tile of every frame-set "
+                         "(north_star's wording; the default for N > 1) or whole frame-sets; the per-GPU bytes are the same.  "
+                         "The N > 1 headline is always the row-tile split with its gather; with_gather reports both splits")
     ap.add_argument("--gather-chunk", type=int, default=8, help="frame-sets per pipelined decode+gather chunk")
     ap.add_argument("--gather-timeout", type=float, default=240.0,
                     help="N > 1: seconds the whole with_gather phase may take before the line is printed without it (a stuck collective must not cost the decode-only result)")
@@ -251,11 +252,13 @@ def launch_ranks(args, argv):
     for ln in out0.splitlines():
         if ln.startswith("{") and '"metric"' in ln:
             line = ln
+    if line is not None:
+        print(line, flush=True)                                # also when a rank failed: the line says what was and was not measured
     if rc != 0 or line is None:
         log("bench: a rank failed (rc %s)%s" % (rc, "" if line else "; no result line from rank 0"))
-        sys.stderr.write(out0)
+        if line is None:
+            sys.stderr.write(out0)
         return rc or 1
-    print(line, flush=True)
     return 0
 
 
@@ -312,6 +315,8 @@ def run_rank(args):
         k, _, v = kv.partition("=")
         tune[k] = int(v)
 
+    if args.shard is None:
+        args.shard = "rows" if world > 1 else "framesets"
     full_spec = synth.make_spec(args.config)
     full_h = full_spec["height"]
     spec, n_sets = full_spec, args.sets_per_gpu
@@ -377,22 +382,38 @@ def run_rank(args):
     fence()
     t_max, kernel_ms_max = max_over_ranks([t_local, kernel_ms])
 
-    def make_result(gather, cpu_single=None, cpu_multi=None, parity=None, other=None):
+    def make_result(gather, cpu_single=None, cpu_multi=None, parity=None, other=None, headline=None):
+        """N = 1: `value` is the decode (there is nothing to gather).  N > 1: `value` is north_star's split END TO END -- every
+        rank decodes its row tile of all world x sets_per_gpu frame-sets and the tiles are gathered into [set][H][W] on rank 0
+        over RCCL -- args.steps steps, MAX over ranks; the decode alone sits beside it under `kernel_only`.  `headline` is
+        (seconds for args.steps steps) or None when the gathered number could not be measured: then `value` is null, never a
+        decode-only rate under the same key."""
         achieved = bytes_per_launch / (kernel_ms_max * 1e-3) / 1e9
         traffic, traffic_source = traffic_entry(args.config, n_sets)
+        kernel_only = {"value": world * args.sets_per_gpu * args.steps / t_max, "unit": "frames/s", "ms_per_step": t_max / args.steps * 1e3,
+                       "what": "decode only, no collective: %d frame-sets per GPU per step" % args.sets_per_gpu}
+        gathered = world > 1 and not args.no_gather
+        if gathered:
+            value = None if headline is None else world * args.sets_per_gpu * args.steps / headline
+            ms_per_step = None if headline is None else headline / args.steps * 1e3
+            workload_tail = ", row-tiled over %d GPUs (%d rows of %d each), RCCL gather of the depth tiles to rank 0 included" % (world, full_h // world, full_h)
+        else:
+            value, ms_per_step, workload_tail = kernel_only["value"], kernel_only["ms_per_step"], ""
         return {
-            "metric": "depth_frames_per_sec", "value": world * args.sets_per_gpu * args.steps / t_max, "unit": "frames/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": t_max / args.steps * 1e3,
+            "metric": "depth_frames_per_sec", "value": value, "unit": "frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32+f64", "data": "synthetic",
-            "config": {"workload": "%s: %dx%d, %d-frequency x %d-step temporal unwrap%s + triangulation, %d frame-sets per GPU per step"
-                                   % (args.config, W, full_h, spec["n_freq"], spec["n_steps"], " + %d-bit Gray mask" % spec["gray_bits"] if n_gray else "", args.sets_per_gpu),
-                       "periods": spec["periods"], "sharding": ("by frame-set" if args.shard == "framesets" or world == 1 else "by row tile (%d rows of %d per GPU, %d frame-sets)" % (H, full_h, n_sets)) + ", no data-path collective",
+            "config": {"workload": "%s: %dx%d, %d-frequency x %d-step temporal unwrap%s + triangulation, %d frame-sets per GPU per step%s"
+                                   % (args.config, W, full_h, spec["n_freq"], spec["n_steps"], " + %d-bit Gray mask" % spec["gray_bits"] if n_gray else "", args.sets_per_gpu, workload_tail),
+                       "periods": spec["periods"],
+                       "sharding": ("by row tile, one grouped ncclSend/ncclRecv gather per step" if gathered else
+                                    ("by frame-set" if args.shard == "framesets" or world == 1 else "by row tile (%d rows of %d per GPU, %d frame-sets)" % (H, full_h, n_sets)) + ", no data-path collective"),
                        "kernel_variant": args.variant, "settle_launches": settle, "tuning": tune or None},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": kernel_name(spec, args.variant), "launch_ms": kernel_ms_max,
                          "algorithmic_bytes_per_launch": bytes_per_launch},
-            "achieved_hbm_gbps_per_gpu": achieved,
+            "achieved_hbm_gbps_per_gpu": achieved, "kernel_only": kernel_only,
             "rccl_world_size": (dist.get_world_size() if world > 1 else 1), "collective_backend": (backend if world > 1 else None),
             "cpu_baseline": cpu_single, "cpu_baseline_all_cores": cpu_multi,
             "parity_vs_oracle": parity, "other_configs": other, "with_gather": gather,
@@ -401,18 +422,25 @@ def run_rank(args):
     # ------------------------------------------------------------------ N > 1: decode + gather, both ways of cutting the batch
     gather = None
     watchdog = None
+    headline = None                 # seconds for args.steps steps of decode + gather by rows (MAX over ranks)
+    gather_ok = True
     if world > 1 and not args.no_gather:
         import threading
         gather = {}
+        progress = {"split": None, "phase": "setup", "step": None}
 
         def gather_stuck():
-            # the collective phase hangs (a rank died, a fabric problem): the decode-only measurement above is complete and is
-            # reported; this process leaves without waiting for the device
+            # the collective phase hangs (a rank died, a fabric problem).  Every rank says where it stands; rank 0 prints the line
+            # with `value` null (the decode-only measurement above is complete and stays under kernel_only); the process leaves
+            # with exit code 4 without waiting for the device -- a hung collective must not read as a success
+            log("[bench] rank %d: with_gather did not finish within %.0f s -- stuck in split=%s phase=%s step=%s"
+                % (rank, args.gather_timeout, progress["split"], progress["phase"], progress["step"]))
             if rank == 0:
                 g = dict(gather)
-                g["error"] = "the with_gather phase did not finish within %.0f s and was abandoned" % args.gather_timeout
-                print(json.dumps(make_result(g)), flush=True)
-            os._exit(0)
+                g["error"] = ("the with_gather phase did not finish within %.0f s and was abandoned (rank 0 in split=%s phase=%s step=%s)"
+                              % (args.gather_timeout, progress["split"], progress["phase"], progress["step"]))
+                print(json.dumps(make_result(g, headline=None)), flush=True)
+            os._exit(4)
         watchdog = threading.Timer(args.gather_timeout, gather_stuck)
         watchdog.daemon = True
         watchdog.start()
@@ -430,8 +458,11 @@ def run_rank(args):
             comm = None
             gather["error"] = "communicator: %s: %s" % (type(e).__name__, e)
         total = world * args.sets_per_gpu
-        reps = max(3, min(20, args.steps // 15))
-        for split in ("framesets", "rows"):
+        # rows: north_star's split and the headline -- exactly args.steps timed steps after args.warmup; framesets: a short side measurement
+        side_reps = max(3, min(20, args.steps // 15))
+        for split in ("rows", "framesets"):
+            n_warm, n_steps = (max(2, min(args.warmup, 10)), args.steps) if split == "rows" else (2, side_reps)
+            progress.update(split=split, phase="setup", step=None)
             res = {}
             gctx = None
             try:
@@ -478,18 +509,24 @@ def run_rank(args):
 
                     def drain():
                         pass
-                for _ in range(2):
+                progress.update(phase="warmup")
+                for i in range(n_warm):
+                    progress.update(step=i)
                     decode_and_gather()
                 drain()
+                progress.update(phase="kernel_only", step=None)
                 fence()
-                tk, _ = timed(decode_only, reps, on=gstream)
+                tk, _ = timed(decode_only, n_steps, on=gstream)
                 fence()
+                progress.update(phase="timed")
                 t0g = time.perf_counter()
-                for _ in range(reps):
+                for i in range(n_steps):
+                    progress.update(step=i)
                     decode_and_gather()
                 drain()
                 torch.cuda.synchronize()
                 tg = time.perf_counter() - t0g
+                progress.update(phase="check", step=None)
                 fence()
                 tk_max, tg_max = max_over_ranks([tk, tg])
                 # the gathered array against what every rank decoded: wrapping int64 sums of the bit patterns, per rank
@@ -506,13 +543,17 @@ def run_rank(args):
                         if ok and n and rows:
                             part = got_full[s0:s0 + n, r0:r0 + rows].contiguous().view(torch.int64).sum()
                             ok = ok and int(part) == int(sums[r])
-                res = {"kernel_only": {"value": total * reps / tk_max, "unit": "frames/s", "ms_per_step": tk_max / reps * 1e3},
-                       "end_to_end": {"value": total * reps / tg_max, "unit": "frames/s", "ms_per_step": tg_max / reps * 1e3},
-                       "steps": reps, "bytes_into_root_per_step": int(((total - gn) * full_h if split == "framesets" else total * (full_h - grows)) * W * 8),
+                res = {"kernel_only": {"value": total * n_steps / tk_max, "unit": "frames/s", "ms_per_step": tk_max / n_steps * 1e3},
+                       "end_to_end": {"value": total * n_steps / tg_max, "unit": "frames/s", "ms_per_step": tg_max / n_steps * 1e3},
+                       "steps": n_steps, "warmup": n_warm,
+                       "bytes_into_root_per_step": int(((total - gn) * full_h if split == "framesets" else total * (full_h - grows)) * W * 8),
                        "gathered_shape": [total, full_h, W], "messages_at_root_per_step": (world - 1) * (1 if split == "framesets" else total),
                        "gathered_equals_local_decodes": ok}
-            except Exception as e:      # the decode-only line above must still be reported
+                if split == "rows" and ok is not False:
+                    headline = tg_max              # (a gather that delivers other bytes than the ranks decoded is a failure, not a number)
+            except Exception as e:      # the decode-only measurement above must still be reported
                 res = {"error": "%s: %s" % (type(e).__name__, e)}
+                gather_ok = False
             finally:
                 if gctx is not None:
                     if comm is not None:
@@ -521,6 +562,8 @@ def run_rank(args):
                         except Exception:
                             pass
                     gctx.close()
+            if res.get("gathered_equals_local_decodes") is False:
+                gather_ok = False
             gather[split] = res
         if comm is not None:
             try:
@@ -593,17 +636,22 @@ def run_rank(args):
                     del oph, ogr, outs
                 except Exception as e:
                     other[label] = {"error": "%s: %s" % (type(e).__name__, e)}
-        result = make_result(gather, cpu_single, cpu_multi, parity, other)
+        result = make_result(gather, cpu_single, cpu_multi, parity, other, headline=headline)
         print(json.dumps(result), flush=True)
     ctx.close()
     if world > 1:
         import threading
-        bye = threading.Timer(60.0, lambda: os._exit(0))       # the result is out: a peer that never reaches the barrier must not hang the job
+        # the result is out: a peer that never reaches the barrier must not hang the job -- but leaving this way is not a success
+        bye = threading.Timer(60.0, lambda: (log("[bench] rank %d: a peer never reached the closing barrier" % rank), os._exit(5)))
         bye.daemon = True
         bye.start()
         dist.barrier()
         dist.destroy_process_group()
         bye.cancel()
+    if world > 1 and not args.no_gather and not (gather_ok and headline is not None):
+        # the line is out with value null: the gather failed or delivered other bytes than the ranks decoded
+        log("[bench] rank %d: a gathered measurement failed or delivered other bytes than the ranks decoded (see with_gather in the line)" % rank)
+        sys.exit(6)
 
 
 def selftest_rank(args):
@@ -621,15 +669,25 @@ def selftest_rank(args):
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     total, H, W = 2 * world, 13, 8
     want = torch.arange(total * H * W, dtype=torch.float64).reshape(total, H, W)
-    ok = {}
-    for name, table in (("framesets", shard.shards_by_frameset(total, world, H)), ("rows", shard.shards_by_rows(total, world, H))):
+    res = {}
+    for name, table, n_steps in (("rows", shard.shards_by_rows(total, world, H), args.steps), ("framesets", shard.shards_by_frameset(total, world, H), 2)):
         s0, n, r0, rows = table[rank]
-        full = shard.gather_shards(want[s0:s0 + n, r0:r0 + rows].contiguous(), table, H, W, dst=0)
-        ok[name] = bool(rank != 0 or torch.equal(full, want))
+        local = want[s0:s0 + n, r0:r0 + rows].contiguous()
+        dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(n_steps):
+            full = shard.gather_shards(local, table, H, W, dst=0)
+        dist.barrier()
+        tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        res[name] = {"end_to_end": {"value": total * n_steps / float(tt[0]), "unit": "frames/s", "ms_per_step": float(tt[0]) / n_steps * 1e3},
+                     "steps": n_steps, "gathered_equals_local_decodes": bool(rank != 0 or torch.equal(full, want))}
     dist.barrier()
     if rank == 0:
-        print(json.dumps({"metric": "launcher_selftest", "value": float(t[0]), "unit": "max rank", "n_gpus": world,
-                          "rccl_world_size": dist.get_world_size(), "collective_backend": "gloo", "with_gather": ok}), flush=True)
+        # the key layout of the real N > 1 line: `value` IS the row-tile split end to end, exactly --steps steps
+        print(json.dumps({"metric": "launcher_selftest", "value": res["rows"]["end_to_end"]["value"], "unit": "frames/s", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": res["rows"]["end_to_end"]["ms_per_step"], "max_rank": float(t[0]),
+                          "rccl_world_size": dist.get_world_size(), "collective_backend": "gloo", "kernel_only": None, "with_gather": res}), flush=True)
     dist.destroy_process_group()
 
 

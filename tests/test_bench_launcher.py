@@ -22,8 +22,12 @@ def test_parent_starts_two_ranks_and_relays_the_line():
     assert len(lines) == 1, r.stdout                                    # exactly one line on stdout
     d = json.loads(lines[0])
     assert d["metric"] == "launcher_selftest" and d["n_gpus"] == 2 and d["rccl_world_size"] == 2
-    assert d["value"] == 1.0                                            # MAX over ranks of the rank number
-    assert d["with_gather"] == {"framesets": True, "rows": True}
+    assert d["max_rank"] == 1.0                                         # MAX over ranks of the rank number
+    # the key layout of the N > 1 line: the headline IS the row-tile split end to end (gather included), --steps steps of it
+    rows = d["with_gather"]["rows"]
+    assert d["value"] == rows["end_to_end"]["value"] > 0 and rows["steps"] == d["steps"] == 3
+    assert d["ms_per_step"] == rows["end_to_end"]["ms_per_step"] and "kernel_only" in d
+    assert all(d["with_gather"][k]["gathered_equals_local_decodes"] is True for k in ("rows", "framesets"))
 
 
 def test_failing_rank_gives_nonzero_exit():
