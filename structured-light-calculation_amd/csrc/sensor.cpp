@@ -1,6 +1,7 @@
 // sensor.cpp -- see sensor.hpp.  Host-only file I/O; nothing here touches the GPU.
 #include "sensor.hpp"
 
+#include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -31,12 +32,13 @@ bool ReadBmpGray(const std::string &path, std::vector<uint8_t> &pixels, int &row
     int32_t h = (int32_t)rd32(&buf[22]);
     const uint16_t bpp = rd16(&buf[28]);
     const uint32_t comp = rd32(&buf[30]);
-    if (w <= 0 || h == 0 || comp != 0) return false;
+    if (w <= 0 || h == 0 || h == INT32_MIN || comp != 0) return false;   // (-INT32_MIN does not exist)
     const bool top_down = h < 0;
     if (top_down) h = -h;
     if (bpp != 8 && bpp != 24 && bpp != 32) return false;
     const size_t row_bytes = (((size_t)w * bpp + 31) / 32) * 4;
-    if ((size_t)data_off + row_bytes * (size_t)h > buf.size()) return false;
+    // every row must lie inside the file; by division, so that a forged height cannot wrap the product
+    if ((size_t)data_off > buf.size() || (size_t)h > (buf.size() - (size_t)data_off) / row_bytes) return false;
     uint8_t pal[256];
     if (bpp == 8) {
         uint32_t n_col = rd32(&buf[46]);

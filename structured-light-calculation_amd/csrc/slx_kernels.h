@@ -120,6 +120,18 @@ struct SlxTuning {
 // Rows per work item the strip kernel's launcher picks (host-side model, exported for the CPU tests).
 extern "C" unsigned slx_strip_rows_model(unsigned height, unsigned interleave, unsigned chunks_per_group, unsigned n_sets, unsigned slots_per_cu, unsigned preferred);
 
+// A planned decode launch (slx_plan.cpp, host arithmetic only): the parameter block with the work-item geometry filled in,
+// which kernel family, the grid.  Returns 0, or non-zero when no plan exists (variant 2 on ineligible operands, ...).
+struct SlxLaunchPlan {
+    SlxKParams kp;
+    int mode, aux;
+    int strip;               // 1: slx_strip_kernel, 0: slx_fused_kernel
+    int gray_ring_bits;      // strip kernel: 6 when the Gray planes ride the DMA ring, else 0
+    unsigned grid_x, grid_y, block;
+    size_t lds_bytes;
+};
+int slx_plan_launch(const SlxKParams &kp, int mode, bool aux, int n_sets, int variant, const SlxTuning *tune, SlxLaunchPlan *plan);
+
 // Launches the fused kernel for `n_sets` frame-sets on `stream` (hipStream_t).
 // Returns 0, or a hipError_t value.  `variant` selects a kernel variant, `tune` (may be null) the item geometry.
 int slx_launch_fused(const SlxKParams &kp, int mode, bool aux, int n_sets, int variant, void *stream, const SlxTuning *tune = nullptr);

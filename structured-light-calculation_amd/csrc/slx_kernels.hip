@@ -1358,12 +1358,6 @@ kernel_fn pick_strip(int F, bool aux)
 
 }  // namespace
 
-int slx_num_variants(void) { return 4; }
-
-int slx_cloud_entries(int width, int height) { return width * ((height + kCloudTile - 1) / kCloudTile); }
-
-int slx_cloud_tiles(int width, int height) { return ((width + kCloudTile - 1) / kCloudTile) * ((height + kCloudTile - 1) / kCloudTile); }
-
 int slx_launch_cloud_count(const SlxKParams &kp, const double *z, unsigned *counts, unsigned *tiles, void *stream)
 {
     const int RB = (kp.height + kCloudTile - 1) / kCloudTile;
@@ -1385,237 +1379,24 @@ int slx_launch_cloud_write(const SlxKParams &kp, const double *z, const unsigned
     return (int)hipGetLastError();
 }
 
-bool slx_fast_arith_ok(const SlxKParams &kp)
-{
-    for (int f = 0; f < kp.n_freq; f++)
-        if (kp.period[f] > (1 << 14)) return false;
-    // the depth quotient's operands must stay far inside the double range (tri_depth<LEAN>)
-    const double big = 0x1p90;
-    for (double v : {kp.cA, kp.cB, kp.K1, kp.K2, kp.P00, kp.P01, kp.P20, kp.P21, kp.fu, kp.fv, kp.cx, kp.cy})
-        if (!(__builtin_fabs(v) < big)) return false;
-    return true;
-}
-
-bool slx_strip_eligible(const SlxKParams &kp, int mode, bool aux)
-{
-    if (!kp.aligned) return false;
-    if (aux && (kp.pix || kp.gray_out)) return false;                // the per-frequency pix planes and the Gray plane come from the generic kernel only
-    {
-        // second-pass divisors (x = z uc / fu, y = z vc / fv) must sit well inside the double range for the unscaled division
-        const double lo = 0x1p-90;
-        if (aux && !(__builtin_fabs(kp.fu) > lo && __builtin_fabs(kp.fv) > lo)) return false;
-    }
-    if (kp.n_steps != 4) {                                           // x1 fast path: 8 steps, Gray-free, the expected weight table
-        if (!(kp.n_steps == 8 && mode == SLX_MODE_MULTIFREQ)) return false;
-        const float r = kp.wy[1];
-        const float ey[8] = {1.f, r, 0.f, -r, -1.f, -r, 0.f, r}, ex[8] = {0.f, r, 1.f, r, 0.f, -r, -1.f, -r};
-        for (int k = 0; k < 8; k++)
-            if (kp.wy[k] != ey[k] || kp.wx[k] != ex[k]) return false;
-        if (!(r > 0.70f && r < 0.71f) || kp.wscale != 0.25f) return false;
-    }
-    if (mode != SLX_MODE_MULTIFREQ && mode != SLX_MODE_GRAY_PHASE && mode != SLX_MODE_MULTIFREQ_GRAYMASK) return false;
-    if (kp.quads_per_row == 0 || kp.quads_per_row > 1024) return false;
-    if (!slx_fast_arith_ok(kp)) return false;
-    if ((unsigned long long)kp.row_stride * (unsigned)kp.height >= (1ull << 31)) return false;   // 32-bit plane offsets
-    {
-        // the phase planes must be equally spaced, ascending, the last within 2 GiB of the first (32-bit buffer offsets):
-        // the layout of a batch and of the context's staging slab; anything else takes the generic kernel
-        const int np = kp.n_freq * kp.n_steps;
-        const uintptr_t a0 = reinterpret_cast<uintptr_t>(kp.phase[0]);
-        const uintptr_t step = np > 1 ? reinterpret_cast<uintptr_t>(kp.phase[1]) - a0 : 0;
-        if (np > 1 && reinterpret_cast<uintptr_t>(kp.phase[1]) < a0) return false;
-        for (int k = 0; k < np; k++)
-            if (reinterpret_cast<uintptr_t>(kp.phase[k]) != a0 + (uintptr_t)k * step) return false;
-        if ((unsigned long long)step * (unsigned)(np > 1 ? np - 1 : 0) >= (1ull << 31)) return false;
-    }
-    if ((unsigned long long)kp.width * ((unsigned)kp.height + 2048ull) >= (1ull << 29)) return false;   // 32-bit output byte offsets, rows past the tile included
-    return true;
-}
-
-static int launch_generic(const SlxKParams &kp, int mode, bool aux, int n_sets, void *stream)
-{
-    kernel_fn fn = pick(mode, kp.n_freq, kp.n_steps == 4, aux);
-    if (!fn) return (int)hipErrorInvalidValue;
-    const unsigned block = 256;
-    unsigned long long threads;
-    if (mode == SLX_MODE_MULTIFREQ_GRAYMASK) {
-        const unsigned long long waves = ((unsigned long long)kp.n_quads + 61ull) / 62ull;
-        threads = waves * 64ull;
-    } else {
-        threads = kp.n_quads;
-    }
-    const unsigned grid_x = (unsigned)((threads + block - 1) / block);
-    if (grid_x == 0 || n_sets <= 0) return (int)hipErrorInvalidValue;
-    // operand shapes were validated by the caller (slx_api.cpp: check_launch_shapes)
-    hipLaunchKernelGGL(fn, dim3(grid_x, (unsigned)n_sets, 1), dim3(block, 1, 1), 0, (hipStream_t)stream, kp);
-    return (int)hipGetLastError();
-}
-
-// Rows per work item of the strip kernel, from the measured sweeps of tools/single_set.py (profiles/r03_rows_sweep.json):
-//  * a launch that fills the chip several times over (>= 15 360 items = 3.75 per resident wave slot) takes the kernel's
-//    preferred item: 16 rows for the Gray-free 4-step kernels (VALU-bound; 16 rows amortise an item's start-up best and
-//    the tiers below cut the drain), 3 rows where the Gray planes ride the ring (REF 166 vs 176 us at 8 rows and 220 at 16,
-//    C3 218 vs 226 / 238: those kernels wait for their DMA, and short items keep the waves of a SIMD out of step), 10 rows
-//    for 8 steps (C5: 368 vs 407 us at 16);
-//  * a launch of the VALU-bound kernels too small for that gets ONE round of items when items of <= 10 rows can cover it -- the smallest item count
-//    that fits the resident wave slots, so every slot works from the first cycle to the last and nothing is left for a
-//    thinly filled second round: one 1920x1200 frame-set (9 000 wave-rows for 4 096 slots; the call the reference makes,
-//    R/CCalculation.cpp:171-206) runs as 3 000 items of 3 rows in 13.2 us, against 14.7 us as 9 000 items of one row;
-//  * in between, the largest item that still gives 15 360 items.
-unsigned slx_strip_rows_model(unsigned height, unsigned interleave, unsigned chunks_per_group, unsigned n_sets, unsigned slots_per_cu, unsigned preferred)
-{
-    const unsigned long long slots = 256ull * std::max(1u, slots_per_cu), many = 256ull * 20ull * 3ull;
-    auto items = [&](unsigned r) {
-        const unsigned long long rows_group = (unsigned long long)interleave * r;
-        return ((height + rows_group - 1) / rows_group) * chunks_per_group * (unsigned long long)n_sets;
-    };
-    const unsigned cand[] = {16, 12, 10, 8, 6, 5, 4, 3, 2, 1};
-    if (preferred < 1 || preferred > 16) preferred = 16;
-    if (items(preferred) >= many) return preferred;
-    if (preferred <= 3) {
-        // the DMA-bound Gray kernels like short items whatever the launch: 3 rows while that gives 1.5 items per slot
-        // (4 frame-sets of the reference's size: 27.1 us, against 29.6 us as one round of 6-row items), else 2, else 1
-        // (one frame-set at 1280x1024: 2 560 items of 2 rows; C3's single frame-set 20.6 us at 2 rows, 21.7 at 3)
-        if (items(3) * 2 >= slots * 3) return 3;
-        return items(2) * 2 >= slots ? 2 : 1;
-    }
-    unsigned one_round = 0;                                          // smallest item that covers the launch in one round
-    for (unsigned r : cand)
-        if (items(r) <= slots) one_round = r;
-    if (one_round >= 1 && one_round <= 10) return one_round;
-    for (unsigned r : cand)
-        if (r <= preferred && items(r) >= many) return r;
-    return 1;
-}
-
+// Launches a plan of slx_plan_launch (slx_plan.cpp: kernel choice, work items, grid -- host arithmetic only).
 int slx_launch_fused(const SlxKParams &kp_in, int mode, bool aux, int n_sets, int variant, void *stream, const SlxTuning *tune)
 {
-    const SlxTuning none{};
-    const SlxTuning &tn = tune ? *tune : none;
-    const bool can_strip = slx_strip_eligible(kp_in, mode, aux);
-    if (variant == SLX_VARIANT_GENERIC || variant == SLX_VARIANT_GENERIC_FAST || !can_strip) {
-        if (variant == SLX_VARIANT_STRIP) return (int)hipErrorInvalidValue;
-        SlxKParams kg = kp_in;
-        kg.fast_arith = (variant != SLX_VARIANT_GENERIC && mode >= SLX_MODE_GRAY_PHASE && slx_fast_arith_ok(kp_in)) ? 1 : 0;
-        if (variant == SLX_VARIANT_GENERIC_FAST && !kg.fast_arith) return (int)hipErrorInvalidValue;
-        return launch_generic(kg, mode, aux, n_sets, stream);
+    SlxLaunchPlan plan;
+    if (slx_plan_launch(kp_in, mode, aux, n_sets, variant, tune, &plan) != 0) return (int)hipErrorInvalidValue;
+    const SlxKParams &kp = plan.kp;
+    kernel_fn fn;
+    if (!plan.strip) {
+        fn = pick(mode, kp.n_freq, kp.n_steps == 4, aux);
+    } else {
+        const int gb = plan.gray_ring_bits;
+        fn = mode == SLX_MODE_MULTIFREQ ? (kp.n_steps == 8 ? pick_strip<SLX_MODE_MULTIFREQ, 0, 8>(kp.n_freq, aux) : pick_strip<SLX_MODE_MULTIFREQ, 0>(kp.n_freq, aux))
+             : mode == SLX_MODE_MULTIFREQ_GRAYMASK
+                 ? (gb ? pick_strip<SLX_MODE_MULTIFREQ_GRAYMASK, 6>(kp.n_freq, aux) : pick_strip<SLX_MODE_MULTIFREQ_GRAYMASK, 0>(kp.n_freq, aux))
+                 : (gb ? pick_strip<SLX_MODE_GRAY_PHASE, 6>(1, aux) : pick_strip<SLX_MODE_GRAY_PHASE, 0>(1, aux));
     }
-    SlxKParams kp = kp_in;
-    kp.plane_base = kp.phase[0];                                     // equally spaced, ascending (slx_strip_eligible)
-    kp.phase_first = 0;
-    kp.phase_step = kp.n_freq * kp.n_steps > 1 ? (unsigned)(kp.phase[1] - kp.phase[0]) : 0u;
-    kp.gray_first = kp.gray_step = 0;
-    kp.dma_imm = (kp.n_freq * kp.n_steps == 1 || kp.phase_step >= 256u) ? 1 : 0;
-    // geometry: `interleave` rows end to end fill whole waves; an item is 64 quads x rows_per_lane rows
-    const unsigned QR = kp.quads_per_row;
-    unsigned g = QR, h = 64;
-    while (h) { const unsigned r = g % h; g = h; h = r; }          // gcd(QR, 64)
-    kp.interleave = 64u / g;
-    kp.chunks_per_group = mode == SLX_MODE_MULTIFREQ_GRAYMASK ? (kp.interleave * QR + 61u) / 62u   // 62 quads + 2 halo lanes per wave
-                                                             : kp.interleave * QR / 64u;
-    kp.plain_order = tn.plain_order ? 1 : 0;
-    // Gray planes ride the DMA ring when there are 6 bits of them (the reference's and config 3's count) and every
-    // plane, in every frame-set of the launch, sits within 2 GiB above the lowest plane; otherwise the kernel reads
-    // them with ordinary loads
-    int gb = 0;
-    if (mode != SLX_MODE_MULTIFREQ && kp.gray_bits == 6 && !tn.gray_plain) {
-        gb = 6;
-        // equally spaced, ascending, like the phase planes
-        const long long gstep = (long long)(kp.gray[1] - kp.gray[0]);
-        for (int k = 0; k < 12; k++)
-            if (gstep < 0 || kp.gray[k] != kp.gray[0] + (long long)k * gstep) gb = 0;
-        const uint8_t *lo = kp.gray[0] < kp.phase[0] ? kp.gray[0] : kp.phase[0];
-        const long long delta = (long long)kp.gray_set_stride - (long long)kp.phase_set_stride;
-        const long long g_first = (long long)(kp.gray[0] - lo), g_last = g_first + 11 * gstep;
-        const long long p_last = (long long)(kp.phase[0] - lo) + (long long)(kp.n_freq * 4 - 1) * kp.phase_step;
-        for (long long rel : {g_first, g_last}) {
-            const long long hi = rel + delta * (long long)(n_sets - 1);
-            if (rel >= (1ll << 31) || hi < 0 || hi >= (1ll << 31)) gb = 0;
-        }
-        if (p_last >= (1ll << 31) || gstep >= (1ll << 31)) gb = 0;
-        if (gb) {
-            kp.plane_base = lo;
-            kp.phase_first = (unsigned)(kp.phase[0] - lo);
-            kp.gray_first = (unsigned)g_first;
-            kp.gray_step = (unsigned)gstep;
-            kp.gray_set_delta = delta;
-            if (gstep < 256) kp.dma_imm = 0;
-        }
-    }
-    // LDS per wave: 2 ring slots (max(4 n_freq, 2 gb) planes with 4 steps, 8 planes with 8 steps, 256 B each) + 2 KiB of depth staging
-    const unsigned ring_planes = kp.n_steps == 4 ? std::max((unsigned)kp.n_freq * 4u, 2u * (unsigned)gb) : 8u;
-    const unsigned lds_wave = 2u * ring_planes * 256u + 2048u + (aux ? 2048u : 0u);      // + the optional planes' staging area
-    // rows per item (slx_strip_rows_model): the kernel's preferred item for a launch that fills the chip many times over,
-    // one round of items for a small one
-    const unsigned slots_per_cu = std::min(16u, 160u * 1024u / lds_wave);
-    const unsigned preferred = kp.n_steps == 8 ? 10u : gb ? 3u : 16u;
-    unsigned rb = slx_strip_rows_model((unsigned)kp.height, kp.interleave, kp.chunks_per_group, (unsigned)n_sets, slots_per_cu, preferred);
-    // <= 32 rows: slx_strip_eligible bounds the 32-bit output offsets for interleave (<= 64) x 32 rows past the tile
-    if (tn.strip_rows >= 1 && tn.strip_rows <= 32) rb = (unsigned)tn.strip_rows;
-    // Tiers: the head of every frame-set in items of rb rows, then shorter items (a quarter of the previous tier's rows)
-    // for the last tail_pct % of the rows; with more than two tiers each takes 60 % of what is left, the last one all of
-    // it.  Short items run last and cut the end of the launch, where the chip drains for about one item's lifetime.
-    unsigned tail_pct = 20, tail_rb = rb / 4, tiers = 2;   // measured (tools/ab.py, C4 and C3): 2 tiers beat 1 by 2 %, 3 and 4 lose it again
-    if (tn.tail_pct != 0) tail_pct = tn.tail_pct < 0 ? 0u : (unsigned)tn.tail_pct;
-    if (tn.tail_rows > 0) tail_rb = (unsigned)tn.tail_rows;
-    if (tn.tiers >= 1 && tn.tiers <= SLX_MAX_TIERS) tiers = (unsigned)tn.tiers;
-    const unsigned rows_group = kp.interleave * rb;
-    const unsigned groups = ((unsigned)kp.height + rows_group - 1) / rows_group;
-    if (!(rb >= 8 && tail_rb >= 1 && tail_rb < rb && tail_pct > 0 && tail_pct < 100 && groups >= 4)) tiers = 1;   // (tiers below 8 rows: tried on REF and C3 at 3 rows, no gain)
-    // waves per workgroup: as many as keep the most waves resident in the CU's 160 KiB of LDS (16 at most: 4 per SIMD)
-    const unsigned lds_shared = 0u;                                     // nothing is shared between the waves of a workgroup
-    unsigned waves_per_wg = 4u;
-    {
-        unsigned best = 0;
-        for (unsigned w = 4; w >= 1; w--) {
-            const unsigned resident = std::min(16u, w * (160u * 1024u / (w * lds_wave + lds_shared)));
-            if (resident > best) { best = resident; waves_per_wg = w; }
-        }
-    }
-    if (tn.strip_waves >= 1 && tn.strip_waves <= 4) waves_per_wg = (unsigned)tn.strip_waves;
-    unsigned long long need_wgs = 0;
-    {
-        unsigned row0 = 0, t = 0, r = rb;
-        unsigned head_groups = tiers > 1 ? (unsigned)((unsigned long long)groups * (100u - tail_pct) / 100u) : groups;
-        if (head_groups < 1 || head_groups >= groups) { head_groups = groups; tiers = 1; }
-        unsigned long long first_wg = 0;
-        while (true) {
-            const unsigned group_rows = kp.interleave * r;
-            const unsigned left = (unsigned)kp.height - row0;
-            unsigned g_here;
-            if (t == 0) g_here = head_groups;
-            else if (t + 1 == tiers || r == 1) g_here = (left + group_rows - 1) / group_rows;        // the last tier takes what is left
-            else g_here = std::max(1u, (unsigned)((unsigned long long)left * 60u / 100u / group_rows));
-            if ((unsigned long long)g_here * group_rows >= left) g_here = (left + group_rows - 1) / group_rows;
-            kp.tier_rows[t] = r;
-            kp.tier_row0[t] = row0;
-            kp.tier_items_per_set[t] = g_here * kp.chunks_per_group;
-            const unsigned long long items = (unsigned long long)kp.tier_items_per_set[t] * (unsigned)n_sets;
-            const unsigned long long wgs = (items + waves_per_wg - 1) / waves_per_wg;
-            if (items >= (1ull << 32) || first_wg + wgs >= (1ull << 31)) return (int)hipErrorInvalidValue;
-            kp.tier_items[t] = (unsigned)items;
-            kp.tier_first_wg[t] = (unsigned)first_wg;
-            kp.tier_wgs[t] = (unsigned)wgs;
-            first_wg += wgs;
-            row0 += g_here * group_rows;
-            t++;
-            if (row0 >= (unsigned)kp.height || t == SLX_MAX_TIERS) break;
-            r = t == 1 ? tail_rb : std::max(1u, r / 4u);
-        }
-        kp.n_tiers = t;
-        need_wgs = first_wg;                                             // the waves past a tier's last item idle
-    }
-    const unsigned threads = waves_per_wg * 64u;
-    if (need_wgs == 0 || need_wgs >= (1ull << 31)) return (int)hipErrorInvalidValue;
-    kernel_fn fn = mode == SLX_MODE_MULTIFREQ ? (kp.n_steps == 8 ? pick_strip<SLX_MODE_MULTIFREQ, 0, 8>(kp.n_freq, aux) : pick_strip<SLX_MODE_MULTIFREQ, 0>(kp.n_freq, aux))
-                   : mode == SLX_MODE_MULTIFREQ_GRAYMASK
-                       ? (gb ? pick_strip<SLX_MODE_MULTIFREQ_GRAYMASK, 6>(kp.n_freq, aux) : pick_strip<SLX_MODE_MULTIFREQ_GRAYMASK, 0>(kp.n_freq, aux))
-                       : (gb ? pick_strip<SLX_MODE_GRAY_PHASE, 6>(1, aux) : pick_strip<SLX_MODE_GRAY_PHASE, 0>(1, aux));
     if (!fn) return (int)hipErrorInvalidValue;
-    size_t lds = (size_t)waves_per_wg * lds_wave + lds_shared;
-    if (tn.lds_pad_kib > 0 && tn.lds_pad_kib <= 128) lds += (size_t)tn.lds_pad_kib * 1024u;   // experiments: lower the occupancy
-    if (lds > 160u * 1024u) return (int)hipErrorInvalidValue;
-    // operand shapes were validated by the caller (slx_api.cpp: check_launch_shapes) and slx_strip_eligible
-    hipLaunchKernelGGL(fn, dim3((unsigned)need_wgs, 1, 1), dim3(threads, 1, 1), lds, (hipStream_t)stream, kp);
+    // operand shapes were validated by the caller (slx_api.cpp: check_launch_shapes), slx_strip_eligible and the plan
+    hipLaunchKernelGGL(fn, dim3(plan.grid_x, plan.grid_y, 1), dim3(plan.block, 1, 1), plan.lds_bytes, (hipStream_t)stream, kp);
     return (int)hipGetLastError();
 }

@@ -88,6 +88,9 @@ int main(int argc, char **argv)
     if (rank == 0) CHECK_HIP(hipMalloc((void **)&d_full, full_elems * sizeof(double)));
     else CHECK_HIP(hipMalloc((void **)&d_scratch, (local_elems ? local_elems : 1) * sizeof(double)));
     if (rank == 0) CHECK_HIP(hipMemset(d_full, 0xff, full_elems * sizeof(double)));
+    // the fill runs on the NULL stream, asynchronously; the decode and the gather run on non-blocking streams that do not order
+    // themselves behind it: wait, or the poison could land on top of the result
+    CHECK_HIP(hipDeviceSynchronize());
 
     // decode + gather, pipelined in chunks of 2 frame-sets (the last chunk may be ragged)
     CHECK_SLX(slx_decode_gather(comm, ctx, shards.data(), H, 2, d_in, 12 * tile_plane, nullptr, 0, (size_t)W, d_scratch, d_full, 0, nullptr),
@@ -101,6 +104,7 @@ int main(int argc, char **argv)
     CHECK_SLX(slx_decode_batch(ctx, mine.n_sets, d_in, 12 * tile_plane, nullptr, 0, (size_t)W, d_local, nullptr), slx_last_error(ctx));
     CHECK_SLX(slx_synchronize(ctx), slx_last_error(ctx));
     if (rank == 0) CHECK_HIP(hipMemset(d_full, 0xff, full_elems * sizeof(double)));
+    CHECK_HIP(hipDeviceSynchronize());                             // as above: the fill must have landed before the gather writes
     CHECK_SLX(slx_gather_depth(comm, shards.data(), H, W, d_local, 0, d_full, 0, nullptr), slx_comm_last_error(comm));
     CHECK_SLX(slx_comm_synchronize(comm), slx_comm_last_error(comm));
     if (rank == 0) {

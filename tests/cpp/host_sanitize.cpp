@@ -1,0 +1,308 @@
+// host_sanitize.cpp -- the host side of libslx under AddressSanitizer + UndefinedBehaviorSanitizer (SURVEY.md section 5:
+// "ASan/UBSan on the CPU restatement" -- here the product's own CPU-side code: file readers of untrusted input, the config
+// validation, the launch planner, the gather planner).  Built by g++ from the product's sources (tests/cpp/Makefile, target
+// host_sanitize); no GPU, no device code.  Exit code 0 = every check held and no sanitizer report.
+//   usage: host_sanitize <scratch directory>
+#include <climits>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <random>
+#include <string>
+#include <vector>
+
+#include "dynaframe.hpp"
+#include "sensor.hpp"
+#include "slx.h"
+#include "slx_kernels.h"
+
+static int g_fail = 0, g_strip_plans = 0, g_generic_plans = 0;
+#define CHECK(cond)                                                           \
+    do {                                                                      \
+        if (!(cond)) {                                                        \
+            std::fprintf(stderr, "CHECK failed %s:%d: %s\n", __FILE__, __LINE__, #cond); \
+            g_fail++;                                                         \
+        }                                                                     \
+    } while (0)
+
+static void put32(std::vector<unsigned char> &b, size_t at, uint32_t v) { for (int i = 0; i < 4; i++) b[at + i] = (unsigned char)(v >> (8 * i)); }
+static void put16(std::vector<unsigned char> &b, size_t at, uint16_t v) { b[at] = (unsigned char)v; b[at + 1] = (unsigned char)(v >> 8); }
+static void write_file(const std::string &p, const std::vector<unsigned char> &b) { std::ofstream f(p.c_str(), std::ios::binary); f.write((const char *)b.data(), (std::streamsize)b.size()); }
+
+// a well-formed 8-bit paletted BMP of w x h, pixel (x, y) = (x + 3 y) & 255, bottom-up
+static std::vector<unsigned char> good_bmp(int w, int h, uint32_t n_col = 256)
+{
+    const size_t row = ((size_t)w + 3) & ~(size_t)3, pal = 4 * 256, off = 54 + pal;
+    std::vector<unsigned char> b(off + row * (size_t)h, 0);
+    b[0] = 'B'; b[1] = 'M';
+    put32(b, 2, (uint32_t)b.size()); put32(b, 10, (uint32_t)off); put32(b, 14, 40); put32(b, 18, (uint32_t)w); put32(b, 22, (uint32_t)h);
+    put16(b, 26, 1); put16(b, 28, 8); put32(b, 30, 0); put32(b, 46, n_col);
+    for (int i = 0; i < 256; i++) b[54 + 4 * i] = b[54 + 4 * i + 1] = b[54 + 4 * i + 2] = (unsigned char)i;
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) b[off + row * (size_t)(h - 1 - y) + (size_t)x] = (unsigned char)((x + 3 * y) & 255);
+    return b;
+}
+
+static void test_bmp(const std::string &dir)
+{
+    std::vector<uint8_t> px;
+    int r = 0, c = 0;
+    const std::string p = dir + "/t.bmp";
+    write_file(p, good_bmp(13, 7));
+    CHECK(slx::ReadBmpGray(p, px, r, c) && r == 7 && c == 13 && px.size() == 91 && px[0] == 0 && px[13 * 2 + 5] == ((5 + 6) & 255));
+    // forged headers: every one of them must be refused (or read inside the file), never touch memory outside the buffer
+    struct Forge { size_t at; uint32_t v; bool is16; } forges[] = {
+        {22, 0x80000000u, false},       // height = INT32_MIN: -h does not exist
+        {22, 0x7fffffffu, false},       // height far beyond the file
+        {22, 0xfffffff9u, false},       // top-down, 7 rows: legal
+        {18, 0x7fffffffu, false},       // width far beyond the file
+        {18, 0, false}, {22, 0, false}, // empty image
+        {10, 0xfffffff0u, false},       // data offset past the end of the file
+        {10, 0, false},                 // data offset inside the header: reads header bytes as pixels, still inside the file
+        {46, 100000u, false},           // more palette entries than a palette has
+        {46, 2, false},                 // short palette
+        {14, 12, false},                // OS/2 header
+        {14, 0xffffff00u, false},       // header size past the file: the palette offset must not wrap
+        {28, 1, true}, {28, 16, true}, {28, 24, true}, {28, 32, true},   // other bit depths (24 / 32: rows no longer fit)
+        {30, 1, false},                 // RLE
+    };
+    for (const Forge &f : forges) {
+        std::vector<unsigned char> b = good_bmp(13, 7);
+        if (f.is16) put16(b, f.at, (uint16_t)f.v); else put32(b, f.at, f.v);
+        write_file(p, b);
+        px.clear();
+        const bool ok = slx::ReadBmpGray(p, px, r, c);
+        if (ok) CHECK(r > 0 && c > 0 && px.size() == (size_t)r * (size_t)c);
+    }
+    // truncated at every length
+    const std::vector<unsigned char> whole = good_bmp(13, 7);
+    for (size_t n = 0; n < whole.size(); n += 7) {
+        write_file(p, std::vector<unsigned char>(whole.begin(), whole.begin() + (long)n));
+        CHECK(!slx::ReadBmpGray(p, px, r, c));
+    }
+    // random bytes behind a valid magic
+    std::mt19937 rng(7);
+    for (int k = 0; k < 300; k++) {
+        std::vector<unsigned char> b = good_bmp(9, 5);
+        for (int j = 0; j < 6; j++) b[2 + rng() % 52] = (unsigned char)rng();
+        write_file(p, b);
+        const bool ok = slx::ReadBmpGray(p, px, r, c);
+        if (ok) CHECK(px.size() == (size_t)r * (size_t)c);
+    }
+    // the C entry points: size query, short buffer
+    write_file(p, good_bmp(13, 7));
+    CHECK(slx_read_bmp_gray(p.c_str(), nullptr, 0, &r, &c) == SLX_OK && r == 7 && c == 13);
+    std::vector<uint8_t> small(10);
+    CHECK(slx_read_bmp_gray(p.c_str(), small.data(), small.size(), &r, &c) == SLX_ERR_INVALID_ARG);
+    CHECK(slx_read_bmp_gray((dir + "/missing.bmp").c_str(), nullptr, 0, &r, &c) == SLX_ERR_UNAVAILABLE);
+}
+
+static void test_pgm(const std::string &dir)
+{
+    std::vector<uint8_t> px;
+    int r = 0, c = 0;
+    const std::string p = dir + "/t.pgm";
+    auto put = [&](const std::string &text) { std::ofstream f(p.c_str(), std::ios::binary); f << text; };
+    put(std::string("P5\n# a comment\n3 2\n255\n") + std::string("\x01\x02\x03\x04\x05\x06", 6));
+    CHECK(slx::ReadPgmGray(p, px, r, c) && r == 2 && c == 3 && px[5] == 6);
+    for (const char *bad : {"P5\n3 2\n255\n\x01\x02", "P5\n99999999999 2\n255\n", "P5\n3 2\n65535\n", "P5\n-3 2\n255\n", "P5\n3", "P5 1073741824 1073741824 255 ", "P2\n1 1\n255\n0", "P5\n#",
+                            "P5\n1073741823 1073741823\n255\nx"}) {
+        put(bad);
+        CHECK(!slx::ReadPgmGray(p, px, r, c));
+    }
+}
+
+static void test_yaml_and_gray_table(const std::string &dir)
+{
+    const std::string p = dir + "/c.yml";
+    auto put = [&](const std::string &text) { std::ofstream f(p.c_str()); f << text; };
+    auto mat = [](const char *k, int n) {
+        std::string s = std::string(k) + ": !!opencv-matrix\n   rows: 3\n   cols: 3\n   dt: d\n   data: [ ";
+        for (int i = 0; i < n; i++) s += (i ? ", " : "") + std::to_string(i + 1) + ".5e+000";
+        return s + " ]\n";
+    };
+    slx::Calibration cal;
+    put("%YAML:1.0\n" + mat("CamMat", 9) + mat("ProMat", 9) + mat("R", 9) + mat("T", 3));
+    CHECK(slx::ReadCalibrationYaml(p, cal) && cal.CamMat[8] == 9.5 && cal.T[2] == 3.5);
+    put("%YAML:1.0\n" + mat("CamMat", 9) + mat("ProMat", 9) + mat("R", 10) + mat("T", 3));     // one value too many
+    CHECK(!slx::ReadCalibrationYaml(p, cal));
+    put("%YAML:1.0\n" + mat("CamMat", 9) + mat("ProMat", 9) + mat("R", 9));                       // a key missing
+    CHECK(!slx::ReadCalibrationYaml(p, cal));
+    put("CamMat: data: [ 1, 2");                                                                  // no closing bracket
+    CHECK(!slx::ReadCalibrationYaml(p, cal));
+    put("CamMat:");
+    CHECK(!slx::ReadCalibrationYaml(p, cal));
+    put("xCamMat: data: [1]\nT: data: [ nan, x, 1 ]\n");
+    CHECK(!slx::ReadCalibrationYaml(p, cal));
+    double a[9], b[9], c[9], t[3];
+    CHECK(slx_read_calibration_yaml((dir + "/none.yml").c_str(), a, b, c, t) == SLX_ERR_UNAVAILABLE);
+    // Gray table "<binary> <gray>" rows (R/Patterns/vGrayCode.txt): out-of-range and huge entries must not index outside the table
+    const std::string g = dir + "/g.txt";
+    { std::ofstream f(g.c_str()); f << "0 0\n1 1\n2 3\n3 2\n7 99\n-5 -1\n99999999999 3\n4 2147483647\n"; }
+    std::vector<int16_t> lut;
+    CHECK(slx::ReadGrayCodeFile(g, 8, lut) && lut.size() == 8 && lut[1] == 1);
+    CHECK(!slx::ReadGrayCodeFile(dir + "/none.txt", 8, lut));
+}
+
+static slx_config base_config(int w, int h, int mode, int F, int N, int G)
+{
+    static int16_t lut[1 << 16];
+    slx_config c;
+    std::memset(&c, 0, sizeof c);
+    c.width = w; c.height = h; c.mode = mode; c.n_freq = F; c.n_steps = N; c.gray_bits = G; c.gray_stripe = 20; c.gray_lut = lut;
+    for (int f = 0; f < SLX_MAX_FREQ; f++) c.period[f] = 1920 >> (3 * f);
+    c.fov_min = 100; c.fov_max = 1000; c.device = -1;
+    c.cam[0] = c.cam[4] = 1200; c.cam[8] = 1; c.pro[0] = c.pro[4] = 2000; c.pro[8] = 1; c.rot[0] = c.rot[4] = c.rot[8] = 1; c.trans[0] = -30;
+    return c;
+}
+
+static void test_validate_and_create()
+{
+    char msg[256];
+    slx_config c = base_config(64, 48, SLX_MODE_MULTIFREQ, 3, 4, 0);
+    CHECK(slx_validate_config(&c, msg, sizeof msg) == SLX_OK);
+    CHECK(slx_validate_config(nullptr, msg, sizeof msg) == SLX_ERR_INVALID_ARG);
+    for (int w : {0, -1, INT_MAX}) { slx_config d = c; d.width = w; d.height = INT_MAX; CHECK(slx_validate_config(&d, msg, 4) != SLX_OK); }
+    for (int m : {-1, 5, INT_MIN}) { slx_config d = c; d.mode = m; CHECK(slx_validate_config(&d, nullptr, 0) != SLX_OK); }
+    for (int n : {0, 2, SLX_MAX_STEPS + 1, INT_MAX}) { slx_config d = c; d.n_steps = n; CHECK(slx_validate_config(&d, msg, sizeof msg) != SLX_OK); }
+    for (int f : {0, SLX_MAX_FREQ + 1, INT_MIN}) { slx_config d = c; d.n_freq = f; CHECK(slx_validate_config(&d, msg, sizeof msg) != SLX_OK); }
+    { slx_config d = c; d.period[1] = 1 << 24; CHECK(slx_validate_config(&d, msg, sizeof msg) != SLX_OK); }
+    { slx_config d = base_config(64, 48, SLX_MODE_GRAY_PHASE, 1, 4, 17); CHECK(slx_validate_config(&d, msg, sizeof msg) != SLX_OK); }
+    { slx_config d = base_config(64, 48, SLX_MODE_GRAY_PHASE, 1, 4, 6); d.gray_lut = nullptr; CHECK(slx_validate_config(&d, msg, sizeof msg) != SLX_OK); }
+    { slx_config d = c; d.aux_outputs = 0xffffffffu; CHECK(slx_validate_config(&d, msg, sizeof msg) != SLX_OK); }
+    // no GPU here (or a GPU: then the context is created and destroyed): never a crash, never a CPU fallback
+    slx_ctx *ctx = nullptr;
+    const int rc = slx_create(&c, &ctx);
+    CHECK(rc == SLX_OK || rc == SLX_ERR_NO_DEVICE || rc == SLX_ERR_HIP);
+    if (rc == SLX_OK) slx_destroy(ctx);
+    else CHECK(ctx == nullptr && std::strlen(slx_last_error(nullptr)) > 0);
+    slx_destroy(nullptr);
+}
+
+// Every plan the launcher can make for a tile: the work items of all tiers must cover every row of a frame-set exactly once
+// (rows past the tile are allowed, they are range-checked away), and what the kernel forms in 32 bits must fit.
+static void check_plan(int w, int h, int n_sets, int mode, int F, int N, int G, const SlxTuning *tn, bool aux)
+{
+    SlxKParams kp;
+    std::memset(&kp, 0, sizeof kp);
+    kp.width = w; kp.height = h; kp.quads_per_row = (unsigned)((w + 3) / 4); kp.n_quads = kp.quads_per_row * (unsigned)h;
+    kp.n_freq = F; kp.n_steps = N; kp.gray_bits = G; kp.gray_stripe = 20; kp.aligned = (w % 4) == 0; kp.row_stride = (size_t)w;
+    for (int f = 0; f < F; f++) kp.period[f] = 1920 >> (3 * f);
+    kp.cx = w / 2.0; kp.cy = h / 2.0; kp.fu = kp.fv = 1200; kp.P00 = 1; kp.P01 = .1; kp.P20 = .01; kp.P21 = .02; kp.K1 = 5; kp.K2 = 7; kp.cA = 3; kp.cB = 2;
+    kp.out_set_stride = (size_t)w * (size_t)h;
+    const float r = 0.70710677f;
+    const float ey[8] = {1.f, r, 0.f, -r, -1.f, -r, 0.f, r}, ex[8] = {0.f, r, 1.f, r, 0.f, -r, -1.f, -r};
+    for (int k = 0; k < 8 && N == 8; k++) kp.wy[k] = ey[k], kp.wx[k] = ex[k];
+    kp.wscale = 2.0f / (float)N;
+    static uint8_t arena[1];                                         // addresses only: the planner never dereferences a plane
+    const size_t plane = (size_t)w * (size_t)h;
+    for (int i = 0; i < F * N; i++) kp.phase[i] = arena + (size_t)i * plane;
+    for (int i = 0; i < 2 * G; i++) kp.gray[i] = arena + (size_t)(F * N + i) * plane;
+    kp.phase_set_stride = kp.gray_set_stride = (size_t)(F * N + 2 * G) * plane;
+    for (int variant : {SLX_VARIANT_AUTO, SLX_VARIANT_GENERIC, SLX_VARIANT_STRIP}) {
+        SlxLaunchPlan plan;
+        const int rc = slx_plan_launch(kp, mode, aux, n_sets, variant, tn, &plan);
+        if (rc != 0) { CHECK(variant == SLX_VARIANT_STRIP || n_sets <= 0 || n_sets > 65535); continue; }
+        CHECK(plan.grid_x >= 1 && plan.grid_y >= 1 && plan.block >= 64 && plan.block <= 256 && plan.lds_bytes <= 160u * 1024u);
+        (plan.strip ? g_strip_plans : g_generic_plans)++;
+        if (!plan.strip) { CHECK((unsigned long long)plan.grid_x * plan.block >= kp.n_quads && (int)plan.grid_y == n_sets); continue; }
+        const SlxKParams &q = plan.kp;
+        CHECK(q.interleave >= 1 && q.interleave <= 64 && (q.interleave * q.quads_per_row) % (mode == SLX_MODE_MULTIFREQ_GRAYMASK ? 1u : 64u) == 0);
+        CHECK(q.n_tiers >= 1 && q.n_tiers <= SLX_MAX_TIERS && q.tier_row0[0] == 0 && q.tier_first_wg[0] == 0);
+        unsigned row = 0;
+        unsigned long long wgs = 0;
+        for (unsigned t = 0; t < q.n_tiers; t++) {
+            CHECK(q.tier_row0[t] == row && q.tier_rows[t] >= 1 && q.tier_rows[t] <= 32 && q.tier_first_wg[t] == wgs);
+            CHECK(q.tier_items_per_set[t] % q.chunks_per_group == 0 && q.tier_items[t] == q.tier_items_per_set[t] * (unsigned)n_sets);
+            const unsigned groups = q.tier_items_per_set[t] / q.chunks_per_group;
+            CHECK(groups >= 1);
+            row += groups * q.tier_rows[t] * q.interleave;
+            CHECK((unsigned long long)q.tier_wgs[t] * (plan.block / 64) >= q.tier_items[t]);
+            wgs += q.tier_wgs[t];
+        }
+        CHECK(row >= (unsigned)h);                                            // every row belongs to exactly one tier's items
+        CHECK(row < (unsigned)h + 64u * 32u + 64u);                           // and the overshoot stays inside what slx_strip_eligible bounded
+        CHECK(wgs == plan.grid_x);
+        CHECK((unsigned long long)(row + 1) * (unsigned)w * 8ull < (1ull << 32));   // 32-bit byte offsets of the depth stores, rows past the tile included
+    }
+}
+
+static void test_plans()
+{
+    std::mt19937 rng(11);
+    const int shapes[][2] = {{1920, 1200}, {1280, 1024}, {1280, 720}, {640, 480}, {4096, 3000}, {4, 1}, {8, 1200}, {500, 5}, {1920, 150}, {1920, 37}, {4096, 130}, {64, 20}, {252, 3000}, {4092, 17}};
+    for (const auto &s : shapes)
+        for (int n_sets : {1, 2, 5, 32, 256, 4000})
+            for (int cfg = 0; cfg < 4; cfg++) {
+                const int mode = cfg == 0 ? SLX_MODE_MULTIFREQ : cfg == 1 ? SLX_MODE_GRAY_PHASE : cfg == 2 ? SLX_MODE_MULTIFREQ_GRAYMASK : SLX_MODE_MULTIFREQ;
+                const int F = cfg == 1 ? 1 : cfg == 3 ? 4 : 3, N = cfg == 3 ? 8 : 4, G = (cfg == 1 || cfg == 2) ? 6 : 0;
+                if ((unsigned long long)s[0] * s[1] * (unsigned)(F * N + 2 * G) * (unsigned)n_sets >= (1ull << 40)) continue;
+                check_plan(s[0], s[1], n_sets, mode, F, N, G, nullptr, false);
+                check_plan(s[0], s[1], n_sets, mode, F, N, G, nullptr, true);
+                for (int k = 0; k < 6; k++) {
+                    SlxTuning tn;
+                    std::memset(&tn, 0, sizeof tn);
+                    tn.strip_rows = (int)(rng() % 33); tn.tail_pct = (int)(rng() % 101) - 1; tn.tail_rows = (int)(rng() % 33); tn.tiers = (int)(rng() % 5);
+                    tn.strip_waves = (int)(rng() % 5); tn.gray_plain = (int)(rng() % 2);
+                    check_plan(s[0], s[1], n_sets, mode, F, N, G, &tn, false);
+                }
+            }
+    // random small tiles
+    for (int k = 0; k < 3000; k++) check_plan(4 * (1 + (int)(rng() % 600)), 1 + (int)(rng() % 400), 1 + (int)(rng() % 40), SLX_MODE_MULTIFREQ, 3, 4, 0, nullptr, false);
+    // the rows-per-item rule itself: always 1..16, monotone sanity
+    for (unsigned hh : {1u, 7u, 150u, 720u, 1200u, 3000u, 100000u})
+        for (unsigned n : {1u, 3u, 32u, 65535u})
+            for (unsigned pref : {0u, 3u, 10u, 16u, 99u}) {
+                const unsigned rws = slx_strip_rows_model(hh, 2, 15, n, 16, pref);
+                CHECK(rws >= 1 && rws <= 16);
+            }
+}
+
+static void test_gather_plans()
+{
+    // every rank's message list against the others': per ordered pair the k-th send meets the k-th receive with the same length
+    for (int world = 1; world <= 8; world++)
+        for (int split = 0; split < 2; split++)
+            for (int root : {-1, 0, world - 1}) {
+                const int H = 37, W = 12, total = 2 * world + 1;
+                std::vector<slx_shard> sh((size_t)world);
+                for (int r = 0; r < world; r++) {
+                    if (split == 0) { const int lo = total * r / world, hi = total * (r + 1) / world; sh[(size_t)r] = {lo, hi - lo, 0, H}; }
+                    else { const int lo = H * r / world, hi = H * (r + 1) / world; sh[(size_t)r] = {0, total, lo, hi - lo}; }
+                }
+                std::vector<std::vector<slx_msg>> plans((size_t)world);
+                for (int r = 0; r < world; r++) {
+                    int n = 0;
+                    CHECK(slx_gather_plan(sh.data(), world, r, H, W, 0, total, 0, root, nullptr, 0, &n) == SLX_OK);
+                    plans[(size_t)r].resize((size_t)n);
+                    CHECK(slx_gather_plan(sh.data(), world, r, H, W, 0, total, 0, root, plans[(size_t)r].data(), n, &n) == SLX_OK);
+                }
+                for (int a = 0; a < world; a++)
+                    for (int b = 0; b < world; b++) {
+                        std::vector<unsigned long long> sends, recvs;
+                        for (const slx_msg &m : plans[(size_t)a]) if (m.send && m.peer == b) sends.push_back(m.count);
+                        for (const slx_msg &m : plans[(size_t)b]) if (!m.send && m.peer == a) recvs.push_back(m.count);
+                        CHECK(sends == recvs);
+                        for (const slx_msg &m : plans[(size_t)b]) if (!m.send) CHECK(m.offset + m.count <= (unsigned long long)total * H * W);
+                    }
+            }
+    int n = 0;
+    CHECK(slx_gather_plan(nullptr, 2, 0, 4, 4, 0, 1, 0, 0, nullptr, 0, &n) == SLX_ERR_INVALID_ARG);
+}
+
+int main(int argc, char **argv)
+{
+    const std::string dir = argc > 1 ? argv[1] : ".";
+    test_bmp(dir);
+    test_pgm(dir);
+    test_yaml_and_gray_table(dir);
+    test_validate_and_create();
+    test_plans();
+    test_gather_plans();
+    if (g_fail) { std::fprintf(stderr, "host_sanitize: %d check(s) failed\n", g_fail); return 1; }
+    CHECK(g_strip_plans > 5000 && g_generic_plans > 1000);
+    if (g_fail) return 1;
+    std::printf("host_sanitize ok: %d strip plans, %d generic plans checked\n", g_strip_plans, g_generic_plans);
+    return 0;
+}
