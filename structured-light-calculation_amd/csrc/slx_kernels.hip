@@ -127,10 +127,50 @@ __device__ __forceinline__ f32x2 v_max(f32x2 x, f32x2 y) { return {__builtin_fma
 __device__ __forceinline__ f32x2 v_max3(f32x2 x, f32x2 y, float z) { return {__builtin_fmaxf(__builtin_fmaxf(x.x, y.x), z), __builtin_fmaxf(__builtin_fmaxf(x.y, y.y), z)}; }
 __device__ __forceinline__ f32x2 v_min(f32x2 x, f32x2 y) { return {__builtin_fminf(x.x, y.x), __builtin_fminf(x.y, y.y)}; }
 __device__ __forceinline__ f32x2 v_rcp(f32x2 x) { return {__builtin_amdgcn_rcpf(x.x), __builtin_amdgcn_rcpf(x.y)}; }
-// per component: p > q ? x : y
-__device__ __forceinline__ f32x2 v_sel_gt(f32x2 p, f32x2 q, f32x2 x, f32x2 y) { return {p.x > q.x ? x.x : y.x, p.y > q.y ? x.y : y.y}; }
 __device__ __forceinline__ f32x2 v_mul_sat(f32x2 x, float s) { return pk_mul_sat(x, f32x2{s, s}); }
 __device__ __forceinline__ f32x2 v_neg_sat(f32x2 x) { return pk_neg_sat(x); }
+
+// ---- selects as arithmetic on 2-cycle instructions --------------------------------------------------------------
+// tools/valubench.hip: a wave's plain v_mul_f32 / v_add_f32 (also with |x| or clamp modifiers) issue in 2 cycles, v_fma_f32
+// in ~3.5, every packed f32 operation, v_cmp, v_cndmask, v_min / v_max in 4.  A compare + select of a pixel pair costs 16
+// cycles; the forms below cost 8 or less.
+// sat(x * s), one pixel: v_mul_f32 ... clamp (hipcc has no source form for the clamp bit)
+__device__ __forceinline__ float mul_sat1(float x, float s)
+{
+    float r;
+    asm("v_mul_f32_e64 %0, %1, %2 clamp" : "=v"(r) : "v"(x), "s"(s));
+    return r;
+}
+// 1.0 where |p| > |q|, else 0.0 (both 0 or separated by far more than 2^-60: every caller's operands are)
+__device__ __forceinline__ f32x2 v_gt01_abs(f32x2 p, f32x2 q)
+{
+    return {mul_sat1(__builtin_fabsf(p.x) - __builtin_fabsf(q.x), 0x1p60f), mul_sat1(__builtin_fabsf(p.y) - __builtin_fabsf(q.y), 0x1p60f)};
+}
+// fma(k, m, |z|) per pixel: v_fma_f32 with the |.| modifier on the addend (VOP3P has no abs; written as asm because hipcc's
+// vectoriser otherwise pairs the two fmas into a v_pk_fma_f32 behind two v_and_b32)
+__device__ __forceinline__ float fma_absz1(float k, float m, float z)
+{
+    float r;
+    asm("v_fma_f32 %0, %1, %2, |%3|" : "=v"(r) : "s"(k), "v"(m), "v"(z));
+    return r;
+}
+__device__ __forceinline__ f32x2 v_fma_absz(float k, f32x2 m, f32x2 z) { return {fma_absz1(k, m.x, z.x), fma_absz1(k, m.y, z.y)}; }
+// |x| * s per pixel: v_mul_f32 with the |.| modifier
+__device__ __forceinline__ float absmul1(float x, float s)
+{
+    float r;
+    asm("v_mul_f32_e64 %0, |%1|, %2" : "=v"(r) : "v"(x), "s"(s));
+    return r;
+}
+__device__ __forceinline__ f32x2 v_absmul(f32x2 x, float s) { return {absmul1(x.x, s), absmul1(x.y, s)}; }
+// sat(fma(x, y, z)), both halves in one packed instruction
+__device__ __forceinline__ f32x2 pk_fma_sat(f32x2 x, f32x2 y, f32x2 z)
+{
+    f32x2 r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 clamp" : "=v"(r) : "v"(x), "v"(y), "v"(z));
+    return r;
+}
+__device__ __forceinline__ f32x2 v_fma_sat(f32x2 x, float y, float z) { return pk_fma_sat(x, f32x2{y, y}, f32x2{z, z}); }
 
 #define SLX_LOCKSTEP1(NAME) __device__ __forceinline__ F32x2x2 NAME(F32x2x2 x) { return {NAME(x.a), NAME(x.b)}; }
 SLX_LOCKSTEP1(v_abs)
@@ -145,25 +185,32 @@ __device__ __forceinline__ F32x2x2 v_fma(F32x2x2 x, F32x2x2 y, float z) { return
 __device__ __forceinline__ F32x2x2 v_max(F32x2x2 x, F32x2x2 y) { return {v_max(x.a, y.a), v_max(x.b, y.b)}; }
 __device__ __forceinline__ F32x2x2 v_max3(F32x2x2 x, F32x2x2 y, float z) { return {v_max3(x.a, y.a, z), v_max3(x.b, y.b, z)}; }
 __device__ __forceinline__ F32x2x2 v_min(F32x2x2 x, F32x2x2 y) { return {v_min(x.a, y.a), v_min(x.b, y.b)}; }
-__device__ __forceinline__ F32x2x2 v_sel_gt(F32x2x2 p, F32x2x2 q, F32x2x2 x, F32x2x2 y) { return {v_sel_gt(p.a, q.a, x.a, y.a), v_sel_gt(p.b, q.b, x.b, y.b)}; }
 __device__ __forceinline__ F32x2x2 v_mul_sat(F32x2x2 x, float s) { return {v_mul_sat(x.a, s), v_mul_sat(x.b, s)}; }
+__device__ __forceinline__ F32x2x2 v_gt01_abs(F32x2x2 p, F32x2x2 q) { return {v_gt01_abs(p.a, q.a), v_gt01_abs(p.b, q.b)}; }
+__device__ __forceinline__ F32x2x2 v_fma_absz(float k, F32x2x2 m, F32x2x2 z) { return {v_fma_absz(k, m.a, z.a), v_fma_absz(k, m.b, z.b)}; }
+__device__ __forceinline__ F32x2x2 v_absmul(F32x2x2 x, float s) { return {v_absmul(x.a, s), v_absmul(x.b, s)}; }
+__device__ __forceinline__ F32x2x2 v_fma_sat(F32x2x2 x, float y, float z) { return {v_fma_sat(x.a, y, z), v_fma_sat(x.b, y, z)}; }
 
-// From the angle's first-octant value to pix: the 90 / 180 / 360 degree fix-ups, RN(a / 360) * T + 0.5 and the wrap.
-// The sign fix-ups and the final wrap are selects; compares and v_cndmask do not pack, but a saturating packed multiply
-// does (VOP3P clamp, which hipcc does not emit for f32 pairs): m = sat(-2^60 x) is 1 where x < 0 and 0 elsewhere (|x| is 0
-// or far above 2^-60), and fma(1 - 2m, a, 180 m) is a where m = 0 and RN(180 - a) where m = 1 -- the same single rounding as
-// the subtraction.  Likewise m = sat((pix - T) * 2^60) is 1 exactly where pix > T (the smallest positive difference is
-// an ulp) and fma(-T, m, pix) is RN(pix - T) or pix.  mc, ms: 1 where the cosine / sine term is negative.
+// From the angle's first-octant value a in [0, 45] to pix: the 90 / 180 / 360 degree fix-ups of cv::fastAtan2, RN(a / 360) * T + 0.5
+// and the wrap (R/CDecodePhase.cpp:67-75), without a compare or a select.
+//  * A fix-up "m ? K - a : a" (m in {0, 1}, 0 <= a <= K) is |fma(-K, m, a)|: RN(a - K) = -RN(K - a) (rounding is symmetric), and
+//    with m = 0 the fma returns a itself.  The |.| rides as a source modifier on the next fix-up's v_fma_f32 and, after the last
+//    one, on the multiply by T: everything between -- a * RN(1/360) and its residual correction -- is odd in a, so the sign is
+//    carried through and dropped at the end.  mgt: 1 where the sine term is the larger magnitude; mc, ms: 1 where the cosine /
+//    sine term is negative.
+//  * The wrap "pix > T ? pix - T : pix": m = sat((pix - T) 2^60) in ONE fma (pix 2^60 and T 2^60 are exact, and so is their
+//    difference wherever it is positive: pix - T is then a multiple of ulp(pix) in (0, 0.5]); fma(-T, m, pix) is RN(pix - T) or pix.
 template <typename V>
-__device__ __forceinline__ V pix_from_octant_angle(V a, V mc, V ms, float Tf)
+__device__ __forceinline__ V pix_from_octant_angle(V a, V mgt, V mc, V ms, float Tf)
 {
-    a = v_fma(v_fma(-2.f, mc, 1.f), a, mc * 180.f);
-    a = v_fma(v_fma(-2.f, ms, 1.f), a, ms * 360.f);
-    const V d0 = a * kInv360;
-    const V d = v_fma(v_fma(-360.f, d0, a), kInv360, d0);          // RN(a / 360), see the identities above
-    V pix = d * Tf;
+    const V u = v_fma(-90.f, mgt, a);                                // |u| = 90 - a or a
+    const V t = v_fma_absz(-180.f, mc, u);                           // |t| = 180 - |u| or |u|
+    const V r = v_fma_absz(-360.f, ms, t);                           // |r| = 360 - |t| or |t|: the angle, sign to be dropped
+    const V d0 = r * kInv360;
+    const V d = v_fma(v_fma(-360.f, d0, r), kInv360, d0);            // +-RN(angle / 360), see the identities above
+    V pix = v_absmul(d, Tf);
     pix = pix + 0.5f;
-    const V mw = v_mul_sat(pix - Tf, 0x1p60f);
+    const V mw = v_fma_sat(pix, 0x1p60f, -Tf * 0x1p60f);
     return v_fma(-Tf, mw, pix);
 }
 
@@ -183,11 +230,10 @@ __device__ __forceinline__ V wrapped_pix_from_diffs(V s2, V c2, float Tf)
     const V q0 = mn * r;
     const V c = v_fma(v_fma(-mx, q0, mn), r, q0);                   // RN(mn / mx)
     const V cc = c * c;
-    V a = (((kP7 * cc + kP5) * cc + kP3) * cc + kP1) * c;
-    a = v_sel_gt(as, ac, 90.f - a, a);
+    const V a = (((kP7 * cc + kP5) * cc + kP3) * cc + kP1) * c;
     const V mc = SCALED ? v_mul_sat(c2, -0x1p60f) : v_neg_sat(c2);
     const V ms = SCALED ? v_mul_sat(s2, -0x1p60f) : v_neg_sat(s2);
-    return pix_from_octant_angle(a, mc, ms, Tf);
+    return pix_from_octant_angle(a, v_gt01_abs(s2, c2), mc, ms, Tf);
 }
 
 // a2 literally (any float inputs): used by the x1 path, N != 4.
@@ -567,9 +613,8 @@ __device__ __forceinline__ V pix_tail_inrange(V y, V x, float Tf)
     q = v_fma(v_fma(-dd, q, mn), r, q);
     const V c = v_fma(v_fma(-dd, q, mn), r, q);
     const V cc = c * c;
-    V a = (((kP7 * cc + kP5) * cc + kP3) * cc + kP1) * c;
-    a = v_sel_gt(ay, ax, 90.f - a, a);
-    return pix_from_octant_angle(a, v_mul_sat(x, -0x1p60f), v_mul_sat(y, -0x1p60f), Tf);
+    const V a = (((kP7 * cc + kP5) * cc + kP3) * cc + kP1) * c;
+    return pix_from_octant_angle(a, v_gt01_abs(y, x), v_mul_sat(x, -0x1p60f), v_mul_sat(y, -0x1p60f), Tf);
 }
 
 // a3 for the four pixels of a quad at once (R/CDecodeGray.cpp:150-176: bit = pattern > inverse, ties -> 0), on the dwords
