@@ -291,6 +291,39 @@ def test_strip_kernel_geometries(api, oracle, synth, variant, shape):
         assert_same(got, ref, ("z",))
 
 
+@pytest.mark.parametrize("periods", [[640], [640, 80], [1024, 128, 16], [4096, 512, 64, 8]])
+@pytest.mark.parametrize("rows", [0, 1, 2, 3, 5, 16])
+def test_eight_step_ring_depths(api, oracle, synth, torch_cuda, periods, rows):
+    """The 8-step path moves one frequency per DMA chunk through the ring, with counted waits that depend on the chunk's place
+    in the row and on the item's length.  Every frequency count (1 to 4 chunks per row) x item lengths from one row (the whole
+    item is ring start-up and drain) to 16, depth and the optional planes, ragged tile."""
+    torch = torch_cuda
+    spec = small_spec(synth, "C5", 328, 43)
+    spec["periods"], spec["n_freq"] = list(periods), len(periods)
+    n_sets = 2
+    sets = [synth.random_planes(spec, seed=300 + 7 * s + len(periods))[0] for s in range(n_sets)]
+    want = ("z", "U", "x", "y") + (("k",) if len(periods) > 1 else ())
+    refs = [oracle.pipeline(spec, p, None, want=want) for p in sets]
+    ph = torch.from_numpy(np.stack(sets)).cuda()
+    H, W = spec["height"], spec["width"]
+    outs = {n: torch.full((n_sets, H, W), -7.0, dtype=torch.float64, device="cuda") for n in ("z", "U", "x", "y")}
+    if len(periods) > 1:
+        outs["k"] = torch.full((n_sets, len(periods) - 1, H, W), -7, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    with api.Context(spec) as ctx:
+        ctx.set_variant(2)
+        ctx.set_tuning(strip_rows=rows)
+        z_only = torch.full((n_sets, H, W), -7.0, dtype=torch.float64, device="cuda")
+        torch.cuda.synchronize()
+        ctx.decode_batch(n_sets, ph, None, z_only)
+        ctx.decode_batch_ex(n_sets, ph, None, **outs)
+        ctx.synchronize()
+    for s in range(n_sets):
+        assert np.array_equal(z_only[s].cpu().numpy(), refs[s]["z"], equal_nan=True), (s, "z only")
+        for n in want:
+            assert np.array_equal(outs[n][s].cpu().numpy(), refs[s][n], equal_nan=True), (s, n)
+
+
 @pytest.mark.parametrize("rows,tail_pct,tail_rows,tiers", [(8, 20, 2, 2), (16, 30, 4, 3), (8, 50, 1, 4), (12, 10, 3, 3), (16, 60, 4, 4), (32, 70, 8, 4)])
 @pytest.mark.parametrize("shape", [(67, 256), (130, 1000), (200, 64), (97, 1920)])
 def test_strip_kernel_long_and_short_items(api, oracle, synth, shape, rows, tail_pct, tail_rows, tiers):
