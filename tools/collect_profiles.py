@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Copies the judged summaries out of gpurun_out/prof_<tag>/ (scratch) into profiles/ (tracked).
 Usage: tools/collect_profiles.py <tag> <config> <sets_per_launch> <out_prefix>"""
-import collections, csv, glob, json, os, sys
+import collections, csv, glob, json, os, re, sys
 tag, config, sets, prefix = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
 out = "profiles"
 os.makedirs(out, exist_ok=True)
@@ -32,7 +32,7 @@ fetch = vals["FETCH_SIZE"]["mean_per_dispatch"] * 1024 * 2
 write = vals["WRITE_SIZE"]["mean_per_dispatch"] * 1024
 tp = os.path.join(out, "traffic.json")
 t = json.load(open(tp)) if os.path.exists(tp) else {}
-t[config] = {"hbm_bytes_per_launch": fetch + write, "read_bytes": fetch, "write_bytes": write, "sets_per_launch": sets, "kernel": kernel,
+t[config] = {"round": (re.match(r"r0*(\d+)", prefix) or [None, "?"])[1], "hbm_bytes_per_launch": fetch + write, "read_bytes": fetch, "write_bytes": write, "sets_per_launch": sets, "kernel": kernel,
              "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (%s_pmc_summary.json); FETCH_SIZE (KiB) x 1024 x 2 "
                        "(gfx950 tallies 128-B read requests at 64 B: MI355X_MICROARCH.md, HBM), WRITE_SIZE (KiB) x 1024" % prefix}
 json.dump(t, open(tp, "w"), indent=1)
