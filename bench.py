@@ -287,6 +287,7 @@ def run_rank(args):
     device = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("NCCL_DEBUG", "WARN")      # RCCL is silent by default: a failing collective should say why in the log
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
         else:
