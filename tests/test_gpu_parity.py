@@ -324,6 +324,33 @@ def test_eight_step_ring_depths(api, oracle, synth, torch_cuda, periods, rows):
             assert np.array_equal(outs[n][s].cpu().numpy(), refs[s][n], equal_nan=True), (s, n)
 
 
+@pytest.mark.parametrize("name", ["C1x4", "C2", "C3", "C5"])
+def test_every_item_length_and_launch_size(api, oracle, synth, torch_cuda, name):
+    """The launcher picks the rows per work item from the launch's size (1, 2, 3, 5, 6, 10, 12, 16 ... rows, with or without the
+    tiered tail): every length 1..16 forced on a ragged batch, and the automatic choice for batches of 1 to 9 frame-sets, in
+    every strip-kernel mode, against the oracle."""
+    torch = torch_cuda
+    spec = small_spec(synth, name, 516, 71)
+    n_max = 9
+    sets = [synth.random_planes(spec, seed=4000 + s) for s in range(n_max)]
+    refs = [oracle.pipeline(spec, p, g, want=("z",))["z"] for p, g in sets]
+    ph = torch.from_numpy(np.stack([p for p, _ in sets])).cuda()
+    gr = None if sets[0][1] is None else torch.from_numpy(np.stack([g for _, g in sets])).cuda()
+    H, W = spec["height"], spec["width"]
+    torch.cuda.synchronize()
+    with api.Context(spec) as ctx:
+        ctx.set_variant(2)
+        for rows, n in [(r, 3) for r in range(1, 17)] + [(0, n) for n in range(1, n_max + 1)]:
+            ctx.set_tuning(strip_rows=rows)
+            z = torch.full((n, H, W), -5.0, dtype=torch.float64, device="cuda")
+            torch.cuda.synchronize()
+            ctx.decode_batch(n, ph[:n], None if gr is None else gr[:n], z)
+            ctx.synchronize()
+            got = z.cpu().numpy()
+            for s in range(n):
+                assert np.array_equal(got[s], refs[s], equal_nan=True), (rows, n, s)
+
+
 @pytest.mark.parametrize("rows,tail_pct,tail_rows,tiers", [(8, 20, 2, 2), (16, 30, 4, 3), (8, 50, 1, 4), (12, 10, 3, 3), (16, 60, 4, 4), (32, 70, 8, 4)])
 @pytest.mark.parametrize("shape", [(67, 256), (130, 1000), (200, 64), (97, 1920)])
 def test_strip_kernel_long_and_short_items(api, oracle, synth, shape, rows, tail_pct, tail_rows, tiers):
