@@ -591,14 +591,14 @@ def run_rank(args):
         if world == 1 and not args.no_other_configs:
             # every other configuration the boundary serves, >= 50 launches each after a short settle, so that each has a
             # number taken by this run's clock, and parity of frame-set 0 against the oracle for each:
-            #   C3, C5, C2   the other single-GPU BASELINE configurations
+            #   C3, C5, C2   the other single-GPU BASELINE configurations (C2: 80 frame-sets = the headline launch's 1.47 GB)
             #   REF          the reference's own compiled-in case (x4: 1280x1024, 6-bit Gray + 4-step), 24 B/px
             #   C4+xyUk      slx_decode_batch_ex with x, y, U, k beside z -- what the reference computes for every frame
             #                (R/CCalculation.cpp:756-771); its OWN bytes, 20 + 24 + 8 = 52 B/px, never mixed into the 20 B/px figure
             #   C4x1, REFx1  ONE frame-set per launch: the call the reference makes (CCalculation::CalculateFirst)
             other = {}
             threads = min(len(os.sched_getaffinity(0)), 16)
-            for label, name, sets, aux in (("C3", "C3", 16, ()), ("C5", "C5", 4, ()), ("REF", "REF", 32, ()), ("C2", "C2", 32, ()),
+            for label, name, sets, aux in (("C3", "C3", 16, ()), ("C5", "C5", 4, ()), ("REF", "REF", 32, ()), ("C2", "C2", 80, ()),
                                            ("C4+xyUk", "C4", 16, ("x", "y", "U", "k")), ("C4x1", "C4", 1, ()), ("REFx1", "REF", 1, ())):
                 if label == args.config:
                     continue
