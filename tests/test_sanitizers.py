@@ -14,6 +14,7 @@ def _run(cmd, cwd=None, timeout=900):
     env = dict(os.environ)
     env["ASAN_OPTIONS"] = "abort_on_error=0:detect_leaks=1"
     env["UBSAN_OPTIONS"] = "print_stacktrace=1:halt_on_error=1"
+    env["LSAN_OPTIONS"] = "suppressions=" + os.path.join(ROOT, "tests", "cpp", "lsan.supp") + ":print_suppressions=0"
     return subprocess.run(cmd, cwd=cwd, capture_output=True, text=True, timeout=timeout, env=env)
 
 
