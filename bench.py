@@ -142,6 +142,63 @@ def traffic_entry(config, n_sets):
     return None, "not measured"
 
 
+def traffic_probe(args):
+    """HBM bytes per launch of the headline kernel, measured in THIS run: two child runs of this script (12 launches of the same
+    workload each) under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` -- separate passes, no trace domain mixed in, the
+    program directly after `--` -- started before this process touches the GPU.  FETCH_SIZE (KiB) x 1024 x 2 (gfx950 tallies
+    128-byte read requests at 64 bytes: MI355X_MICROARCH.md, HBM), WRITE_SIZE (KiB) x 1024; means over the kernel's dispatches.
+    Returns (bytes per launch, provenance) or (None, why not)."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    got = {}
+    work = tempfile.mkdtemp(prefix="slx_traffic_", dir="/tmp")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(work, counter)
+            env = dict(os.environ, TMPDIR="/tmp")
+            cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", out, "--", sys.executable, os.path.abspath(__file__),
+                   "--traffic-probe-child", "--config", args.config, "--sets-per-gpu", str(args.sets_per_gpu), "--variant", str(args.variant)]
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=240)
+            files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return None, "rocprofv3 --pmc %s failed (rc %s)" % (counter, r.returncode)
+            vals = [float(row["Counter_Value"]) for row in csv.DictReader(open(files[0]))
+                    if row["Counter_Name"] == counter and ("slx_strip_kernel" in row["Kernel_Name"] or "slx_fused_kernel" in row["Kernel_Name"])]
+            if not vals:
+                return None, "no dispatch of the decode kernel in the %s pass" % counter
+            got[counter] = (sum(vals) / len(vals), len(vals))
+    except Exception as e:
+        return None, "%s: %s" % (type(e).__name__, e)
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+    read_b, write_b = got["FETCH_SIZE"][0] * 1024.0 * 2.0, got["WRITE_SIZE"][0] * 1024.0
+    return read_b + write_b, ("measured in this run: rocprofv3 --pmc FETCH_SIZE (x 1024 x 2, gfx950 correction) = %.1f MB read and --pmc WRITE_SIZE (x 1024) = %.1f MB "
+                              "written per launch, separate passes, means over %d / %d dispatches of the kernel in two child runs of this command's workload"
+                              % (read_b / 1e6, write_b / 1e6, got["FETCH_SIZE"][1], got["WRITE_SIZE"][1]))
+
+
+def traffic_probe_child(args):
+    """What rocprofv3 wraps for traffic_probe: the headline workload's batch, a dozen launches, nothing else."""
+    import torch
+    synth = importlib.import_module(PKG + ".synth")
+    api = importlib.import_module(PKG + ".api")
+    spec = synth.make_spec(args.config)
+    device = torch.device("cuda", 0)
+    phase, gray = make_batch(torch, synth, spec, args.sets_per_gpu, device, seed=0x5EED + 4)
+    z = torch.empty((args.sets_per_gpu, spec["height"], spec["width"]), dtype=torch.float64, device=device)
+    torch.cuda.synchronize()
+    with api.Context(spec, device=0) as ctx:
+        ctx.set_variant(args.variant)
+        for _ in range(12):
+            ctx.decode_batch(args.sets_per_gpu, phase, gray, z)
+        ctx.synchronize()
+
+
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -155,6 +212,10 @@ def parse_args(argv=None):
     ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE", help="slx_set_tuning override (tools only), e.g. --tune strip_rows=8")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true", help="N = 1: skip the short timings of the other configurations reported under other_configs")
+    ap.add_argument("--no-traffic-probe", action="store_true",
+                    help="N = 1: do not measure roofline.traffic in this run (two short child runs of this script under `rocprofv3 --pmc`, "
+                         "before this process touches the GPU); the committed capture of profiles/traffic.json is replayed instead")
+    ap.add_argument("--traffic-probe-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--no-gather", action="store_true",
                     help="N > 1: skip the gather timings (decode + RCCL gather of the depth maps to rank 0, reported as with_gather)")
     ap.add_argument("--shard", choices=("framesets", "rows"), default=None,
@@ -270,6 +331,11 @@ def run_rank(args):
     args.gpus = world
     if not os.environ.get("SLX_BENCH_SELF_LAUNCHED"):
         ensure_built()                     # before any GPU call; under a launcher every rank passes through the lock
+    live_traffic = (None, None)
+    if world == 1 and not args.no_traffic_probe:
+        t0p = time.perf_counter()
+        live_traffic = traffic_probe(args)  # child processes; this process has not touched the GPU yet
+        log("[bench] traffic probe: %s (%.1f s)" % (live_traffic[1], time.perf_counter() - t0p))
 
     import numpy as np
     import torch
@@ -391,6 +457,10 @@ def run_rank(args):
         decode-only rate under the same key."""
         achieved = bytes_per_launch / (kernel_ms_max * 1e-3) / 1e9
         traffic, traffic_source = traffic_entry(args.config, n_sets)
+        if live_traffic[0] is not None:
+            traffic, traffic_source = live_traffic
+        elif live_traffic[1]:
+            traffic_source += "; live probe: " + live_traffic[1]
         kernel_only = {"value": world * args.sets_per_gpu * args.steps / t_max, "unit": "frames/s", "ms_per_step": t_max / args.steps * 1e3,
                        "what": "decode only, no collective: %d frame-sets per GPU per step" % args.sets_per_gpu}
         gathered = world > 1 and not args.no_gather
@@ -698,6 +768,8 @@ def main():
         sys.exit(launch_ranks(args, sys.argv[1:]))
     if args.selftest_launcher:
         return selftest_rank(args)
+    if args.traffic_probe_child:
+        return traffic_probe_child(args)
     run_rank(args)
 
 
