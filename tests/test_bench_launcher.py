@@ -43,3 +43,44 @@ def test_more_ranks_than_gpus_is_refused_without_the_rehearsal_flag():
         pytest.skip("this host has the GPUs the command asks for")
     r = _run()                                                          # no GPU in this container (and one on the GPU box)
     assert r.returncode != 0 and "refusing" in r.stderr
+
+
+def test_traffic_probe_parses_the_counter_files(tmp_path, monkeypatch):
+    """bench.py measures roofline.traffic by running itself under `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE`.  Here a
+    stand-in profiler (a shell script that writes the counter file rocprofv3 would) checks the arithmetic around it: the mean over
+    the decode kernel's dispatches only, FETCH_SIZE x 1024 x 2 (gfx950 tallies 128-byte reads at 64 bytes), WRITE_SIZE x 1024,
+    and the fallback when the profiler fails."""
+    import argparse
+    import stat
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("slx_bench_under_test", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    fake = tmp_path / "rocprofv3"
+    fake.write_text("""#!/bin/bash
+# stand-in for rocprofv3: --pmc <COUNTER> ... -d <dir> -- <program>
+while [ $# -gt 0 ]; do case "$1" in --pmc) C=$2; shift;; -d) D=$2; shift;; --) break;; esac; shift; done
+[ -n "$FAKE_FAIL" ] && exit 3
+mkdir -p $D/box
+V=432000; [ $C = WRITE_SIZE ] && V=576000
+{ echo '"Dispatch_Id","Kernel_Name","Counter_Name","Counter_Value"'
+  echo "1,\\"void (anonymous namespace)::slx_strip_kernel<3, 3, 0, 4, false>(SlxKParams)\\",\\"$C\\",$V"
+  echo "2,\\"void (anonymous namespace)::slx_strip_kernel<3, 3, 0, 4, false>(SlxKParams)\\",\\"$C\\",$((V + 2000))"
+  echo "3,\\"some_other_kernel\\",\\"$C\\",999999999"; } > $D/box/1_counter_collection.csv
+""")
+    fake.chmod(fake.stat().st_mode | stat.S_IEXEC)
+    monkeypatch.setenv("PATH", str(tmp_path) + os.pathsep + os.environ["PATH"])
+    for k in list(os.environ):
+        if k.startswith(("ROCPROF", "ROCP_")):
+            monkeypatch.delenv(k)
+    args = argparse.Namespace(config="C4", sets_per_gpu=32, variant=0)
+    total, source = bench.traffic_probe(args)
+    assert total == (433000.0 * 1024 * 2) + (577000.0 * 1024), source
+    assert "measured in this run" in source and "2 / 2 dispatches" in source
+    monkeypatch.setenv("FAKE_FAIL", "1")
+    total, source = bench.traffic_probe(args)
+    assert total is None and "failed" in source
+    monkeypatch.delenv("FAKE_FAIL")
+    monkeypatch.setenv("ROCPROFILER_FAKE", "1")
+    total, source = bench.traffic_probe(args)
+    assert total is None and "already runs under a profiler" in source
