@@ -105,7 +105,16 @@ def cpu_baseline(O, spec, phase_np, gray_np=None, budget_s=12.0):
         dt = time.perf_counter() - t0
         if dt >= budget_s or n >= 200:
             break
-    single = {"value": n / dt, "unit": "frames/s", "cores": 1, "kind": "port",
+    model = "unknown"
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                model = ln.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    host = {"cpu_model": model, "host_logical_cpus": os.cpu_count(), "cpus_this_process_may_use": len(os.sched_getaffinity(0))}
+    single = {"value": n / dt, "unit": "frames/s", "cores": 1, "kind": "port", **host,
               "sample": "%d frame-sets of %dx%d (%s), oracle/slx_oracle.c single thread, reference loop order, %.1f s" % (
                   n, spec["width"], spec["height"], spec["name"], dt)}
     cores = min(len(os.sched_getaffinity(0)), 16)      # a 1-GPU box gets a 16-core share of the host
@@ -117,7 +126,7 @@ def cpu_baseline(O, spec, phase_np, gray_np=None, budget_s=12.0):
         dt2 = time.perf_counter() - t0
         if dt2 >= budget_s / 3 or m >= 400:
             break
-    multi = {"value": m / dt2, "unit": "frames/s", "cores": cores, "kind": "port",
+    multi = {"value": m / dt2, "unit": "frames/s", "cores": cores, "kind": "port", **host,
              "sample": "%d frame-sets, row-parallel OpenMP, %.1f s" % (m, dt2)}
     return single, multi
 
