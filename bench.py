@@ -117,18 +117,27 @@ def cpu_baseline(O, spec, phase_np, gray_np=None, budget_s=12.0):
     single = {"value": n / dt, "unit": "frames/s", "cores": 1, "kind": "port", **host,
               "sample": "%d frame-sets of %dx%d (%s), oracle/slx_oracle.c single thread, reference loop order, %.1f s" % (
                   n, spec["width"], spec["height"], spec["name"], dt)}
-    cores = min(len(os.sched_getaffinity(0)), 16)      # a 1-GPU box gets a 16-core share of the host
-    m = 0
-    t0 = time.perf_counter()
-    while True:
-        O.pipeline(spec, phase_np[m % len(phase_np)], None if gray_np is None else gray_np[m % len(phase_np)], want=("z",), threads=cores, faithful_order=0)
-        m += 1
-        dt2 = time.perf_counter() - t0
-        if dt2 >= budget_s / 3 or m >= 400:
-            break
-    multi = {"value": m / dt2, "unit": "frames/s", "cores": cores, "kind": "port", **host,
-             "sample": "%d frame-sets, row-parallel OpenMP, %.1f s" % (m, dt2)}
+    def row_parallel(cores, budget):
+        m = 0
+        t0 = time.perf_counter()
+        while True:
+            O.pipeline(spec, phase_np[m % len(phase_np)], None if gray_np is None else gray_np[m % len(phase_np)], want=("z",), threads=cores, faithful_order=0)
+            m += 1
+            dt2 = time.perf_counter() - t0
+            if dt2 >= budget or m >= 400:
+                break
+        return {"value": m / dt2, "unit": "frames/s", "cores": cores, "kind": "port", **host,
+                "sample": "%d frame-sets, row-parallel OpenMP on %d threads, %.1f s" % (m, cores, dt2)}
+    # every CPU this process may use; and, beside it, 16 threads -- the 1-GPU box's nominal share of its host (rounds 1-3 reported that figure)
+    usable = len(os.sched_getaffinity(0))
+    multi = row_parallel(usable, budget_s / 3)
+    if usable > 16:
+        multi["with_16_threads"] = row_parallel(16, budget_s / 4)
     return single, multi
+
+
+# frame-sets per launch of the configurations reported under other_configs
+OTHER_SETS = {"C3": 16, "C5": 4, "REF": 32, "C2": 80}
 
 
 def kernel_name(spec, variant):
@@ -151,8 +160,8 @@ def traffic_entry(config, n_sets):
     return None, "not measured"
 
 
-def traffic_probe(args):
-    """HBM bytes per launch of the headline kernel, measured in THIS run: two child runs of this script (12 launches of the same
+def traffic_probe(args, config=None, sets=None):
+    """HBM bytes per launch of a configuration's kernel (default: the headline's), measured in THIS run: two child runs of this script (12 launches of the same
     workload each) under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` -- separate passes, no trace domain mixed in, the
     program directly after `--` -- started before this process touches the GPU.  FETCH_SIZE (KiB) x 1024 x 2 (gfx950 tallies
     128-byte read requests at 64 bytes: MI355X_MICROARCH.md, HBM), WRITE_SIZE (KiB) x 1024; means over the kernel's dispatches.
@@ -166,6 +175,8 @@ def traffic_probe(args):
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(exe):
         return None, "rocprofv3 not found"
+    config = config or args.config
+    sets = sets or args.sets_per_gpu
     got = {}
     work = tempfile.mkdtemp(prefix="slx_traffic_", dir="/tmp")
     try:
@@ -173,13 +184,18 @@ def traffic_probe(args):
             out = os.path.join(work, counter)
             env = dict(os.environ, TMPDIR="/tmp")
             cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", out, "--", sys.executable, os.path.abspath(__file__),
-                   "--traffic-probe-child", "--config", args.config, "--sets-per-gpu", str(args.sets_per_gpu), "--variant", str(args.variant)]
+                   "--traffic-probe-child", "--config", config, "--sets-per-gpu", str(sets), "--variant", str(args.variant)]
+            for kv in args.tune:                     # the probe must run the launch plan the timed region runs (strip_rows, gray_plain ... change the traffic)
+                cmd += ["--tune", kv]
             r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=240)
-            files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
+            files = sorted(glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True))
             if r.returncode != 0 or not files:
                 return None, "rocprofv3 --pmc %s failed (rc %s)" % (counter, r.returncode)
-            vals = [float(row["Counter_Value"]) for row in csv.DictReader(open(files[0]))
-                    if row["Counter_Name"] == counter and ("slx_strip_kernel" in row["Kernel_Name"] or "slx_fused_kernel" in row["Kernel_Name"])]
+            vals = []
+            for fn in files:                         # the profiler may write one file per process: every one of them is read
+                with open(fn) as fh:
+                    vals += [float(row["Counter_Value"]) for row in csv.DictReader(fh)
+                             if row["Counter_Name"] == counter and ("slx_strip_kernel" in row["Kernel_Name"] or "slx_fused_kernel" in row["Kernel_Name"])]
             if not vals:
                 return None, "no dispatch of the decode kernel in the %s pass" % counter
             got[counter] = (sum(vals) / len(vals), len(vals))
@@ -205,6 +221,7 @@ def traffic_probe_child(args):
     torch.cuda.synchronize()
     with api.Context(spec, device=0) as ctx:
         ctx.set_variant(args.variant)
+        ctx.set_tuning(**{k: int(v) for k, _, v in (kv.partition("=") for kv in args.tune)})
         for _ in range(12):
             ctx.decode_batch(args.sets_per_gpu, phase, gray, z)
         ctx.synchronize()
@@ -343,10 +360,16 @@ def run_rank(args):
     if not os.environ.get("SLX_BENCH_SELF_LAUNCHED"):
         ensure_built()                     # before any GPU call; under a launcher every rank passes through the lock
     live_traffic = (None, None)
+    live_other = {}                        # other_configs label -> (bytes per launch, provenance), measured in this run
     if world == 1 and not args.no_traffic_probe:
         t0p = time.perf_counter()
         live_traffic = traffic_probe(args)  # child processes; this process has not touched the GPU yet
         log("[bench] traffic probe: %s (%.1f s)" % (live_traffic[1], time.perf_counter() - t0p))
+        if not args.no_other_configs and args.config != "C3":
+            # BASELINE.json's config 3 is the one worded "rocprof HBM-bandwidth capture": its traffic is measured live as well
+            t0p = time.perf_counter()
+            live_other["C3"] = traffic_probe(args, "C3", OTHER_SETS["C3"])
+            log("[bench] traffic probe C3: %s (%.1f s)" % (live_other["C3"][1], time.perf_counter() - t0p))
 
     import numpy as np
     import torch
@@ -488,7 +511,12 @@ def run_rank(args):
             "config": {"workload": "%s: %dx%d, %d-frequency x %d-step temporal unwrap%s + triangulation, %d frame-sets per GPU per step%s"
                                    % (args.config, W, full_h, spec["n_freq"], spec["n_steps"], " + %d-bit Gray mask" % spec["gray_bits"] if n_gray else "", args.sets_per_gpu, workload_tail),
                        "periods": spec["periods"],
-                       "sharding": ("by row tile, one grouped ncclSend/ncclRecv gather per step" if gathered else
+                       "sharding": (("by row tile (%d rows of %d per GPU), one grouped ncclSend/ncclRecv gather of the depth tiles to rank 0 per step. "
+                                     "`value` is that split END TO END and is bound by the root's ingest: (N-1)/N of every depth map "
+                                     "(%.2f GB per step) arrives over rank 0's N-1 = %d xGMI links, so it is expected BELOW N x the N = 1 value "
+                                     "and is not a regression of the decode; the decode alone scales as `kernel_only` (%.0f frames/s here)")
+                                    % (full_h // world, full_h, world * args.sets_per_gpu * (full_h - full_h // world) * W * 8 / 1e9, world - 1,
+                                       kernel_only["value"]) if gathered else
                                     ("by frame-set" if args.shard == "framesets" or world == 1 else "by row tile (%d rows of %d per GPU, %d frame-sets)" % (H, full_h, n_sets)) + ", no data-path collective"),
                        "kernel_variant": args.variant, "settle_launches": settle, "tuning": tune or None},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -496,7 +524,10 @@ def run_rank(args):
                          "kernel": kernel_name(spec, args.variant), "launch_ms": kernel_ms_max,
                          "algorithmic_bytes_per_launch": bytes_per_launch},
             "achieved_hbm_gbps_per_gpu": achieved, "kernel_only": kernel_only,
-            "rccl_world_size": (dist.get_world_size() if world > 1 else 1), "collective_backend": (backend if world > 1 else None),
+            # rccl_world_size: ncclCommCount of the communicator the gather ran on (slx_comm_info asks RCCL), null when no RCCL
+            # communicator existed (N = 1, --no-gather, the one-GPU gloo rehearsal); torch's own count sits beside it
+            "rccl_world_size": rccl_info["world"], "rccl_rank_of_rank0": rccl_info["rank"], "torch_world_size": (dist.get_world_size() if world > 1 else 1),
+            "collective_backend": (backend if world > 1 else None),
             "cpu_baseline": cpu_single, "cpu_baseline_all_cores": cpu_multi,
             "parity_vs_oracle": parity, "other_configs": other, "with_gather": gather,
         }
@@ -504,6 +535,7 @@ def run_rank(args):
     # ------------------------------------------------------------------ N > 1: decode + gather, both ways of cutting the batch
     gather = None
     watchdog = None
+    rccl_info = {"world": None, "rank": None}
     headline = None                 # seconds for args.steps steps of decode + gather by rows (MAX over ranks)
     gather_ok = True
     if world > 1 and not args.no_gather:
@@ -526,7 +558,7 @@ def run_rank(args):
         watchdog = threading.Timer(args.gather_timeout, gather_stuck)
         watchdog.daemon = True
         watchdog.start()
-        gather.update({"rccl_world_size": dist.get_world_size(), "backend": "RCCL (libslx slx_decode_gather: grouped ncclSend/ncclRecv)" if backend == "nccl"
+        gather.update({"torch_world_size": dist.get_world_size(), "backend": "RCCL (libslx slx_decode_gather: grouped ncclSend/ncclRecv)" if backend == "nccl"
                   else "%s via torch.distributed (one-GPU rehearsal, depth maps staged through the host)" % backend,
                   "chunk_sets": args.gather_chunk, "root": 0})
         comm = None
@@ -536,6 +568,8 @@ def run_rank(args):
                 ids = [api.comm_unique_id() if rank == 0 else None]
                 dist.broadcast_object_list(ids, src=0)
                 comm = api.Comm(ctx, ids[0], world, rank)
+                rccl_info["world"], rccl_info["rank"] = comm.info()          # RCCL's own count and rank for this communicator
+                gather["rccl_world_size"] = rccl_info["world"]
         except Exception as e:
             comm = None
             gather["error"] = "communicator: %s: %s" % (type(e).__name__, e)
@@ -679,7 +713,8 @@ def run_rank(args):
             #   C4x1, REFx1  ONE frame-set per launch: the call the reference makes (CCalculation::CalculateFirst)
             other = {}
             threads = min(len(os.sched_getaffinity(0)), 16)
-            for label, name, sets, aux in (("C3", "C3", 16, ()), ("C5", "C5", 4, ()), ("REF", "REF", 32, ()), ("C2", "C2", 80, ()),
+            for label, name, sets, aux in (("C3", "C3", OTHER_SETS["C3"], ()), ("C5", "C5", OTHER_SETS["C5"], ()), ("REF", "REF", OTHER_SETS["REF"], ()),
+                                           ("C2", "C2", OTHER_SETS["C2"], ()),
                                            ("C4+xyUk", "C4", 16, ("x", "y", "U", "k")), ("C4x1", "C4", 1, ()), ("REFx1", "REF", 1, ())):
                 if label == args.config:
                     continue
@@ -698,16 +733,32 @@ def run_rank(args):
 
                         def ostep():
                             octx.decode_batch_ex(sets, oph, ogr, **outs)
-                        for _ in range(60):
-                            ostep()
+                        # parity first: the oracle call is seconds of CPU work during which the GPU idles and its clock drops
+                        ostep()
                         torch.cuda.synchronize()
-                        n_launch = max(50, min(args.steps, 100)) * (4 if sets == 1 else 1)
-                        _, oms = timed(ostep, n_launch, on=own_stream(octx))
+                        oref = O.pipeline(ospec, oph[0].cpu().numpy(), None if ogr is None else ogr[0].cpu().numpy(), want=("z",) + tuple(aux), threads=threads)
+                        ok = all(bool(np.array_equal(outs[p][0].cpu().numpy(), oref[p], equal_nan=True)) for p in ("z",) + tuple(aux))
+                        # then settle BY TIME, immediately before the timed region: >= 60 ms and >= 40 launches of this very
+                        # configuration (the clock needs ~35 ms of load after an idle spell, tools/ramp.py) ...
+                        t_settle, n_settle = time.perf_counter(), 0
+                        while n_settle < 40 or time.perf_counter() - t_settle < 0.060:
+                            for _ in range(10):
+                                ostep()
+                            torch.cuda.synchronize()
+                            n_settle += 10
+                        # ... and the MEDIAN of 5 back-to-back blocks (a single block is at the mercy of one clock step)
+                        n_launch = max(30, min(args.steps, 60)) * (4 if sets == 1 else 1)
+                        blocks = sorted(timed(ostep, n_launch, on=own_stream(octx))[1] for _ in range(5))
+                        oms = blocks[2]
                     obytes = sets * oH * oW * (synth.algorithmic_bytes_per_pixel(ospec) + aux_bpp)
-                    oref = O.pipeline(ospec, oph[0].cpu().numpy(), None if ogr is None else ogr[0].cpu().numpy(), want=("z",) + tuple(aux), threads=threads)
-                    ok = all(bool(np.array_equal(outs[p][0].cpu().numpy(), oref[p], equal_nan=True)) for p in ("z",) + tuple(aux))
                     otraffic, osource = (None, "not measured") if aux or sets == 1 else traffic_entry(name, sets)
-                    other[label] = {"value": sets / (oms * 1e-3), "unit": "frames/s", "sets_per_launch": sets, "launches": n_launch, "launch_ms": oms,
+                    if label in live_other:
+                        if live_other[label][0] is not None:
+                            otraffic, osource = live_other[label]
+                        else:
+                            osource += "; live probe: " + str(live_other[label][1])
+                    other[label] = {"value": sets / (oms * 1e-3), "unit": "frames/s", "sets_per_launch": sets, "launches": 5 * n_launch, "launch_ms": oms,
+                                    "launch_ms_blocks": blocks, "settle_launches": n_settle,
                                     "outputs": ["z"] + list(aux), "bytes_per_pixel": synth.algorithmic_bytes_per_pixel(ospec) + aux_bpp,
                                     "roofline": {"bound": "hbm", "achieved": obytes / (oms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                                  "frac": obytes / (oms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "traffic": otraffic, "traffic_source": osource,
@@ -769,7 +820,7 @@ def selftest_rank(args):
         # the key layout of the real N > 1 line: `value` IS the row-tile split end to end, exactly --steps steps
         print(json.dumps({"metric": "launcher_selftest", "value": res["rows"]["end_to_end"]["value"], "unit": "frames/s", "n_gpus": world,
                           "steps": args.steps, "warmup": args.warmup, "ms_per_step": res["rows"]["end_to_end"]["ms_per_step"], "max_rank": float(t[0]),
-                          "rccl_world_size": dist.get_world_size(), "collective_backend": "gloo", "kernel_only": None, "with_gather": res}), flush=True)
+                          "rccl_world_size": None, "torch_world_size": dist.get_world_size(), "collective_backend": "gloo", "kernel_only": None, "with_gather": res}), flush=True)
     dist.destroy_process_group()
 
 

@@ -249,7 +249,8 @@ enum slx_tuning_key {
     SLX_TUNE_LDS_PAD_KIB = 5,  /* extra LDS per workgroup in KiB (lowers the occupancy), 1..128         */
     SLX_TUNE_PLAIN_ORDER = 6,  /* 1: Gray-mask work items in plain order instead of XCD-grouped         */
     SLX_TUNE_TIERS = 7,        /* tiers of ever shorter work items towards the end of a launch, 1..4    */
-    SLX_TUNE_COUNT = 8
+    SLX_TUNE_WEAVE = 8,        /* rows woven into one row group (a lane's rows are that far apart), 1..64 */
+    SLX_TUNE_COUNT = 9
 };
 int slx_set_tuning(slx_ctx *ctx, int key, int value);
 

@@ -407,7 +407,7 @@ class Context:
 
 
 VARIANT_AUTO, VARIANT_GENERIC, VARIANT_STRIP, VARIANT_GENERIC_FAST = range(4)
-TUNE_KEYS = {"strip_rows": 0, "tail_pct": 1, "tail_rows": 2, "gray_plain": 3, "strip_waves": 4, "lds_pad_kib": 5, "plain_order": 6, "tiers": 7}
+TUNE_KEYS = {"strip_rows": 0, "tail_pct": 1, "tail_rows": 2, "gray_plain": 3, "strip_waves": 4, "lds_pad_kib": 5, "plain_order": 6, "tiers": 7, "weave": 8}
 
 
 class Pipe:
@@ -508,9 +508,15 @@ class Comm:
         if rc != OK:
             self._h = C.c_void_p()
             raise SlxError(rc, lib().slx_comm_last_error(None).decode())
+        self.world, self.rank = self.info()
+
+    def info(self):
+        """(ranks, this rank) as RCCL reports them for the communicator the gather runs on (ncclCommCount / ncclCommUserRank)."""
         w, r = C.c_int(), C.c_int()
-        lib().slx_comm_info(self._h, C.byref(w), C.byref(r))
-        self.world, self.rank = w.value, r.value
+        rc = lib().slx_comm_info(self._h, C.byref(w), C.byref(r))
+        if rc != OK:
+            raise SlxError(rc, "slx_comm_info failed")
+        return w.value, r.value
 
     def close(self):
         if self._h:

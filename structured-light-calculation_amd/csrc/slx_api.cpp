@@ -375,6 +375,10 @@ int slx_create(const slx_config *cfg, slx_ctx **out)
     kp.fov_min = c.fov_min;
     kp.fov_max = c.fov_max;
     kp.out_set_stride = (size_t)c.width * (size_t)c.height;
+    {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) kp.n_cus = (unsigned)cus;
+    }
     if (mode_has_phase(c.mode)) nstep_weights(c.n_steps, kp.wy, kp.wx, &kp.wscale);
     if (mode_has_depth(c.mode)) calibrate(ctx);
     for (int f = 0; f < SLX_MAX_FREQ; f++) {
@@ -1097,7 +1101,8 @@ int slx_set_tuning(slx_ctx *ctx, int key, int value)
     struct Range { int *field; int lo, hi; };
     SlxTuning &t = ctx->tune;
     const Range r[SLX_TUNE_COUNT] = {{&t.strip_rows, 0, 32}, {&t.tail_pct, -1, 99}, {&t.tail_rows, 0, 32}, {&t.gray_plain, 0, 1},
-                                     {&t.strip_waves, 0, 4}, {&t.lds_pad_kib, 0, 128}, {&t.plain_order, 0, 1}, {&t.tiers, 0, SLX_MAX_TIERS}};
+                                     {&t.strip_waves, 0, 4}, {&t.lds_pad_kib, 0, 128}, {&t.plain_order, 0, 1}, {&t.tiers, 0, SLX_MAX_TIERS},
+                                     {&t.weave, 0, 64}};
     if (key < 0 || key >= SLX_TUNE_COUNT) return fail(ctx, SLX_ERR_INVALID_ARG, "unknown tuning key %d", key);
     if (value < r[key].lo || value > r[key].hi) return fail(ctx, SLX_ERR_INVALID_ARG, "tuning key %d takes values in [%d,%d] (got %d)", key, r[key].lo, r[key].hi, value);
     *r[key].field = value;

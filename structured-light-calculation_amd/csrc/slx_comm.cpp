@@ -226,6 +226,15 @@ int slx_comm_create(slx_ctx *ctx, const void *id, size_t id_bytes, int world, in
         c->comm = nullptr;
         return bail(cfail(c, SLX_ERR_HIP, "ncclCommInitRank(rank %d of %d, device %d): %s", rank, world, c->device, ncclGetErrorString(r)));
     }
+    // world and rank as the communicator RCCL built reports them -- what slx_comm_info returns and the bench prints as
+    // "rccl_world_size" -- not the numbers the caller passed in; a communicator that disagrees with them is refused
+    int got_world = -1, got_rank = -1;
+    if (ncclCommCount(c->comm, &got_world) != ncclSuccess || ncclCommUserRank(c->comm, &got_rank) != ncclSuccess)
+        return bail(cfail(c, SLX_ERR_HIP, "ncclCommCount / ncclCommUserRank failed on the new communicator"));
+    if (got_world != world || got_rank != rank)
+        return bail(cfail(c, SLX_ERR_HIP, "RCCL built a communicator of %d ranks (this one %d), asked for %d (%d)", got_world, got_rank, world, rank));
+    c->world = got_world;
+    c->rank = got_rank;
     int rc = finish_create(c, out);
     return rc == SLX_OK ? rc : bail(rc);
 }
@@ -267,11 +276,14 @@ int slx_gather_plan(const slx_shard *shards, int world, int rank, int height, in
     return SLX_OK;
 }
 
+// Asks the communicator itself (ncclCommCount / ncclCommUserRank), every time: the numbers are RCCL's, not remembered arguments.
 int slx_comm_info(const slx_comm *c, int *world, int *rank)
 {
-    if (!c) return SLX_ERR_INVALID_ARG;
-    if (world) *world = c->world;
-    if (rank) *rank = c->rank;
+    if (!c || !c->comm) return SLX_ERR_INVALID_ARG;
+    int w = 0, r = 0;
+    if (ncclCommCount(c->comm, &w) != ncclSuccess || ncclCommUserRank(c->comm, &r) != ncclSuccess) return SLX_ERR_HIP;
+    if (world) *world = w;
+    if (rank) *rank = r;
     return SLX_OK;
 }
 

@@ -63,6 +63,7 @@ struct SlxKParams {
     unsigned tier_first_wg[SLX_MAX_TIERS], tier_wgs[SLX_MAX_TIERS];
     int fast_arith;                             // generic kernel: use the bit-identical cheap unwrap / in-range division (host-checked)
     int plain_order;                            // Gray-mask strip kernel: items in plain order instead of XCD-grouped (slx_set_tuning, A/B only)
+    unsigned n_cus;                             // compute units of the context's device (0: 256, an unpartitioned MI355X); sizes "one round of items"
     unsigned long long *stamps;                 // diagnostics: 4 words per work item (s_memtime / s_memrealtime at start, end) or null
     unsigned long long stamp_items;             // items the stamp buffer has room for
 };
@@ -115,10 +116,16 @@ struct SlxTuning {
     int strip_waves;     // waves per workgroup, 1..4
     int lds_pad_kib;     // extra LDS per workgroup (lowers the occupancy), 0..128
     int plain_order;     // 1: Gray-mask items in plain order instead of XCD-grouped
+    int weave;           // rows woven into one row group, rounded down to a multiple of the smallest legal count, 1..64
 };
 
+// Waves per SIMD the VGPR count of a strip-kernel instantiation allows (host-side table, checked against the compiled kernels
+// by tests/test_kernel_resources.py).
+extern "C" unsigned slx_strip_waves_per_simd(int mode, int n_freq, int gray_ring_bits, int n_steps, int aux);
+
 // Rows per work item the strip kernel's launcher picks (host-side model, exported for the CPU tests).
-extern "C" unsigned slx_strip_rows_model(unsigned height, unsigned interleave, unsigned chunks_per_group, unsigned n_sets, unsigned slots_per_cu, unsigned preferred);
+extern "C" unsigned slx_strip_rows_model(unsigned height, unsigned interleave, unsigned chunks_per_group, unsigned n_sets, unsigned slots_per_cu, unsigned preferred,
+                                         unsigned n_cus);
 
 // A planned decode launch (slx_plan.cpp, host arithmetic only): the parameter block with the work-item geometry filled in,
 // which kernel family, the grid.  Returns 0, or non-zero when no plan exists (variant 2 on ineligible operands, ...).

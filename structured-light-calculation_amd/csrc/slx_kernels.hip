@@ -24,6 +24,10 @@
 
 #pragma clang fp contract(off)
 
+#ifndef SLX_EXP
+#define SLX_EXP 0
+#endif
+
 namespace {
 
 // ---- cv::fastAtan2 constants (OpenCV 2.4.9 mathfuncs.cpp), float products in float ------
@@ -222,6 +226,9 @@ __device__ __forceinline__ V pix_from_octant_angle(V a, V mgt, V mc, V ms, float
 template <bool SCALED, typename V>
 __device__ __forceinline__ V wrapped_pix_from_diffs(V s2, V c2, float Tf)
 {
+#if SLX_EXP & 16
+    return v_fma(s2, c2, Tf);              // TIMING DIAGNOSTIC ONLY (wrong results): no angle
+#endif
     constexpr float kGuard = SCALED ? 0x1p-23f : 1.0f;
     const V as = v_abs(s2), ac = v_abs(c2);
     const V mx = v_max3(as, ac, kGuard);
@@ -280,9 +287,10 @@ __device__ __forceinline__ double div_f64_inrange(double num, double den)
 }
 
 // a7 for one pixel: z = -(cA - cB U)/(cC - cD U), FOV clamp, U == 0 / mask -> 0.
-template <bool LEAN>
+// RAW: the quotient as computed and, in *drop_out, whether it is to be dropped (the caller zeroes it where that is cheaper than a select).
+template <bool LEAN, bool RAW = false>
 __device__ __forceinline__ double tri_depth(double Uv, double cC, double cD, double cA, double cB,
-                                            double fov_min, double fov_max, bool valid)
+                                            double fov_min, double fov_max, bool valid, bool *drop_out = nullptr)
 {
     const double num = cA - cB * Uv;
     double zz;
@@ -299,6 +307,10 @@ __device__ __forceinline__ double tri_depth(double Uv, double cC, double cD, dou
     }
     // one select for the three reasons to drop the depth (a NaN depth fails no test and stays, as in the reference)
     const bool drop = (zz < fov_min) | (zz > fov_max) | (Uv == 0.0) | !valid;
+    if constexpr (RAW) {
+        *drop_out = drop;
+        return zz;
+    }
     return drop ? 0.0 : zz;
 }
 
@@ -696,6 +708,16 @@ __device__ __forceinline__ StripPos strip_locate(const SlxKParams &p, unsigned i
     constexpr unsigned SPAN = HALO ? 62u : 64u;
     StripPos s;
     const unsigned lane = threadIdx.x & 63u;
+#if SLX_EXP & 32
+    // TIMING DIAGNOSTIC ONLY: consecutive groups of 60 items are dealt round-robin over 8 frame-sets (the launch must hold a multiple of 8):
+    // short items with the footprint of long ones
+    if (items_per_set % 60u == 0u && (gridDim.x * (blockDim.x >> 6)) % (8u * items_per_set) == 0u) {   // else: not a bijection, leave the order alone
+        const unsigned blk = item / 60u, within = item - blk * 60u;
+        const unsigned bps = items_per_set / 60u;                     // blocks per set (items_per_set a multiple of 60 in the diagnostic runs)
+        const unsigned oct = blk / (8u * bps), r8 = blk - oct * 8u * bps;
+        item = ((oct * 8u + (r8 & 7u)) * bps + (r8 >> 3)) * 60u + within;
+    }
+#endif
     s.set = item / items_per_set;
     const unsigned rem = item - s.set * items_per_set;
     const unsigned g = rem / p.chunks_per_group;
@@ -822,6 +844,9 @@ __global__ __launch_bounds__(256) void slx_strip_kernel(const SlxKParams p)
         for (int f = 1; f < F; f++) asm volatile("" : "+v"(kinvT[f]));
     }
 
+    constexpr bool ZERO_IN_LDS = (SLX_EXP & 2) && !MASKED && !AUX;
+    double kzero = 0.0;
+    asm volatile("" : "+v"(kzero));
     bool lane_valid;
     const StripPos pos = strip_locate<MASKED>(p, item, items_per_set, RB, region_row0, lane_valid);
     const size_t pset = (size_t)pos.set * p.phase_set_stride;
@@ -1002,13 +1027,25 @@ __global__ __launch_bounds__(256) void slx_strip_kernel(const SlxKParams p)
                 }
 #pragma unroll
                 for (int f = 0; f < ((NS == 4 && c == 0) ? F : 0); f++) {
+                    const f32x2 kUp = {0x1p126f, 0x1p126f};
+#if SLX_EXP & 1
+                    // every byte of the quad arrives as its own zero-extended dword (ds_read_u8: the LDS pipe does the byte select), i.e. as
+                    // the denormal byte * 2^-149; a pixel pair's difference is then ONE packed subtraction
+                    typedef __attribute__((address_space(3))) const volatile uint8_t lds_u8;   // volatile: hipcc would merge the four loads of a dword back into one
+                    lds_u8 *sb = (lds_u8 *)(src);
+                    auto den = [&](int plane, int j) { return __builtin_bit_cast(float, (uint32_t)sb[((f * 4 + plane) * 64) * 4 + j]); };
+                    auto pair = [&](int plane, int j) { return f32x2{den(plane, j), den(plane, j + 1)}; };
+                    const F32x2x2 px = wrapped_pix_from_diffs<true>(
+                        F32x2x2{(pair(0, 0) - pair(2, 0)) * kUp, (pair(0, 2) - pair(2, 2)) * kUp},
+                        F32x2x2{(pair(1, 0) - pair(3, 0)) * kUp, (pair(1, 2) - pair(3, 2)) * kUp}, Tf[f]);
+#else
                     const uint32_t w0 = src[(f * 4 + 0) * 64], w1 = src[(f * 4 + 1) * 64];
                     const uint32_t w2 = src[(f * 4 + 2) * 64], w3 = src[(f * 4 + 3) * 64];
                     // differences as denormals (x 2^-149), rescaled to x 2^-23 by one packed multiply per pair
-                    const f32x2 kUp = {0x1p126f, 0x1p126f};
                     const F32x2x2 px = wrapped_pix_from_diffs<true>(
                         F32x2x2{f32x2{byte_diff_denorm<0>(w0, w2), byte_diff_denorm<1>(w0, w2)} * kUp, f32x2{byte_diff_denorm<2>(w0, w2), byte_diff_denorm<3>(w0, w2)} * kUp},
                         F32x2x2{f32x2{byte_diff_denorm<0>(w1, w3), byte_diff_denorm<1>(w1, w3)} * kUp, f32x2{byte_diff_denorm<2>(w1, w3), byte_diff_denorm<3>(w1, w3)} * kUp}, Tf[f]);
+#endif
                     pix[f][0] = px.a.x;
                     pix[f][1] = px.a.y;
                     pix[f][2] = px.b.x;
@@ -1034,6 +1071,7 @@ __global__ __launch_bounds__(256) void slx_strip_kernel(const SlxKParams p)
 #pragma unroll
                 for (int j = 0; j < SLX_QUAD; j++) kf[f][j] = 0;
         }
+        bool dropq[SLX_QUAD] = {false, false, false, false};
         int v0[SLX_QUAD] = {1, 1, 1, 1};                                // x3: lanes without pixels never veto
         int okq[SLX_QUAD] = {1, 1, 1, 1};                               // the mask plane: 1 outside the Gray-mask mode
         if (row < H) {
@@ -1104,6 +1142,9 @@ __global__ __launch_bounds__(256) void slx_strip_kernel(const SlxKParams p)
             } else {
 #pragma unroll
                 for (int j = 0; j < SLX_QUAD; j++) {
+#if SLX_EXP & 8
+                    U[j] = (double)((pix[0][j] + pix[F - 1][j]) + pix[F > 1 ? 1 : 0][j]);   // TIMING DIAGNOSTIC ONLY (wrong results): no unwrap
+#else
                     double Uf = (double)pix[0][j];
 #pragma unroll
                     for (int f = 1; f < F; f++) {
@@ -1112,6 +1153,7 @@ __global__ __launch_bounds__(256) void slx_strip_kernel(const SlxKParams p)
                         if constexpr (AUX && NK > 0) kf[f - 1][j] = k;
                     }
                     U[j] = Uf;
+#endif
                 }
             }
             if constexpr (MASKED) {                                     // x3, stripe agreement of this lane's pixels
@@ -1131,7 +1173,12 @@ __global__ __launch_bounds__(256) void slx_strip_kernel(const SlxKParams p)
                 for (int j = 0; j < SLX_QUAD; j++) {
                     const double cC = (aC[j] + tvC) + kK1;
                     const double cD = (aD[j] + tvD) + kK2;
-                    z[j] = tri_depth<true>(U[j], cC, cD, kcA, kcB, kfmin, kfmax, true);
+#if SLX_EXP & 4
+                    z[j] = U[j] + cC;          // TIMING DIAGNOSTIC ONLY (wrong results): no triangulation
+#else
+                    if constexpr (ZERO_IN_LDS) z[j] = tri_depth<true, true>(U[j], cC, cD, kcA, kcB, kfmin, kfmax, true, &dropq[j]);
+                    else z[j] = tri_depth<true>(U[j], cC, cD, kcA, kcB, kfmin, kfmax, true);
+#endif
                 }
             }
             if constexpr (!MASKED) {
@@ -1139,6 +1186,14 @@ __global__ __launch_bounds__(256) void slx_strip_kernel(const SlxKParams p)
                 // tile stage nothing and are never stored.
                 stage[2 * lane + 0] = vec2{z[0], z[1]};
                 stage[2 * lane + 1] = vec2{z[2], z[3]};
+                if constexpr (ZERO_IN_LDS) {
+                    // a dropped depth is overwritten with 0.0 in the staging area by the lanes that drop it: an exec-masked ds_write_b64
+                    // (scalar mask + LDS pipe) instead of two v_cndmask per pixel; a wave's LDS operations execute in order
+                    const unsigned sa = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)(stage + 2 * lane);
+#pragma unroll
+                    for (int j = 0; j < SLX_QUAD; j++)
+                        if (dropq[j]) asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(sa), "v"(kzero), "n"(8 * j) : "memory");
+                }
             }
         }
         if constexpr (MASKED) {

@@ -68,6 +68,21 @@ bool slx_strip_eligible(const SlxKParams &kp, int mode, bool aux)
     return true;
 }
 
+// Waves per SIMD the register file allows a strip-kernel instantiation (512 VGPRs per lane and SIMD, allocated in blocks of 8):
+// 4 up to 128 VGPRs, 3 up to 168.  The instantiations above 128 are the optional-plane (AUX) variants of the wide configurations;
+// tests/test_kernel_resources.py compiles the kernels and fails when this table claims more waves than the compiled code allows,
+// when any instantiation spills a vector register or uses scratch (the counted s_waitcnt vmcnt(n) of the DMA ring are exact only
+// while hipcc adds no vector-memory operation of its own), or when a Gray-free / ring-Gray instantiation without the optional
+// planes leaves the 128 that 4 waves per SIMD need.
+unsigned slx_strip_waves_per_simd(int mode, int n_freq, int gray_ring_bits, int n_steps, int aux)
+{
+    if (!aux) return 4;
+    if (mode == SLX_MODE_MULTIFREQ) return n_freq >= 4 ? 3 : 4;
+    if (mode == SLX_MODE_MULTIFREQ_GRAYMASK) return (gray_ring_bits ? n_freq >= 2 : n_freq >= 3) ? 3 : 4;
+    (void)n_steps;
+    return 4;
+}
+
 // Rows per work item of the strip kernel, from the measured sweeps of tools/single_set.py (profiles/r03_rows_sweep.json):
 //  * a launch that fills the chip several times over (>= 15 360 items = 3.75 per resident wave slot) takes the kernel's
 //    preferred item: 16 rows for the Gray-free 4-step kernels (VALU-bound; 16 rows amortise an item's start-up best and
@@ -79,9 +94,11 @@ bool slx_strip_eligible(const SlxKParams &kp, int mode, bool aux)
 //    thinly filled second round: one 1920x1200 frame-set (9 000 wave-rows for 4 096 slots; the call the reference makes,
 //    R/CCalculation.cpp:171-206) runs as 3 000 items of 3 rows in 13.2 us, against 14.7 us as 9 000 items of one row;
 //  * in between, the largest item that still gives 15 360 items.
-unsigned slx_strip_rows_model(unsigned height, unsigned interleave, unsigned chunks_per_group, unsigned n_sets, unsigned slots_per_cu, unsigned preferred)
+unsigned slx_strip_rows_model(unsigned height, unsigned interleave, unsigned chunks_per_group, unsigned n_sets, unsigned slots_per_cu, unsigned preferred,
+                              unsigned n_cus)
 {
-    const unsigned long long slots = 256ull * std::max(1u, slots_per_cu), many = 256ull * 20ull * 3ull;
+    const unsigned long long cus = n_cus ? n_cus : 256u;             // the device's compute units (a partitioned or smaller device has fewer)
+    const unsigned long long slots = cus * std::max(1u, slots_per_cu), many = cus * 20ull * 3ull;
     auto items = [&](unsigned r) {
         const unsigned long long rows_group = (unsigned long long)interleave * r;
         return ((height + rows_group - 1) / rows_group) * chunks_per_group * (unsigned long long)n_sets;
@@ -144,6 +161,11 @@ int slx_plan_launch(const SlxKParams &kp_in, int mode, bool aux, int n_sets, int
     unsigned g = QR, h = 64;
     while (h) { const unsigned r = g % h; g = h; h = r; }          // gcd(QR, 64)
     kp.interleave = 64u / g;
+    if (tn.weave > 1) {
+        // more rows per row group than whole waves need: the group's waves then sweep `interleave` consecutive rows in step
+        const unsigned m = std::min(64u, (unsigned)tn.weave) / kp.interleave;
+        if (m > 1) kp.interleave *= m;
+    }
     kp.chunks_per_group = mode == SLX_MODE_MULTIFREQ_GRAYMASK ? (kp.interleave * QR + 61u) / 62u   // 62 quads + 2 halo lanes per wave
                                                              : kp.interleave * QR / 64u;
     kp.plain_order = tn.plain_order ? 1 : 0;
@@ -180,9 +202,11 @@ int slx_plan_launch(const SlxKParams &kp_in, int mode, bool aux, int n_sets, int
     const unsigned lds_wave = 2u * ring_planes * 256u + 2048u + (aux ? 2048u : 0u);      // + the optional planes' staging area
     // rows per item (slx_strip_rows_model): the kernel's preferred item for a launch that fills the chip many times over,
     // one round of items for a small one
-    const unsigned slots_per_cu = std::min(16u, 160u * 1024u / lds_wave);
+    // resident waves per CU: what the LDS holds, and what the instantiation's registers allow (slx_strip_waves_per_simd)
+    const unsigned waves_by_regs = 4u * slx_strip_waves_per_simd(mode, kp.n_freq, gb, kp.n_steps, aux ? 1 : 0);
+    const unsigned slots_per_cu = std::min(waves_by_regs, 160u * 1024u / lds_wave);
     const unsigned preferred = kp.n_steps == 8 ? 10u : gb ? 3u : 16u;
-    unsigned rb = slx_strip_rows_model((unsigned)kp.height, kp.interleave, kp.chunks_per_group, (unsigned)n_sets, slots_per_cu, preferred);
+    unsigned rb = slx_strip_rows_model((unsigned)kp.height, kp.interleave, kp.chunks_per_group, (unsigned)n_sets, slots_per_cu, preferred, kp.n_cus);
     // <= 32 rows: slx_strip_eligible bounds the 32-bit output offsets for interleave (<= 64) x 32 rows past the tile
     if (tn.strip_rows >= 1 && tn.strip_rows <= 32) rb = (unsigned)tn.strip_rows;
     // Tiers: the head of every frame-set in items of rb rows, then shorter items (a quarter of the previous tier's rows)
@@ -201,7 +225,7 @@ int slx_plan_launch(const SlxKParams &kp_in, int mode, bool aux, int n_sets, int
     {
         unsigned best = 0;
         for (unsigned w = 4; w >= 1; w--) {
-            const unsigned resident = std::min(16u, w * (160u * 1024u / (w * lds_wave + lds_shared)));
+            const unsigned resident = std::min(waves_by_regs, w * (160u * 1024u / (w * lds_wave + lds_shared)));
             if (resident > best) { best = resident; waves_per_wg = w; }
         }
     }

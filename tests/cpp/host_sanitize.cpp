@@ -171,12 +171,12 @@ static void test_validate_and_create()
     { slx_config d = base_config(64, 48, SLX_MODE_GRAY_PHASE, 1, 4, 17); CHECK(slx_validate_config(&d, msg, sizeof msg) != SLX_OK); }
     { slx_config d = base_config(64, 48, SLX_MODE_GRAY_PHASE, 1, 4, 6); d.gray_lut = nullptr; CHECK(slx_validate_config(&d, msg, sizeof msg) != SLX_OK); }
     { slx_config d = c; d.aux_outputs = 0xffffffffu; CHECK(slx_validate_config(&d, msg, sizeof msg) != SLX_OK); }
-    // no GPU here (or a GPU: then the context is created and destroyed): never a crash, never a CPU fallback
+    // No device is visible to this process (tests/test_sanitizers.py hides the GPUs of a GPU box, so that the run is the same
+    // everywhere and no runtime allocation needs a leak suppression): never a crash, never a CPU fallback, always SLX_ERR_NO_DEVICE.
     slx_ctx *ctx = nullptr;
     const int rc = slx_create(&c, &ctx);
-    CHECK(rc == SLX_OK || rc == SLX_ERR_NO_DEVICE || rc == SLX_ERR_HIP);
-    if (rc == SLX_OK) slx_destroy(ctx);
-    else CHECK(ctx == nullptr && std::strlen(slx_last_error(nullptr)) > 0);
+    CHECK(rc == SLX_ERR_NO_DEVICE);
+    CHECK(ctx == nullptr && std::strlen(slx_last_error(nullptr)) > 0);
     slx_destroy(nullptr);
 }
 
@@ -254,7 +254,7 @@ static void test_plans()
     for (unsigned hh : {1u, 7u, 150u, 720u, 1200u, 3000u, 100000u})
         for (unsigned n : {1u, 3u, 32u, 65535u})
             for (unsigned pref : {0u, 3u, 10u, 16u, 99u}) {
-                const unsigned rws = slx_strip_rows_model(hh, 2, 15, n, 16, pref);
+                const unsigned rws = slx_strip_rows_model(hh, 2, 15, n, 16, pref, (n % 3) ? 256u : 0u);
                 CHECK(rws >= 1 && rws <= 16);
             }
 }

@@ -21,7 +21,7 @@ def test_parent_starts_two_ranks_and_relays_the_line():
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, r.stdout                                    # exactly one line on stdout
     d = json.loads(lines[0])
-    assert d["metric"] == "launcher_selftest" and d["n_gpus"] == 2 and d["rccl_world_size"] == 2
+    assert d["metric"] == "launcher_selftest" and d["n_gpus"] == 2 and d["torch_world_size"] == 2 and d["rccl_world_size"] is None   # gloo: no RCCL communicator exists
     assert d["max_rank"] == 1.0                                         # MAX over ranks of the rank number
     # the key layout of the N > 1 line: the headline IS the row-tile split end to end (gather included), --steps steps of it
     rows = d["with_gather"]["rows"]
@@ -61,22 +61,36 @@ def test_traffic_probe_parses_the_counter_files(tmp_path, monkeypatch):
 # stand-in for rocprofv3: --pmc <COUNTER> ... -d <dir> -- <program>
 while [ $# -gt 0 ]; do case "$1" in --pmc) C=$2; shift;; -d) D=$2; shift;; --) break;; esac; shift; done
 [ -n "$FAKE_FAIL" ] && exit 3
+echo "$@" >> $FAKE_ARGV_LOG
 mkdir -p $D/box
 V=432000; [ $C = WRITE_SIZE ] && V=576000
+# one file per process, as the profiler writes them: the first holds no decode dispatch at all
+{ echo '"Dispatch_Id","Kernel_Name","Counter_Name","Counter_Value"'
+  echo "7,\\"a_kernel_of_the_runtime\\",\\"$C\\",123"; } > $D/box/0_counter_collection.csv
 { echo '"Dispatch_Id","Kernel_Name","Counter_Name","Counter_Value"'
   echo "1,\\"void (anonymous namespace)::slx_strip_kernel<3, 3, 0, 4, false>(SlxKParams)\\",\\"$C\\",$V"
-  echo "2,\\"void (anonymous namespace)::slx_strip_kernel<3, 3, 0, 4, false>(SlxKParams)\\",\\"$C\\",$((V + 2000))"
   echo "3,\\"some_other_kernel\\",\\"$C\\",999999999"; } > $D/box/1_counter_collection.csv
+{ echo '"Dispatch_Id","Kernel_Name","Counter_Name","Counter_Value"'
+  echo "2,\\"void (anonymous namespace)::slx_strip_kernel<3, 3, 0, 4, false>(SlxKParams)\\",\\"$C\\",$((V + 2000))"; } > $D/box/2_counter_collection.csv
 """)
     fake.chmod(fake.stat().st_mode | stat.S_IEXEC)
     monkeypatch.setenv("PATH", str(tmp_path) + os.pathsep + os.environ["PATH"])
     for k in list(os.environ):
         if k.startswith(("ROCPROF", "ROCP_")):
             monkeypatch.delenv(k)
-    args = argparse.Namespace(config="C4", sets_per_gpu=32, variant=0)
+    argv_log = tmp_path / "argv.log"
+    monkeypatch.setenv("FAKE_ARGV_LOG", str(argv_log))
+    args = argparse.Namespace(config="C4", sets_per_gpu=32, variant=0, tune=["strip_rows=8", "gray_plain=1"])
     total, source = bench.traffic_probe(args)
-    assert total == (433000.0 * 1024 * 2) + (577000.0 * 1024), source
+    assert total == (433000.0 * 1024 * 2) + (577000.0 * 1024), source         # dispatches from every counter file, the decode kernel's only
     assert "measured in this run" in source and "2 / 2 dispatches" in source
+    # the child runs the launch plan the timed region runs: every --tune item is forwarded, and so are the workload's keys
+    for ln in argv_log.read_text().splitlines():
+        assert "--tune strip_rows=8 --tune gray_plain=1" in ln and "--config C4 --sets-per-gpu 32" in ln, ln
+    # another configuration of other_configs (C3: BASELINE config 3, "rocprof HBM-bandwidth capture")
+    argv_log.write_text("")
+    total3, _ = bench.traffic_probe(args, "C3", 16)
+    assert total3 == total and all("--config C3 --sets-per-gpu 16" in ln for ln in argv_log.read_text().splitlines())
     monkeypatch.setenv("FAKE_FAIL", "1")
     total, source = bench.traffic_probe(args)
     assert total is None and "failed" in source

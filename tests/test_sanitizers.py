@@ -15,6 +15,10 @@ def _run(cmd, cwd=None, timeout=900):
     env["ASAN_OPTIONS"] = "abort_on_error=0:detect_leaks=1"
     env["UBSAN_OPTIONS"] = "print_stacktrace=1:halt_on_error=1"
     env["LSAN_OPTIONS"] = "suppressions=" + os.path.join(ROOT, "tests", "cpp", "lsan.supp") + ":print_suppressions=0"
+    # CPU only, also on a GPU box: with no visible device slx_create returns SLX_ERR_NO_DEVICE before any context exists, so the
+    # sanitized process never builds HIP state and the result is the same in the CPU container and on the box
+    env["HIP_VISIBLE_DEVICES"] = ""
+    env["ROCR_VISIBLE_DEVICES"] = ""
     return subprocess.run(cmd, cwd=cwd, capture_output=True, text=True, timeout=timeout, env=env)
 
 
