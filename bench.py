@@ -141,6 +141,8 @@ OTHER_SETS = {"C3": 16, "C5": 4, "REF": 32, "C2": 80}
 
 
 def kernel_name(spec, variant):
+    if spec["mode"] in (0, 1) and variant in (0, 2) and spec["n_steps"] == 4 and (spec["mode"] == 0 or spec["gray_bits"] == 6):
+        return "slx_decoder_strip_kernel<mode %d>" % spec["mode"]
     strip = variant in (0, 2) and ((spec["mode"] == 3 and spec["n_steps"] in (4, 8)) or (spec["mode"] in (2, 4) and spec["n_steps"] == 4))
     return ("slx_strip_kernel" if strip else "slx_fused_kernel") + "<mode %d, F=%d, N=%d>" % (spec["mode"], spec["n_freq"], spec["n_steps"])
 
@@ -715,13 +717,19 @@ def run_rank(args):
             threads = min(len(os.sched_getaffinity(0)), 16)
             for label, name, sets, aux in (("C3", "C3", OTHER_SETS["C3"], ()), ("C5", "C5", OTHER_SETS["C5"], ()), ("REF", "REF", OTHER_SETS["REF"], ()),
                                            ("C2", "C2", OTHER_SETS["C2"], ()),
-                                           ("C4+xyUk", "C4", 16, ("x", "y", "U", "k")), ("C4x1", "C4", 1, ()), ("REFx1", "REF", 1, ())):
+                                           ("C4+xyUk", "C4", 16, ("x", "y", "U", "k")), ("C4x1", "C4", 1, ()), ("REFx1", "REF", 1, ()),
+                                           # the reference's two decoder objects on their own (CDecodePhase::Decode: 4 planes in, f64 pix out,
+                                           # 12 B/px; CDecodeGray::Decode: 12 planes in, f64 stripe edge out, 20 B/px), at the reference's size
+                                           ("PHASEx32", "REFPHASE", 32, ()), ("GRAYx32", "REFGRAY", 32, ())):
                 if label == args.config:
                     continue
                 try:
                     ospec = synth.make_spec(name)
                     oH, oW = ospec["height"], ospec["width"]
                     oph, ogr = make_batch(torch, synth, ospec, sets, device, seed=0x5EED + sum(map(ord, label)))
+                    if oph.shape[1] == 0:
+                        oph = None                                   # the Gray decoder has no phase planes
+                    primary = {synth.MODE_PHASE_ONLY: "pix", synth.MODE_GRAY_ONLY: "gray"}.get(ospec["mode"], "z")   # what the primary output holds
                     outs = {"z": torch.empty((sets, oH, oW), dtype=torch.float64, device=device)}
                     for p in aux:
                         outs[p] = (torch.empty((sets, ospec["n_freq"] - 1, oH, oW), dtype=torch.int32, device=device) if p == "k"
@@ -736,7 +744,9 @@ def run_rank(args):
                         # parity first: the oracle call is seconds of CPU work during which the GPU idles and its clock drops
                         ostep()
                         torch.cuda.synchronize()
-                        oref = O.pipeline(ospec, oph[0].cpu().numpy(), None if ogr is None else ogr[0].cpu().numpy(), want=("z",) + tuple(aux), threads=threads)
+                        oref = O.pipeline(ospec, None if oph is None else oph[0].cpu().numpy(), None if ogr is None else ogr[0].cpu().numpy(),
+                                          want=(primary,) + tuple(aux), threads=threads)
+                        oref["z"] = oref[primary].reshape(oH, oW)
                         ok = all(bool(np.array_equal(outs[p][0].cpu().numpy(), oref[p], equal_nan=True)) for p in ("z",) + tuple(aux))
                         # then settle BY TIME, immediately before the timed region: >= 60 ms and >= 40 launches of this very
                         # configuration (the clock needs ~35 ms of load after an idle spell, tools/ramp.py) ...
@@ -759,7 +769,7 @@ def run_rank(args):
                             osource += "; live probe: " + str(live_other[label][1])
                     other[label] = {"value": sets / (oms * 1e-3), "unit": "frames/s", "sets_per_launch": sets, "launches": 5 * n_launch, "launch_ms": oms,
                                     "launch_ms_blocks": blocks, "settle_launches": n_settle,
-                                    "outputs": ["z"] + list(aux), "bytes_per_pixel": synth.algorithmic_bytes_per_pixel(ospec) + aux_bpp,
+                                    "outputs": [primary] + list(aux), "bytes_per_pixel": synth.algorithmic_bytes_per_pixel(ospec) + aux_bpp,
                                     "roofline": {"bound": "hbm", "achieved": obytes / (oms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                                  "frac": obytes / (oms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "traffic": otraffic, "traffic_source": osource,
                                                  "kernel": kernel_name(ospec, args.variant), "algorithmic_bytes_per_launch": obytes},

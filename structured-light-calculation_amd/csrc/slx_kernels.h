@@ -39,13 +39,12 @@ struct SlxKParams {
     double cx, cy, fu, fv, P00, P01, K1, P20, P21, K2, cA, cB;
     // ---- fast path (slx_strip_kernel) ----
     // The planes of a group are equally spaced (slx_strip_eligible): plane k of the phase group starts phase_first + k *
-    // phase_step bytes after plane_base, Gray plane k gray_first + k * gray_step -- two running scalar offsets in the kernel
+    // phase_step bytes after plane_base, Gray plane k (when the Gray planes ride the ring) k * gray_step bytes after gray[0] -- two running scalar offsets in the kernel
     // instead of one register per plane.
     const uint8_t *plane_base;                  // lowest plane address: the buffer descriptor's base
     unsigned phase_first, phase_step;
-    unsigned gray_first, gray_step;             // only when the Gray planes ride the ring
+    unsigned gray_step;                         // only when the Gray planes ride the ring
     int dma_imm;                                // planes are >= 256 bytes apart: the DMAs of a chunk share one M0 and step by the immediate offset
-    long long gray_set_delta;                   // gray_set_stride - phase_set_stride (the descriptor's base advances by phase_set_stride)
     double inv_period[SLX_MAX_FREQ];            // RN(1/T_f)
     double half_biased[SLX_MAX_FREQ];           // 0.5 + 2^-30/T_f
     int std_gray;                               // lut is the reflected Gray code: bin = prefix-xor(gray)

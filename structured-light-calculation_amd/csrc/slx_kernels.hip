@@ -24,6 +24,9 @@
 
 #pragma clang fp contract(off)
 
+// Timing diagnostics, never part of the product build (tools/build_exp.sh builds tmp_ab/libslx_exp<N>.so with -DSLX_EXP=N): they leave
+// VALU work out -- the results are WRONG -- to show what the strip kernel's memory skeleton alone takes:
+//   4: no triangulation   8: no temporal unwrap   16: no angle evaluation
 #ifndef SLX_EXP
 #define SLX_EXP 0
 #endif
@@ -287,10 +290,9 @@ __device__ __forceinline__ double div_f64_inrange(double num, double den)
 }
 
 // a7 for one pixel: z = -(cA - cB U)/(cC - cD U), FOV clamp, U == 0 / mask -> 0.
-// RAW: the quotient as computed and, in *drop_out, whether it is to be dropped (the caller zeroes it where that is cheaper than a select).
-template <bool LEAN, bool RAW = false>
+template <bool LEAN>
 __device__ __forceinline__ double tri_depth(double Uv, double cC, double cD, double cA, double cB,
-                                            double fov_min, double fov_max, bool valid, bool *drop_out = nullptr)
+                                            double fov_min, double fov_max, bool valid)
 {
     const double num = cA - cB * Uv;
     double zz;
@@ -307,10 +309,6 @@ __device__ __forceinline__ double tri_depth(double Uv, double cC, double cD, dou
     }
     // one select for the three reasons to drop the depth (a NaN depth fails no test and stays, as in the reference)
     const bool drop = (zz < fov_min) | (zz > fov_max) | (Uv == 0.0) | !valid;
-    if constexpr (RAW) {
-        *drop_out = drop;
-        return zz;
-    }
     return drop ? 0.0 : zz;
 }
 
@@ -612,7 +610,13 @@ __global__ __launch_bounds__(256) void slx_fused_kernel(const SlxKParams p)
 //  * the casts through double are exact or round identically (the double product of a float and an integer < 2^24
 //    is exact; the double sum with 0.5 is either exact or rounds to the float the f32 add gives), and RN(x/360)
 //    comes from one residual correction (x/360 is never within 1/90 ulp of a rounding tie);
-//  * |x|, |y| are 0 or >= 2^-6 here, far above the 2^-60 the saturating sign tests need.
+//  * the saturating tests: sat(x * -2^60) is the sign test (|x|, |y| are 0 or >= 2^-26, see next), and sat((|y| - |x|) 2^60) the
+//    "sine term larger" test -- right as long as a NON-ZERO difference of the magnitudes is >= 2^-60.  It is >= 2^-26: every term
+//    of the two sums is a multiple of 2^-24 (a byte value, or RN(g r) with r ~ 0.7071, which is 0 or >= 0.7 and so a multiple of
+//    its ulp >= 2^-24), f32 sums of multiples of 2^-24 below 2^11 are again multiples of 2^-24 (exact below 1, rounded to a coarser
+//    grid above), and the scale wscale = 2/N = 2^-2 makes them multiples of 2^-26.  The bound is on the terms, not on |x|, |y|:
+//    the sums may cancel to anything, but never to a non-zero value below the grid.  A change of wscale or of the weights must
+//    re-derive it (tests/test_gpu_parity.py::test_eight_step_sine_cosine_near_ties sits on the equal-magnitude directions).
 template <typename V>
 __device__ __forceinline__ V pix_tail_inrange(V y, V x, float Tf)
 {
@@ -708,16 +712,6 @@ __device__ __forceinline__ StripPos strip_locate(const SlxKParams &p, unsigned i
     constexpr unsigned SPAN = HALO ? 62u : 64u;
     StripPos s;
     const unsigned lane = threadIdx.x & 63u;
-#if SLX_EXP & 32
-    // TIMING DIAGNOSTIC ONLY: consecutive groups of 60 items are dealt round-robin over 8 frame-sets (the launch must hold a multiple of 8):
-    // short items with the footprint of long ones
-    if (items_per_set % 60u == 0u && (gridDim.x * (blockDim.x >> 6)) % (8u * items_per_set) == 0u) {   // else: not a bijection, leave the order alone
-        const unsigned blk = item / 60u, within = item - blk * 60u;
-        const unsigned bps = items_per_set / 60u;                     // blocks per set (items_per_set a multiple of 60 in the diagnostic runs)
-        const unsigned oct = blk / (8u * bps), r8 = blk - oct * 8u * bps;
-        item = ((oct * 8u + (r8 & 7u)) * bps + (r8 >> 3)) * 60u + within;
-    }
-#endif
     s.set = item / items_per_set;
     const unsigned rem = item - s.set * items_per_set;
     const unsigned g = rem / p.chunks_per_group;
@@ -844,9 +838,6 @@ __global__ __launch_bounds__(256) void slx_strip_kernel(const SlxKParams p)
         for (int f = 1; f < F; f++) asm volatile("" : "+v"(kinvT[f]));
     }
 
-    constexpr bool ZERO_IN_LDS = (SLX_EXP & 2) && !MASKED && !AUX;
-    double kzero = 0.0;
-    asm volatile("" : "+v"(kzero));
     bool lane_valid;
     const StripPos pos = strip_locate<MASKED>(p, item, items_per_set, RB, region_row0, lane_valid);
     const size_t pset = (size_t)pos.set * p.phase_set_stride;
@@ -863,7 +854,11 @@ __global__ __launch_bounds__(256) void slx_strip_kernel(const SlxKParams p)
     // Plane offsets are running scalars: first + k * step, advanced by one s_add per load (the asm keeps hipcc from turning
     // them back into one hoisted register per plane: 24 SGPRs in the Gray modes, which spilled into VGPR lanes and came back
     // through v_readlane every row).
-    const unsigned gray_first = GB > 0 ? p.gray_first + (unsigned)((long long)pos.set * p.gray_set_delta) : 0u;
+    // The Gray planes that ride the ring have a descriptor of their own (base = Gray plane 0 of this frame-set): the two plane groups
+    // may then live anywhere in memory -- separate allocations more than 2 GiB apart included (round 4: bench.py's REF launch fell back
+    // to ordinary Gray loads, 200 against 166 us, when the allocator happened to place its two tensors that far apart).
+    const __amdgpu_buffer_rsrc_t grsrc =
+        GB > 0 ? __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(p.gray[0] + gset), 0, 0xFFFFFFFFu, 0x00020000) : rsrc;
     auto next_plane = [](unsigned &so, unsigned step) { asm volatile("s_add_u32 %0, %0, %1" : "+s"(so) : "s"(step) : "scc"); };
     auto issue_chunk = [&](unsigned slot, int cc) {                    // DMA of the item's next chunk (chunk cc of its row) into ring[slot]
         const unsigned voff = dma_off < dma_last ? dma_off : dma_last;
@@ -876,16 +871,16 @@ __global__ __launch_bounds__(256) void slx_strip_kernel(const SlxKParams p)
         // address as well: with the immediate stepping through the chunk's planes in LDS (256 k) and 256 taken off the running
         // global offset per plane, M0 is written once per chunk instead of once per load (dma_imm: planes >= 256 bytes apart).
         if (GRAY_CHUNK && cc == 1) {
-            unsigned so = gray_first;
+            unsigned so = 0u;
             if (p.dma_imm) {
                 static_for<NGR>([&](auto k) {
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void *)dst, 4, voff, so, decltype(k)::value * 256, POLICY);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(grsrc, (lds_void *)dst, 4, voff, so, decltype(k)::value * 256, POLICY);
                     if (decltype(k)::value + 1 < NGR) next_plane(so, p.gray_step - 256u);
                 });
             } else {
 #pragma unroll
                 for (int k = 0; k < NGR; k++) {
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void *)(dst + k * 64), 4, voff, so, 0, POLICY);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(grsrc, (lds_void *)(dst + k * 64), 4, voff, so, 0, POLICY);
                     if (k + 1 < NGR) next_plane(so, p.gray_step);
                 }
             }
@@ -1027,25 +1022,13 @@ __global__ __launch_bounds__(256) void slx_strip_kernel(const SlxKParams p)
                 }
 #pragma unroll
                 for (int f = 0; f < ((NS == 4 && c == 0) ? F : 0); f++) {
-                    const f32x2 kUp = {0x1p126f, 0x1p126f};
-#if SLX_EXP & 1
-                    // every byte of the quad arrives as its own zero-extended dword (ds_read_u8: the LDS pipe does the byte select), i.e. as
-                    // the denormal byte * 2^-149; a pixel pair's difference is then ONE packed subtraction
-                    typedef __attribute__((address_space(3))) const volatile uint8_t lds_u8;   // volatile: hipcc would merge the four loads of a dword back into one
-                    lds_u8 *sb = (lds_u8 *)(src);
-                    auto den = [&](int plane, int j) { return __builtin_bit_cast(float, (uint32_t)sb[((f * 4 + plane) * 64) * 4 + j]); };
-                    auto pair = [&](int plane, int j) { return f32x2{den(plane, j), den(plane, j + 1)}; };
-                    const F32x2x2 px = wrapped_pix_from_diffs<true>(
-                        F32x2x2{(pair(0, 0) - pair(2, 0)) * kUp, (pair(0, 2) - pair(2, 2)) * kUp},
-                        F32x2x2{(pair(1, 0) - pair(3, 0)) * kUp, (pair(1, 2) - pair(3, 2)) * kUp}, Tf[f]);
-#else
                     const uint32_t w0 = src[(f * 4 + 0) * 64], w1 = src[(f * 4 + 1) * 64];
                     const uint32_t w2 = src[(f * 4 + 2) * 64], w3 = src[(f * 4 + 3) * 64];
                     // differences as denormals (x 2^-149), rescaled to x 2^-23 by one packed multiply per pair
+                    const f32x2 kUp = {0x1p126f, 0x1p126f};
                     const F32x2x2 px = wrapped_pix_from_diffs<true>(
                         F32x2x2{f32x2{byte_diff_denorm<0>(w0, w2), byte_diff_denorm<1>(w0, w2)} * kUp, f32x2{byte_diff_denorm<2>(w0, w2), byte_diff_denorm<3>(w0, w2)} * kUp},
                         F32x2x2{f32x2{byte_diff_denorm<0>(w1, w3), byte_diff_denorm<1>(w1, w3)} * kUp, f32x2{byte_diff_denorm<2>(w1, w3), byte_diff_denorm<3>(w1, w3)} * kUp}, Tf[f]);
-#endif
                     pix[f][0] = px.a.x;
                     pix[f][1] = px.a.y;
                     pix[f][2] = px.b.x;
@@ -1071,7 +1054,6 @@ __global__ __launch_bounds__(256) void slx_strip_kernel(const SlxKParams p)
 #pragma unroll
                 for (int j = 0; j < SLX_QUAD; j++) kf[f][j] = 0;
         }
-        bool dropq[SLX_QUAD] = {false, false, false, false};
         int v0[SLX_QUAD] = {1, 1, 1, 1};                                // x3: lanes without pixels never veto
         int okq[SLX_QUAD] = {1, 1, 1, 1};                               // the mask plane: 1 outside the Gray-mask mode
         if (row < H) {
@@ -1176,8 +1158,7 @@ __global__ __launch_bounds__(256) void slx_strip_kernel(const SlxKParams p)
 #if SLX_EXP & 4
                     z[j] = U[j] + cC;          // TIMING DIAGNOSTIC ONLY (wrong results): no triangulation
 #else
-                    if constexpr (ZERO_IN_LDS) z[j] = tri_depth<true, true>(U[j], cC, cD, kcA, kcB, kfmin, kfmax, true, &dropq[j]);
-                    else z[j] = tri_depth<true>(U[j], cC, cD, kcA, kcB, kfmin, kfmax, true);
+                    z[j] = tri_depth<true>(U[j], cC, cD, kcA, kcB, kfmin, kfmax, true);
 #endif
                 }
             }
@@ -1186,14 +1167,6 @@ __global__ __launch_bounds__(256) void slx_strip_kernel(const SlxKParams p)
                 // tile stage nothing and are never stored.
                 stage[2 * lane + 0] = vec2{z[0], z[1]};
                 stage[2 * lane + 1] = vec2{z[2], z[3]};
-                if constexpr (ZERO_IN_LDS) {
-                    // a dropped depth is overwritten with 0.0 in the staging area by the lanes that drop it: an exec-masked ds_write_b64
-                    // (scalar mask + LDS pipe) instead of two v_cndmask per pixel; a wave's LDS operations execute in order
-                    const unsigned sa = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)(stage + 2 * lane);
-#pragma unroll
-                    for (int j = 0; j < SLX_QUAD; j++)
-                        if (dropq[j]) asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(sa), "v"(kzero), "n"(8 * j) : "memory");
-                }
             }
         }
         if constexpr (MASKED) {
@@ -1263,6 +1236,147 @@ __global__ __launch_bounds__(256) void slx_strip_kernel(const SlxKParams p)
         p.stamps[4 * item_id + 1] = __builtin_amdgcn_s_memtime();
         p.stamps[4 * item_id + 3] = __builtin_amdgcn_s_memrealtime();
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// The reference's decoder objects on the strip path: what CDecodePhase::Decode (R/CDecodePhase.cpp:83-96 -> CountResult :48-80:
+// four 8-bit planes in, the wrapped phase in projector pixels out as CV_64FC1) and CDecodeGray::Decode (R/CDecodeGray.cpp:108-139
+// -> Grey2Bin :150-176, CountResult :179-204: 2 G planes in, the stripe's left edge out as CV_64FC1) compute, for a host loop that
+// keeps the reference's two-decoder structure instead of the fused call.  Same work items, same
+// HBM -> LDS DMA ring (one chunk = a row of the decoder's planes, two chunks ahead, counted waits), same staged lane-contiguous
+// nontemporal stores as slx_strip_kernel above; the arithmetic is that kernel's wrapped_pix_from_diffs / SWAR Gray pack.
+//   MODE = SLX_MODE_PHASE_ONLY: 4 planes (the reference's 4 steps), 4 + 8 = 12 B/px
+//   MODE = SLX_MODE_GRAY_ONLY:  12 planes (6 bits: the reference's count), reflected-code table, 12 + 8 = 20 B/px
+// Everything else (other step / bit counts, a table that is not the reflected code, ragged widths, unequally spaced planes) stays
+// with slx_fused_kernel (slx_strip_eligible).
+template <int MODE>
+__global__ __launch_bounds__(256) void slx_decoder_strip_kernel(const SlxKParams p)
+{
+    constexpr bool PHASE = MODE == SLX_MODE_PHASE_ONLY;
+    constexpr int GB = 6;
+    constexpr int NP = PHASE ? 4 : 2 * GB;          // planes of a row = one ring chunk
+    constexpr unsigned ROW_DW = NP * 64;            // one ring slot in LDS, dwords per wave
+    constexpr int NZ = 2;                           // stores per row
+    typedef double vec2 __attribute__((ext_vector_type(2)));
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) void lds_void;
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds_raw[];
+    const unsigned t = threadIdx.x;
+    const unsigned lane = t & 63u;
+    const unsigned wave_in_wg = __builtin_amdgcn_readfirstlane(t >> 6);
+    uint32_t *ring = lds_raw + wave_in_wg * (2u * ROW_DW + 512u);
+    vec2 *stage = reinterpret_cast<vec2 *>(ring + 2u * ROW_DW);
+    // tiers of items, as in slx_strip_kernel
+    unsigned wg = blockIdx.x;
+    unsigned RB = p.tier_rows[0], items_per_set = p.tier_items_per_set[0], region_row0 = 0, tier_items = p.tier_items[0];
+#pragma unroll
+    for (int tr = 1; tr < SLX_MAX_TIERS; tr++) {
+        if (tr < (int)p.n_tiers && blockIdx.x >= p.tier_first_wg[tr]) {
+            wg = blockIdx.x - p.tier_first_wg[tr];
+            RB = p.tier_rows[tr];
+            items_per_set = p.tier_items_per_set[tr];
+            region_row0 = p.tier_row0[tr];
+            tier_items = p.tier_items[tr];
+        }
+    }
+    const unsigned item = wg * (blockDim.x >> 6) + wave_in_wg;
+    if (item >= tier_items) return;
+    const unsigned W = (unsigned)p.width, H = (unsigned)p.height;
+    const unsigned row_stride = (unsigned)p.row_stride;
+    const unsigned step_rows = p.interleave;
+    bool lane_valid;
+    const StripPos pos = strip_locate<false>(p, item, items_per_set, RB, region_row0, lane_valid);
+    // the plan puts the decoder's planes (phase or Gray) behind plane_base / phase_first / phase_step / phase_set_stride
+    const __amdgpu_buffer_rsrc_t rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(p.plane_base + (size_t)pos.set * p.phase_set_stride), 0, 0xFFFFFFFFu, 0x00020000);
+    const unsigned dma_step = step_rows * row_stride;
+    const unsigned dma_last = (H - 1u) * row_stride + pos.cq * SLX_QUAD;   // rows past the tile: harmless re-read of the last row
+    unsigned dma_off = pos.row * row_stride + pos.cq * SLX_QUAD;
+    auto next_plane = [](unsigned &so, unsigned step) { asm volatile("s_add_u32 %0, %0, %1" : "+s"(so) : "s"(step) : "scc"); };
+    auto issue_chunk = [&](unsigned slot) {
+        const unsigned voff = dma_off < dma_last ? dma_off : dma_last;
+        dma_off += dma_step;
+        uint32_t *dst = ring + slot * ROW_DW;
+        unsigned so = p.phase_first;
+        if (p.dma_imm) {
+            static_for<NP>([&](auto k) {
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void *)dst, 4, voff, so, decltype(k)::value * 256, 2 /* nt */);
+                if (decltype(k)::value + 1 < NP) next_plane(so, p.phase_step - 256u);
+            });
+        } else {
+#pragma unroll
+            for (int k = 0; k < NP; k++) {
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void *)(dst + k * 64), 4, voff, so, 0, 2 /* nt */);
+                if (k + 1 < NP) next_plane(so, p.phase_step);
+            }
+        }
+    };
+    double *oset = (PHASE ? p.pix : p.gray_out) + (size_t)pos.set * p.out_set_stride;
+    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(oset, 0, H * W * 8u, 0x00020000);
+    unsigned out_boff[2], out_bstep[2];
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        const bool ok = pos.out_row[k] != 0xFFFFFFFFu;
+        out_boff[k] = ok ? pos.out_off[k] * 8u : 0xFFFFFFF0u;
+        out_bstep[k] = ok ? step_rows * W * 8u : 0u;
+    }
+    auto flush_row = [&]() {
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const u32x4 v = *reinterpret_cast<const u32x4 *>(stage + k * 64 + lane);
+            __builtin_amdgcn_raw_buffer_store_b128(v, orsrc, out_boff[k], 0, 2 /* nt */);
+            out_boff[k] += out_bstep[k];
+        }
+    };
+    const float Tf = (float)p.period[0];
+    const double Sd = (double)p.gray_stripe;
+
+    issue_chunk(0);
+    if (RB > 1) issue_chunk(1);
+    for (unsigned i = 0; i < RB; i++) {
+        const unsigned row = pos.row + i * step_rows;
+        const unsigned slot = i & 1u;
+        // counted waits (vmcnt retires in issue order, loads and stores alike): L(i) | Z(i-2) L(i+1) | wait -- see slx_strip_kernel
+        if (i + 1 >= RB) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (i >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP + NZ) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP) : "memory");
+        if (i > 0) flush_row();                                         // last row's stores, one step late
+        uint32_t w[NP];
+        if (row < H) {
+            const uint32_t *src = ring + slot * ROW_DW + lane;
+#pragma unroll
+            for (int k = 0; k < NP; k++) w[k] = src[k * 64];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the slot is free once it has been read
+        }
+        if (i + 2 < RB) issue_chunk(slot);
+        if (row < H) {
+            double o[SLX_QUAD];
+            if constexpr (PHASE) {
+                // a1 + a2: R/CDecodePhase.cpp:59-75, the quad's two pixel pairs in lockstep (wrapped_pix_from_diffs)
+                const f32x2 kUp = {0x1p126f, 0x1p126f};
+                const F32x2x2 px = wrapped_pix_from_diffs<true>(
+                    F32x2x2{f32x2{byte_diff_denorm<0>(w[0], w[2]), byte_diff_denorm<1>(w[0], w[2])} * kUp, f32x2{byte_diff_denorm<2>(w[0], w[2]), byte_diff_denorm<3>(w[0], w[2])} * kUp},
+                    F32x2x2{f32x2{byte_diff_denorm<0>(w[1], w[3]), byte_diff_denorm<1>(w[1], w[3])} * kUp, f32x2{byte_diff_denorm<2>(w[1], w[3]), byte_diff_denorm<3>(w[1], w[3])} * kUp}, Tf);
+                o[0] = (double)px.a.x;                                  // R/CDecodePhase.cpp:75
+                o[1] = (double)px.a.y;
+                o[2] = (double)px.b.x;
+                o[3] = (double)px.b.y;
+            } else {
+                // a3 + a4: bit = pattern > inverse (ties -> 0), pair 0 = LSB, lut[gray] = bin (the reflected code's inverse), x stripe
+                uint32_t acc = 0u;
+#pragma unroll
+                for (int b = 0; b < GB; b++) acc = swar_push_bit7(acc, swar_ge_u8_bit7(w[2 * b + 1], w[2 * b]));
+                const uint32_t bin4 = swar_gray_to_binary_u8(swar_finish_code(acc, GB));
+#pragma unroll
+                for (int j = 0; j < SLX_QUAD; j++) o[j] = (double)(int)((bin4 >> (8 * j)) & 0xffu) * Sd;   // R/CDecodeGray.cpp:200
+            }
+            stage[2 * lane + 0] = vec2{o[0], o[1]};
+            stage[2 * lane + 1] = vec2{o[2], o[3]};
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    flush_row();
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1488,6 +1602,8 @@ int slx_launch_fused(const SlxKParams &kp_in, int mode, bool aux, int n_sets, in
     kernel_fn fn;
     if (!plan.strip) {
         fn = pick(mode, kp.n_freq, kp.n_steps == 4, aux);
+    } else if (mode == SLX_MODE_PHASE_ONLY || mode == SLX_MODE_GRAY_ONLY) {
+        fn = mode == SLX_MODE_PHASE_ONLY ? slx_decoder_strip_kernel<SLX_MODE_PHASE_ONLY> : slx_decoder_strip_kernel<SLX_MODE_GRAY_ONLY>;
     } else {
         const int gb = plan.gray_ring_bits;
         fn = mode == SLX_MODE_MULTIFREQ ? (kp.n_steps == 8 ? pick_strip<SLX_MODE_MULTIFREQ, 0, 8>(kp.n_freq, aux) : pick_strip<SLX_MODE_MULTIFREQ, 0>(kp.n_freq, aux))

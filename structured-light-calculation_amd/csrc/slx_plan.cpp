@@ -32,9 +32,37 @@ bool slx_fast_arith_ok(const SlxKParams &kp)
     return true;
 }
 
+// The planes one ring chunk of the strip kernels holds must be equally spaced, ascending, the last within 2 GiB of the first
+// (32-bit buffer offsets): the layout of a batch and of the context's staging slab; anything else takes the generic kernel.
+static bool planes_equally_spaced(const uint8_t *const *pl, int np)
+{
+    const uintptr_t a0 = reinterpret_cast<uintptr_t>(pl[0]);
+    const uintptr_t step = np > 1 ? reinterpret_cast<uintptr_t>(pl[1]) - a0 : 0;
+    if (np > 1 && reinterpret_cast<uintptr_t>(pl[1]) < a0) return false;
+    for (int k = 0; k < np; k++)
+        if (reinterpret_cast<uintptr_t>(pl[k]) != a0 + (uintptr_t)k * step) return false;
+    return (unsigned long long)step * (unsigned)(np > 1 ? np - 1 : 0) < (1ull << 31);
+}
+
+// The work-item geometry's 32-bit arithmetic (quads per row, plane offsets, output byte offsets with the rows past the tile).
+static bool strip_geometry_ok(const SlxKParams &kp)
+{
+    if (kp.quads_per_row == 0 || kp.quads_per_row > 1024) return false;
+    if ((unsigned long long)kp.row_stride * (unsigned)kp.height >= (1ull << 31)) return false;
+    return (unsigned long long)kp.width * ((unsigned)kp.height + 2048ull) < (1ull << 29);
+}
+
 bool slx_strip_eligible(const SlxKParams &kp, int mode, bool aux)
 {
     if (!kp.aligned) return false;
+    if (mode == SLX_MODE_PHASE_ONLY) {
+        // slx_decoder_strip_kernel: the reference's decoder, 4 steps (R/CDecodePhase.cpp:59-62), a period the f32 identities were swept for
+        return !aux && kp.pix && kp.n_freq == 1 && kp.n_steps == 4 && kp.period[0] <= (1 << 14) && strip_geometry_ok(kp) && planes_equally_spaced(kp.phase, 4);
+    }
+    if (mode == SLX_MODE_GRAY_ONLY) {
+        // 6 bits (the reference's count, R/StaticParameters.cpp:16) with the reflected-code table (R/Patterns/vGrayCode.txt)
+        return !aux && kp.gray_out && kp.gray_bits == 6 && kp.std_gray && strip_geometry_ok(kp) && planes_equally_spaced(kp.gray, 12);
+    }
     if (aux && (kp.pix || kp.gray_out)) return false;                // the per-frequency pix planes and the Gray plane come from the generic kernel only
     {
         // second-pass divisors (x = z uc / fu, y = z vc / fv) must sit well inside the double range for the unscaled division
@@ -50,22 +78,8 @@ bool slx_strip_eligible(const SlxKParams &kp, int mode, bool aux)
         if (!(r > 0.70f && r < 0.71f) || kp.wscale != 0.25f) return false;
     }
     if (mode != SLX_MODE_MULTIFREQ && mode != SLX_MODE_GRAY_PHASE && mode != SLX_MODE_MULTIFREQ_GRAYMASK) return false;
-    if (kp.quads_per_row == 0 || kp.quads_per_row > 1024) return false;
     if (!slx_fast_arith_ok(kp)) return false;
-    if ((unsigned long long)kp.row_stride * (unsigned)kp.height >= (1ull << 31)) return false;   // 32-bit plane offsets
-    {
-        // the phase planes must be equally spaced, ascending, the last within 2 GiB of the first (32-bit buffer offsets):
-        // the layout of a batch and of the context's staging slab; anything else takes the generic kernel
-        const int np = kp.n_freq * kp.n_steps;
-        const uintptr_t a0 = reinterpret_cast<uintptr_t>(kp.phase[0]);
-        const uintptr_t step = np > 1 ? reinterpret_cast<uintptr_t>(kp.phase[1]) - a0 : 0;
-        if (np > 1 && reinterpret_cast<uintptr_t>(kp.phase[1]) < a0) return false;
-        for (int k = 0; k < np; k++)
-            if (reinterpret_cast<uintptr_t>(kp.phase[k]) != a0 + (uintptr_t)k * step) return false;
-        if ((unsigned long long)step * (unsigned)(np > 1 ? np - 1 : 0) >= (1ull << 31)) return false;
-    }
-    if ((unsigned long long)kp.width * ((unsigned)kp.height + 2048ull) >= (1ull << 29)) return false;   // 32-bit output byte offsets, rows past the tile included
-    return true;
+    return strip_geometry_ok(kp) && planes_equally_spaced(kp.phase, kp.n_freq * kp.n_steps);
 }
 
 // Waves per SIMD the register file allows a strip-kernel instantiation (512 VGPRs per lane and SIMD, allocated in blocks of 8):
@@ -76,6 +90,7 @@ bool slx_strip_eligible(const SlxKParams &kp, int mode, bool aux)
 // planes leaves the 128 that 4 waves per SIMD need.
 unsigned slx_strip_waves_per_simd(int mode, int n_freq, int gray_ring_bits, int n_steps, int aux)
 {
+    if (mode == SLX_MODE_PHASE_ONLY || mode == SLX_MODE_GRAY_ONLY) return 8;   // slx_decoder_strip_kernel: <= 64 VGPRs
     if (!aux) return 4;
     if (mode == SLX_MODE_MULTIFREQ) return n_freq >= 4 ? 3 : 4;
     if (mode == SLX_MODE_MULTIFREQ_GRAYMASK) return (gray_ring_bits ? n_freq >= 2 : n_freq >= 3) ? 3 : 4;
@@ -151,61 +166,57 @@ int slx_plan_launch(const SlxKParams &kp_in, int mode, bool aux, int n_sets, int
     }
     SlxKParams &kp = plan->kp;
     kp = kp_in;
-    kp.plane_base = kp.phase[0];                                     // equally spaced, ascending (slx_strip_eligible)
+    const bool decoder = mode == SLX_MODE_PHASE_ONLY || mode == SLX_MODE_GRAY_ONLY;      // slx_decoder_strip_kernel
+    if (mode == SLX_MODE_GRAY_ONLY) {
+        // the decoder kernel finds its planes behind the phase-plane fields whichever decoder it is
+        kp.plane_base = kp.gray[0];
+        kp.phase_step = (unsigned)(kp.gray[1] - kp.gray[0]);
+        kp.phase_set_stride = kp.gray_set_stride;
+    } else {
+        kp.plane_base = kp.phase[0];                                 // equally spaced, ascending (slx_strip_eligible)
+        kp.phase_step = kp.n_freq * kp.n_steps > 1 ? (unsigned)(kp.phase[1] - kp.phase[0]) : 0u;
+    }
     kp.phase_first = 0;
-    kp.phase_step = kp.n_freq * kp.n_steps > 1 ? (unsigned)(kp.phase[1] - kp.phase[0]) : 0u;
-    kp.gray_first = kp.gray_step = 0;
-    kp.dma_imm = (kp.n_freq * kp.n_steps == 1 || kp.phase_step >= 256u) ? 1 : 0;
+    kp.gray_step = 0;
+    kp.dma_imm = ((!decoder && kp.n_freq * kp.n_steps == 1) || kp.phase_step >= 256u) ? 1 : 0;
     // geometry: `interleave` rows end to end fill whole waves; an item is 64 quads x rows_per_lane rows
     const unsigned QR = kp.quads_per_row;
     unsigned g = QR, h = 64;
     while (h) { const unsigned r = g % h; g = h; h = r; }          // gcd(QR, 64)
     kp.interleave = 64u / g;
-    if (tn.weave > 1) {
-        // more rows per row group than whole waves need: the group's waves then sweep `interleave` consecutive rows in step
-        const unsigned m = std::min(64u, (unsigned)tn.weave) / kp.interleave;
+    // Weave: more rows per row group than whole waves need -- a lane's rows are then `interleave` apart and the waves of a group
+    // sweep that many consecutive rows in step.  Measured (tools/ab.py, round 4, two boxes): 8 rows instead of 2 on the 1920-wide
+    // 4-step kernels, config 4 282.9 -> 277.1 us (-2.0 %; the other box 290.1 -> 285.8), config 3 215.5 -> 209.9 (-2.6 %); 16 rows
+    // lose it again; the 1280-wide cases (one row = 5 whole chunks) lose 0.5-1.7 % with any weave and are left alone, 4096-wide
+    // 8-step within noise.  Only full frames: a row group of 8 x rows-per-item rows wastes too much of a short tile.
+    unsigned weave = 0;
+    if (tn.weave > 1) weave = (unsigned)tn.weave;
+    else if (tn.weave == 0 && !decoder && kp.interleave == 2 && kp.n_steps == 4 && kp.height >= 512) weave = 8;
+    if (weave > 1) {
+        const unsigned m = std::min(64u, weave) / kp.interleave;
         if (m > 1) kp.interleave *= m;
     }
     kp.chunks_per_group = mode == SLX_MODE_MULTIFREQ_GRAYMASK ? (kp.interleave * QR + 61u) / 62u   // 62 quads + 2 halo lanes per wave
                                                              : kp.interleave * QR / 64u;
     kp.plain_order = tn.plain_order ? 1 : 0;
-    // Gray planes ride the DMA ring when there are 6 bits of them (the reference's and config 3's count) and every
-    // plane, in every frame-set of the launch, sits within 2 GiB above the lowest plane; otherwise the kernel reads
-    // them with ordinary loads
+    // Gray planes ride the DMA ring when there are 6 bits of them (the reference's and config 3's count) and they are equally
+    // spaced, ascending, the last within 2 GiB of the first (the kernel addresses them through a descriptor of their own, based at
+    // Gray plane 0 of the frame-set: where the phase planes live does not matter); otherwise the kernel reads them with ordinary loads
     int gb = 0;
-    if (mode != SLX_MODE_MULTIFREQ && kp.gray_bits == 6 && !tn.gray_plain) {
+    if (!decoder && mode != SLX_MODE_MULTIFREQ && kp.gray_bits == 6 && !tn.gray_plain && planes_equally_spaced(kp.gray, 12)) {
         gb = 6;
-        // equally spaced, ascending, like the phase planes
-        const long long gstep = (long long)(kp.gray[1] - kp.gray[0]);
-        for (int k = 0; k < 12; k++)
-            if (gstep < 0 || kp.gray[k] != kp.gray[0] + (long long)k * gstep) gb = 0;
-        const uint8_t *lo = kp.gray[0] < kp.phase[0] ? kp.gray[0] : kp.phase[0];
-        const long long delta = (long long)kp.gray_set_stride - (long long)kp.phase_set_stride;
-        const long long g_first = (long long)(kp.gray[0] - lo), g_last = g_first + 11 * gstep;
-        const long long p_last = (long long)(kp.phase[0] - lo) + (long long)(kp.n_freq * 4 - 1) * kp.phase_step;
-        for (long long rel : {g_first, g_last}) {
-            const long long hi = rel + delta * (long long)(n_sets - 1);
-            if (rel >= (1ll << 31) || hi < 0 || hi >= (1ll << 31)) gb = 0;
-        }
-        if (p_last >= (1ll << 31) || gstep >= (1ll << 31)) gb = 0;
-        if (gb) {
-            kp.plane_base = lo;
-            kp.phase_first = (unsigned)(kp.phase[0] - lo);
-            kp.gray_first = (unsigned)g_first;
-            kp.gray_step = (unsigned)gstep;
-            kp.gray_set_delta = delta;
-            if (gstep < 256) kp.dma_imm = 0;
-        }
+        kp.gray_step = (unsigned)(kp.gray[1] - kp.gray[0]);
+        if (kp.gray_step < 256u) kp.dma_imm = 0;
     }
     // LDS per wave: 2 ring slots (max(4 n_freq, 2 gb) planes with 4 steps, 8 planes with 8 steps, 256 B each) + 2 KiB of depth staging
-    const unsigned ring_planes = kp.n_steps == 4 ? std::max((unsigned)kp.n_freq * 4u, 2u * (unsigned)gb) : 8u;
+    const unsigned ring_planes = mode == SLX_MODE_GRAY_ONLY ? 12u : kp.n_steps == 4 ? std::max((unsigned)kp.n_freq * 4u, 2u * (unsigned)gb) : 8u;
     const unsigned lds_wave = 2u * ring_planes * 256u + 2048u + (aux ? 2048u : 0u);      // + the optional planes' staging area
     // rows per item (slx_strip_rows_model): the kernel's preferred item for a launch that fills the chip many times over,
     // one round of items for a small one
     // resident waves per CU: what the LDS holds, and what the instantiation's registers allow (slx_strip_waves_per_simd)
     const unsigned waves_by_regs = 4u * slx_strip_waves_per_simd(mode, kp.n_freq, gb, kp.n_steps, aux ? 1 : 0);
     const unsigned slots_per_cu = std::min(waves_by_regs, 160u * 1024u / lds_wave);
-    const unsigned preferred = kp.n_steps == 8 ? 10u : gb ? 3u : 16u;
+    const unsigned preferred = decoder ? 3u : kp.n_steps == 8 ? 10u : gb ? 3u : 16u;   // the decoder kernels move bytes and little else: short items
     unsigned rb = slx_strip_rows_model((unsigned)kp.height, kp.interleave, kp.chunks_per_group, (unsigned)n_sets, slots_per_cu, preferred, kp.n_cus);
     // <= 32 rows: slx_strip_eligible bounds the 32-bit output offsets for interleave (<= 64) x 32 rows past the tile
     if (tn.strip_rows >= 1 && tn.strip_rows <= 32) rb = (unsigned)tn.strip_rows;

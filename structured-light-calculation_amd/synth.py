@@ -79,6 +79,12 @@ def make_spec(name):
     if name == "REF":       # R/StaticParameters.cpp:4-18
         s = base(1280, 1024, 1280, MODE_GRAY_PHASE, [1280 // (1 << 5)], gray_bits=6)
         return s
+    if name == "REFPHASE":  # the reference's phase decoder alone (CDecodePhase, R/CCalculation.cpp:546-559): 4 planes in, pix out
+        return base(1280, 1024, 1280, MODE_PHASE_ONLY, [1280 // (1 << 5)])
+    if name == "REFGRAY":   # the reference's Gray decoder alone (CDecodeGray, R/CCalculation.cpp:536-545): 12 planes in, stripe edge out
+        s = base(1280, 1024, 1280, MODE_GRAY_ONLY, [], gray_bits=6)
+        s["n_freq"], s["n_steps"] = 0, 4
+        return s
     if name == "C2":
         return base(1280, 720, 1280, MODE_MULTIFREQ, [1280, 160, 20])
     if name == "C3":

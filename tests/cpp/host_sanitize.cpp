@@ -200,6 +200,10 @@ static void check_plan(int w, int h, int n_sets, int mode, int F, int N, int G, 
     for (int i = 0; i < F * N; i++) kp.phase[i] = arena + (size_t)i * plane;
     for (int i = 0; i < 2 * G; i++) kp.gray[i] = arena + (size_t)(F * N + i) * plane;
     kp.phase_set_stride = kp.gray_set_stride = (size_t)(F * N + 2 * G) * plane;
+    static double out_arena[2];                                      // addresses only
+    if (mode == SLX_MODE_PHASE_ONLY) kp.pix = out_arena;             // the decoder modes write pix / gray, not z
+    if (mode == SLX_MODE_GRAY_ONLY) kp.gray_out = out_arena;
+    kp.std_gray = 1;
     for (int variant : {SLX_VARIANT_AUTO, SLX_VARIANT_GENERIC, SLX_VARIANT_STRIP}) {
         SlxLaunchPlan plan;
         const int rc = slx_plan_launch(kp, mode, aux, n_sets, variant, tn, &plan);
@@ -234,12 +238,13 @@ static void test_plans()
     const int shapes[][2] = {{1920, 1200}, {1280, 1024}, {1280, 720}, {640, 480}, {4096, 3000}, {4, 1}, {8, 1200}, {500, 5}, {1920, 150}, {1920, 37}, {4096, 130}, {64, 20}, {252, 3000}, {4092, 17}};
     for (const auto &s : shapes)
         for (int n_sets : {1, 2, 5, 32, 256, 4000})
-            for (int cfg = 0; cfg < 4; cfg++) {
-                const int mode = cfg == 0 ? SLX_MODE_MULTIFREQ : cfg == 1 ? SLX_MODE_GRAY_PHASE : cfg == 2 ? SLX_MODE_MULTIFREQ_GRAYMASK : SLX_MODE_MULTIFREQ;
-                const int F = cfg == 1 ? 1 : cfg == 3 ? 4 : 3, N = cfg == 3 ? 8 : 4, G = (cfg == 1 || cfg == 2) ? 6 : 0;
+            for (int cfg = 0; cfg < 6; cfg++) {
+                const int mode = cfg == 0 ? SLX_MODE_MULTIFREQ : cfg == 1 ? SLX_MODE_GRAY_PHASE : cfg == 2 ? SLX_MODE_MULTIFREQ_GRAYMASK : cfg == 3 ? SLX_MODE_MULTIFREQ
+                                 : cfg == 4 ? SLX_MODE_PHASE_ONLY : SLX_MODE_GRAY_ONLY;           // 4, 5: the decoder objects' strip kernel
+                const int F = cfg == 5 ? 0 : (cfg == 1 || cfg == 4) ? 1 : cfg == 3 ? 4 : 3, N = cfg == 3 ? 8 : 4, G = (cfg == 1 || cfg == 2 || cfg == 5) ? 6 : 0;
                 if ((unsigned long long)s[0] * s[1] * (unsigned)(F * N + 2 * G) * (unsigned)n_sets >= (1ull << 40)) continue;
                 check_plan(s[0], s[1], n_sets, mode, F, N, G, nullptr, false);
-                check_plan(s[0], s[1], n_sets, mode, F, N, G, nullptr, true);
+                if (cfg < 4) check_plan(s[0], s[1], n_sets, mode, F, N, G, nullptr, true);
                 for (int k = 0; k < 6; k++) {
                     SlxTuning tn;
                     std::memset(&tn, 0, sizeof tn);

@@ -117,6 +117,88 @@ def test_gray_only(api, oracle, synth, bits, width):
     assert np.array_equal(got, ref)
 
 
+def test_gray_and_phase_groups_far_apart_in_memory(api, oracle, synth, torch_cuda):
+    """The two plane groups of a batch are separate allocations and may sit anywhere: here more than 2 GiB apart, in either order
+    (the Gray planes ride the DMA ring through a descriptor of their own; round 3's single descriptor made such a launch fall back
+    to ordinary Gray loads).  REF and the Gray-mask mode, strip kernel, against the oracle."""
+    torch = torch_cuda
+    for name in ("REF", "C3"):
+        spec = small_spec(synth, name, 256, 40)
+        n_sets = 3
+        sets = [synth.random_planes(spec, seed=600 + s) for s in range(n_sets)]
+        refs = [oracle.pipeline(spec, p, g, want=("z",))["z"] for p, g in sets]
+        pnp, gnp = np.stack([p for p, _ in sets]), np.stack([g for _, g in sets])
+        for gray_first in (False, True):
+            # one 2.5 GiB buffer, one group at either end of it: the distance is certain, whatever the allocator does
+            arena = torch.empty(((5 << 29) + (1 << 24),), dtype=torch.uint8, device="cuda")
+            lo_np, hi_np = (gnp, pnp) if gray_first else (pnp, gnp)
+            lo = arena[: lo_np.size].view(lo_np.shape)
+            hi = arena[arena.numel() - (1 << 24): arena.numel() - (1 << 24) + hi_np.size].view(hi_np.shape)
+            lo.copy_(torch.from_numpy(lo_np))
+            hi.copy_(torch.from_numpy(hi_np))
+            ph, gr = (hi, lo) if gray_first else (lo, hi)
+            assert abs(ph.data_ptr() - gr.data_ptr()) > (1 << 31)
+            z = torch.full((n_sets, spec["height"], spec["width"]), -7.0, dtype=torch.float64, device="cuda")
+            torch.cuda.synchronize()
+            with api.Context(spec) as ctx:
+                ctx.set_variant(2)
+                ctx.decode_batch(n_sets, ph, gr, z)
+                ctx.synchronize()
+            for s in range(n_sets):
+                assert np.array_equal(z[s].cpu().numpy(), refs[s], equal_nan=True), (name, gray_first, s)
+            del arena, lo, hi, ph, gr
+
+
+@pytest.mark.parametrize("variant", [2, 1, 0])
+def test_decoder_objects_on_the_strip_path(api, oracle, synth, torch_cuda, variant):
+    """CDecodePhase::Decode and CDecodeGray::Decode alone (modes PHASE_ONLY / GRAY_ONLY) as batches through slx_decode_batch:
+    variant 2 must take slx_decoder_strip_kernel (DMA ring, 4 / 12 planes), variant 1 the generic kernel; every rows-per-item
+    choice, ragged heights, a pitch in the planes, unstructured bytes plus clean patterns and exact ties; against the oracle."""
+    torch = torch_cuda
+    rng = np.random.default_rng(1234)
+    for W, H, pitch in ((512, 71, 512), (1280, 33, 1344), (196, 129, 196)):
+        n_sets = 3
+        # phase decoder: all 511 x 511 difference pairs in the first rows, unstructured bytes below
+        pspec = {"width": W, "height": H, "mode": synth.MODE_PHASE_ONLY, "n_freq": 1, "n_steps": 4, "periods": [40]}
+        ph = rng.integers(0, 256, size=(n_sets, 4, H, W), dtype=np.uint8)
+        ex = exhaustive_planes(511)[:, : min(H, 511), : min(W, 511)]
+        ph[0, :, : ex.shape[1], : ex.shape[2]] = ex
+        gspec = {"width": W, "height": H, "mode": synth.MODE_GRAY_ONLY, "gray_bits": 6, "gray_stripe": 20, "gray_lut": synth.standard_gray_lut(6)}
+        gr = rng.integers(0, 256, size=(n_sets, 12, H, W), dtype=np.uint8)
+        gr[:, :, :, : W // 3] = np.where(gr[:, :, :, : W // 3] > 127, 220, 20)
+        gr[:, 1::2, :, : W // 6] = gr[:, 0::2, :, : W // 6]                    # exact ties: bit 0
+        for spec, planes, key in ((pspec, ph, "pix"), (gspec, gr, "gray")):
+            refs = [oracle.pipeline(spec, planes[s] if key == "pix" else None, planes[s] if key == "gray" else None, want=(key,))[key].reshape(H, W)
+                    for s in range(n_sets)]
+            dev = torch.zeros((n_sets, planes.shape[1], H, pitch), dtype=torch.uint8, device="cuda")
+            dev[..., :W] = torch.from_numpy(planes).cuda()
+            view = dev[..., :W]
+            for rows in (0, 1, 2, 3, 5, 16):
+                out = torch.full((n_sets, H, W), -7.0, dtype=torch.float64, device="cuda")
+                torch.cuda.synchronize()
+                with api.Context(spec) as ctx:
+                    ctx.set_variant(variant)
+                    ctx.set_tuning(strip_rows=rows)
+                    ctx.decode_batch(n_sets, view if key == "pix" else None, view if key == "gray" else None, out, row_stride=pitch)
+                    ctx.synchronize()
+                for s in range(n_sets):
+                    assert np.array_equal(out[s].cpu().numpy(), refs[s]), (W, H, key, variant, rows, s)
+    # what the strip variant refuses stays refused (and the automatic choice falls back to the generic kernel)
+    odd = {"width": 64, "height": 8, "mode": synth.MODE_GRAY_ONLY, "gray_bits": 5, "gray_stripe": 40, "gray_lut": synth.standard_gray_lut(5)}
+    g5 = torch.zeros((1, 10, 8, 64), dtype=torch.uint8, device="cuda")
+    o5 = torch.zeros((1, 8, 64), dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    with api.Context(odd) as ctx:
+        ctx.set_variant(variant)
+        if variant == 2:
+            with pytest.raises(api.SlxError) as e:
+                ctx.decode_batch(1, None, g5, o5)
+            assert e.value.code == api.ERR_UNAVAILABLE
+        else:
+            ctx.decode_batch(1, None, g5, o5)
+            ctx.synchronize()
+
+
 # ------------------------------------------------------------------ committed fixtures
 @pytest.mark.parametrize("name", ["C1x4", "C2", "C3", "C5"])
 def test_scene_fixtures(api, synth, golden_dir, name):
@@ -322,6 +404,56 @@ def test_eight_step_ring_depths(api, oracle, synth, torch_cuda, periods, rows):
         assert np.array_equal(z_only[s].cpu().numpy(), refs[s]["z"], equal_nan=True), (s, "z only")
         for n in want:
             assert np.array_equal(outs[n][s].cpu().numpy(), refs[s][n], equal_nan=True), (s, n)
+
+
+def test_eight_step_sine_cosine_near_ties(api, oracle, synth, torch_cuda):
+    """The 8-step fast path picks the octant with a saturating multiply, sat((|sy| - |sx|) 2^60): right as long as a non-zero
+    difference is at least 2^-60.  It is: every term of the two sums is a multiple of 2^-24 (an 8-bit value, or RN(g * r) >= 0.7), so
+    are the f32 sums, and after the 2/N scale any non-zero |sy| - |sx| is >= 2^-26.  This test sits on that edge: 8-tuples whose
+    sine and cosine sums are equal in exact arithmetic (|sy| = |sx|: the 45 / 135 / 225 / 315 degree directions) -- exactly equal in f32
+    when the odd steps are dark, and a few ulps apart when they are not (the two sums add the same terms in different orders) --
+    against the oracle's literal compare, through U (= pix for one frequency) and z."""
+    torch = torch_cuda
+    rng = np.random.default_rng(808)
+    W, H = 512, 96
+    n = W * H
+    g = rng.integers(0, 256, size=(8, n), dtype=np.int64)
+    fam = rng.integers(0, 4, size=n)
+    d = rng.integers(-255, 256, size=n)
+    def pair(diff):                              # two bytes a, b with a - b = diff
+        base = rng.integers(0, 256 - np.abs(diff))
+        return np.where(diff >= 0, base + diff, base), np.where(diff >= 0, base, base - diff)
+    # family 0: exact ties, odd steps dark: sy = g0 - g4 = D, sx = g2 - g6 = +-D
+    # family 1: sy = sx in exact arithmetic (g3 = g7, any g1, g5): near ties of equal sign
+    # family 2: sy = -sx in exact arithmetic (g1 = g5, any g3, g7)
+    # family 3: unstructured
+    sgn = np.where(rng.integers(0, 2, size=n) == 0, 1, -1)
+    a0, a4 = pair(d)
+    a2, a6 = pair(np.where(fam == 2, -d, np.where(fam == 0, sgn * d, d)))
+    for k, v in ((0, a0), (4, a4), (2, a2), (6, a6)):
+        g[k] = np.where(fam < 3, v, g[k])
+    g[1] = np.where(fam == 0, 0, g[1]); g[3] = np.where(fam == 0, 0, g[3]); g[5] = np.where(fam == 0, 0, g[5]); g[7] = np.where(fam == 0, 0, g[7])
+    g[7] = np.where(fam == 1, g[3], g[7])
+    g[5] = np.where(fam == 2, g[1], g[5])
+    planes = g.astype(np.uint8).reshape(8, H, W)
+    for T in (1920, 37):
+        spec = small_spec(synth, "C5", W, H)
+        spec["periods"], spec["n_freq"] = [T], 1
+        ref = oracle.pipeline(spec, planes, None, want=("z", "U"))
+        # the construction does what it says: a good share of the pixels decode to the diagonal directions' neighbourhood
+        frac = (ref["U"] - 0.5) / T
+        near_diag = np.minimum.reduce([np.abs(frac - q) for q in (0.125, 0.375, 0.625, 0.875)]) < 1e-3
+        assert near_diag.mean() > 0.5
+        ph = torch.from_numpy(planes[None]).cuda()
+        outs = {w: torch.full((1, H, W), -7.0, dtype=torch.float64, device="cuda") for w in ("z", "U")}
+        torch.cuda.synchronize()
+        for variant in (2, 1):                  # the strip kernel's 8-step path, and the generic kernel's literal arithmetic
+            with api.Context(spec) as ctx:
+                ctx.set_variant(variant)
+                ctx.decode_batch_ex(1, ph, None, **outs)
+                ctx.synchronize()
+            for w in ("z", "U"):
+                assert np.array_equal(outs[w][0].cpu().numpy(), ref[w], equal_nan=True), (T, variant, w)
 
 
 @pytest.mark.parametrize("name", ["C1x4", "C2", "C3", "C5"])
@@ -1060,6 +1192,41 @@ def test_decode_batch_ex_writes_row_tiles_into_a_full_height_map(api, oracle, sy
             assert np.array_equal(full[n][s].cpu().numpy(), ref[s][n], equal_nan=True), (s, n)
         assert np.array_equal(kfull[s].cpu().numpy(), ref[s]["k"]), s
         assert np.array_equal(mfull[s].cpu().numpy(), ref[s]["mask"]), s
+
+
+def test_north_star_row_tiles_at_full_size_against_the_oracle(api, oracle, synth, shard, torch_cuda):
+    """BASELINE configuration 4 as north_star cuts it, at its real size: the eight 1920 x 150 row tiles (row_offset 0, 150 ... 1050)
+    of 1920 x 1200 frame-sets.  (a) one frame-set, tile by tile through the single-set call: z and y of the eight tiles concatenate
+    to the oracle's full maps; (b) a batch of 4 frame-sets, every "rank" decoding its tile of all of them in ONE launch of
+    slx_decode_batch_ex straight into [set][1200][1920] (plane_stride = 1200 * 1920, what the gather's destination rank does):
+    the assembled array equals the oracle's, set by set.  Tolerance: bit-equal (contract: 1e-4 mm RMS)."""
+    torch = torch_cuda
+    spec = synth.make_spec("C4")
+    H, W, world = spec["height"], spec["width"], 8
+    assert (W, H) == (1920, 1200)
+    scenes = [synth.render(spec, "sphere", seed=91, noise_sigma=2.0)[0]] + [synth.random_planes(spec, seed=92 + s)[0] for s in range(3)]
+    refs = [oracle.pipeline(spec, ph, None, want=("z", "y"), threads=8) for ph in scenes]
+    # (a) the tiles of frame-set 0, one call each
+    parts = []
+    for rank in range(world):
+        tile, lo, hi = shard.row_tile_spec(spec, world, rank)
+        assert (tile["height"], tile["row_offset"], lo, hi) == (150, 150 * rank, 150 * rank, 150 * rank + 150)
+        parts.append(api.decode_frameset(tile, scenes[0][:, lo:hi], None, want=("z", "y")))
+    for w in ("z", "y"):
+        assert np.array_equal(np.concatenate([p[w] for p in parts]), refs[0][w], equal_nan=True), w
+    # (b) 4 frame-sets, each rank's tile of all of them in one launch, in place in the full-height maps
+    n_sets = len(scenes)
+    full = {w: torch.full((n_sets, H, W), -7.0, dtype=torch.float64, device="cuda") for w in ("z", "y")}
+    for rank in range(world):
+        tile, lo, hi = shard.row_tile_spec(spec, world, rank)
+        ph = torch.from_numpy(np.stack([sc[:, lo:hi] for sc in scenes])).cuda()
+        torch.cuda.synchronize()              # the context's stream does not order itself against torch's stream
+        with api.Context(tile) as ctx:
+            ctx.decode_batch_ex(n_sets, ph, None, z=full["z"][0, lo:], y=full["y"][0, lo:], plane_stride=H * W)
+            ctx.synchronize()
+    for s in range(n_sets):
+        for w in ("z", "y"):
+            assert np.array_equal(full[w][s].cpu().numpy(), refs[s][w], equal_nan=True), (s, w)
 
 
 @pytest.mark.parametrize("split", ["framesets", "rows"])

@@ -41,6 +41,15 @@ def kernels(tmp_path_factory):
         found[key] = {f: int(re.search(r"\.%s:\s+(\d+)" % f, blk).group(1))
                       for f in ("vgpr_count", "vgpr_spill_count", "sgpr_spill_count", "private_segment_fixed_size", "group_segment_fixed_size")}
     assert len(found) >= 36, "expected every strip-kernel instantiation in the assembly, found %d" % len(found)
+    # the decoder objects' kernels (modes 0 and 1): keyed like the others, with the counts their launch plan uses
+    for blk in re.split(r"\n  - \.agpr_count:", meta):
+        m = re.search(r"\.name:\s+\S*slx_decoder_strip_kernelILi(\d)E", blk)
+        if m:
+            mode = int(m.group(1))
+            found[(mode, 1 if mode == 0 else 0, 0, 4, 0)] = {f: int(re.search(r"\.%s:\s+(\d+)" % f, blk).group(1))
+                                                             for f in ("vgpr_count", "vgpr_spill_count", "sgpr_spill_count", "private_segment_fixed_size",
+                                                                       "group_segment_fixed_size")}
+    assert (0, 1, 0, 4, 0) in found and (1, 0, 0, 4, 0) in found
     return found
 
 
@@ -57,7 +66,7 @@ def test_strip_kernels_use_only_dynamic_lds(kernels):
 def test_kernels_without_optional_planes_fit_four_waves_per_simd(kernels):
     """512 VGPRs per SIMD lane: 4 waves need <= 128 each.  Every instantiation the headline configurations use (no x / y / U / k planes)
     must stay there: the LDS ring is sized for 16 waves per CU."""
-    over = {k: v["vgpr_count"] for k, v in kernels.items() if k[4] == 0 and v["vgpr_count"] > 128}
+    over = {k: v["vgpr_count"] for k, v in kernels.items() if k[4] == 0 and v["vgpr_count"] > (64 if k[0] in (0, 1) else 128)}
     assert not over, over
 
 
@@ -78,4 +87,5 @@ def test_planner_occupancy_matches_compiled_register_counts(kernels):
         allowed = min(8, 512 // alloc)
         claimed = lib.slx_strip_waves_per_simd(mode, F, GB, NS, AUX)
         assert claimed <= allowed, ((mode, F, GB, NS, AUX), v["vgpr_count"], claimed, allowed)
-        assert claimed == min(4, allowed), ((mode, F, GB, NS, AUX), v["vgpr_count"], claimed, allowed)
+        # the decode kernels are planned for 4 waves per SIMD (their LDS ring allows no more), the decoder kernels (modes 0, 1) for 8
+        assert claimed == min(8 if mode in (0, 1) else 4, allowed), ((mode, F, GB, NS, AUX), v["vgpr_count"], claimed, allowed)
