@@ -218,6 +218,28 @@ int slx_track_next(slx_ctx *ctx, const uint8_t *image, size_t stride_bytes, int 
  * slx_track_* call and belongs to the context. */
 int slx_track_image_buffer(slx_ctx *ctx, uint8_t **buffer, size_t *stride_bytes);
 
+/* k dynamic frames per transfer.  The reference holds all of a run's dynaCam images in memory before it walks them
+ * (CSensor::LoadDatas, R/CSensorV.cpp:60-133; the loop R/CCalculation.cpp:222-317), and the strips of frame fN depend on image fN
+ * alone -- so k images can ride ONE host-to-device transfer instead of k (each single-image transfer pays its own hand-off to the
+ * kernel that waits for it).  Images: n_frames x height x width bytes, rows stride_bytes apart, images image_stride_bytes apart.
+ *  slx_track_next_batch   = n_frames x slx_track_next: one transfer (host images), then one launch per frame back to back on
+ *                           the context's stream.  Afterwards the context's outputs are those of the LAST frame, exactly as after
+ *                           n_frames calls of slx_track_next; deltaz_all (n_frames x height x width f64 in device or host memory,
+ *                           deltaz_mem_kind; or NULL) receives every frame's deltaZ plane -- asynchronously on the context's
+ *                           stream for a device buffer, complete on return for a host one.
+ *  slx_track_stage_frames = only the transfer: the images land in a device slab of the context (*device_images, width bytes per row,
+ *                           height x width per image), for a loop that needs every frame's outputs (CCalculation::CalculateOther
+ *                           writes a point cloud per frame): slx_track_next(ctx, *device_images + f * height * width, width,
+ *                           SLX_MEM_DEVICE) per frame.  The slab stays valid until the second staging call after this one.
+ *  slx_track_frames_buffer= the pinned slab the NEXT staging call (or host-fed batch) of up to n_frames images copies from, for a
+ *                           producer that can write there directly (passing it back skips the library's own copy). */
+#define SLX_TRACK_MAX_BATCH 256
+int slx_track_next_batch(slx_ctx *ctx, const uint8_t *images, size_t stride_bytes, size_t image_stride_bytes, int n_frames, int mem_kind,
+                         double *deltaz_all, int deltaz_mem_kind);
+int slx_track_stage_frames(slx_ctx *ctx, const uint8_t *images, size_t stride_bytes, size_t image_stride_bytes, int n_frames,
+                           const uint8_t **device_images);
+int slx_track_frames_buffer(slx_ctx *ctx, int n_frames, uint8_t **buffer, size_t *stride_bytes, size_t *image_stride_bytes);
+
 /* Device pointer of an output buffer owned by the context (valid until slx_destroy). */
 int slx_output_device_ptr(slx_ctx *ctx, int which, void **ptr);
 

@@ -29,7 +29,7 @@ OUT_NAMES = {"z": OUT_Z, "x": OUT_X, "y": OUT_Y, "U": OUT_U, "pix": OUT_PIX, "gr
 SYMBOLS = [
     "slx_validate_config", "slx_create", "slx_destroy", "slx_last_error", "slx_set_gray_lut",
     "slx_set_frame", "slx_decode", "slx_decode_batch", "slx_synchronize", "slx_get_stream", "slx_get_output",
-    "slx_get_depth", "slx_get_point_cloud", "slx_point_cloud_of_depth", "slx_track_begin", "slx_track_next", "slx_track_image_buffer", "slx_output_device_ptr", "slx_get_calibration", "slx_enable_timing",
+    "slx_get_depth", "slx_get_point_cloud", "slx_point_cloud_of_depth", "slx_track_begin", "slx_track_next", "slx_track_image_buffer", "slx_track_next_batch", "slx_track_stage_frames", "slx_track_frames_buffer", "slx_output_device_ptr", "slx_get_calibration", "slx_enable_timing",
     "slx_last_decode_ms", "slx_debug_stamps", "slx_set_variant", "slx_set_tuning", "slx_read_bmp_gray", "slx_read_pgm_gray", "slx_read_calibration_yaml", "slx_version",
     "slx_decode_batch_ex", "slx_comm_unique_id", "slx_comm_create", "slx_comm_adopt", "slx_comm_destroy", "slx_comm_info", "slx_comm_last_error",
     "slx_comm_synchronize", "slx_gather_depth", "slx_decode_gather", "slx_gather_plan",
@@ -125,6 +125,9 @@ def lib():
         L.slx_point_cloud_of_depth.argtypes = [vp, vp, vp, sz, C.POINTER(sz), C.c_int]
         L.slx_track_begin.argtypes = [vp, vp, sz, C.c_int, C.c_int]
         L.slx_track_next.argtypes = [vp, vp, sz, C.c_int]
+        L.slx_track_next_batch.argtypes = [vp, vp, sz, sz, C.c_int, C.c_int, vp, C.c_int]
+        L.slx_track_stage_frames.argtypes = [vp, vp, sz, sz, C.c_int, C.POINTER(vp)]
+        L.slx_track_frames_buffer.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(sz), C.POINTER(sz)]
         L.slx_track_image_buffer.argtypes = [vp, C.POINTER(vp), C.POINTER(sz)]
         L.slx_output_device_ptr.argtypes = [vp, C.c_int, C.POINTER(vp)]
         L.slx_get_calibration.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]
@@ -373,6 +376,50 @@ class Context:
         """One dynamic frame: strips, deltaP, U, z (x, y), deltaZ are updated in place."""
         ptr, stride, kind = self._image_args(image)
         self._check(lib().slx_track_next(self._h, ptr, stride, kind))
+
+    def _images_args(self, images):
+        if isinstance(images, np.ndarray):
+            assert images.dtype == np.uint8 and images.ndim == 3 and (images.strides[2] == 1 or images.size == 0)
+            return images.ctypes.data, max(images.strides[1], images.shape[2]), images.strides[0], images.shape[0], MEM_HOST
+        assert images.is_cuda and images.dim() == 3 and images.stride(2) == 1
+        self._borrowed.append(images)
+        return images.data_ptr(), images.stride(1), images.stride(0), images.shape[0], MEM_DEVICE
+
+    def track_next_batch(self, images, deltaz_all=None):
+        """k dynamic frames in one call (slx_track_next_batch): images uint8 [k, H, W] (numpy: one transfer; CUDA tensor: borrowed);
+        deltaz_all: CUDA or numpy float64 [k, H, W] receiving every frame's deltaZ, or None."""
+        ptr, stride, istride, k, kind = self._images_args(images)
+        dz, dz_kind = None, MEM_DEVICE
+        if deltaz_all is not None:
+            assert tuple(deltaz_all.shape) == (k, self.spec["height"], self.spec["width"])
+            if isinstance(deltaz_all, np.ndarray):
+                assert deltaz_all.dtype == np.float64 and deltaz_all.flags.c_contiguous
+                dz, dz_kind = deltaz_all.ctypes.data, MEM_HOST
+            else:
+                assert deltaz_all.is_cuda and deltaz_all.is_contiguous()
+                dz = deltaz_all.data_ptr()
+        self._check(lib().slx_track_next_batch(self._h, ptr, stride, istride, k, kind, dz, dz_kind))
+
+    def track_stage_frames(self, images):
+        """One transfer of k host images (numpy uint8 [k, H, W]) into a device slab of the context; returns its device address
+        (image f at + f * H * W, W bytes per row) for track_next_device."""
+        ptr, stride, istride, k, kind = self._images_args(images)
+        assert kind == MEM_HOST
+        dev = C.c_void_p()
+        self._check(lib().slx_track_stage_frames(self._h, ptr, stride, istride, k, C.byref(dev)))
+        return dev.value
+
+    def track_next_device(self, address, stride=None):
+        """slx_track_next on an image in device memory given by its address (e.g. inside the slab of track_stage_frames)."""
+        self._check(lib().slx_track_next(self._h, address, self.spec["width"] if stride is None else stride, MEM_DEVICE))
+
+    def track_frames_buffer(self, k):
+        """The pinned slab the next staging call / host-fed batch of up to k images copies from, as a numpy uint8 [k, H, W] view."""
+        p, stride, istride = C.c_void_p(), C.c_size_t(), C.c_size_t()
+        self._check(lib().slx_track_frames_buffer(self._h, int(k), C.byref(p), C.byref(stride), C.byref(istride)))
+        H, W = self.spec["height"], self.spec["width"]
+        assert stride.value == W and istride.value == H * W
+        return np.ctypeslib.as_array((C.c_uint8 * (k * H * W)).from_address(p.value)).reshape(k, H, W)
 
     def get_calibration(self):
         P = (C.c_double * 12)()

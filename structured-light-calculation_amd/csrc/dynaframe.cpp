@@ -342,6 +342,33 @@ bool CCalculation::CalculateOtherFrame(int fN, const Image8 &dynaCam)
     return true;
 }
 
+bool CCalculation::CalculateOtherFrames(int fN0, const Image8 *dynaCams, int n, std::vector<double> *deltaZ)
+{
+    if (!m_ctx || !m_done || fN0 != m_frame + 1 || !dynaCams || n < 1 || n > SLX_TRACK_MAX_BATCH) return false;
+    const size_t hw = (size_t)m_sp.CAMERA_RESROW * (size_t)m_sp.CAMERA_RESLINE;
+    for (int f = 0; f < n; f++)
+        if (dynaCams[f].empty() || dynaCams[f].rows != m_sp.CAMERA_RESROW || dynaCams[f].cols != m_sp.CAMERA_RESLINE || dynaCams[f].on_device) {
+            m_err = "an image is empty, on the device or has the wrong size";
+            return false;
+        }
+    // the images go into the context's pinned slab (the one deep copy the reference's GetCamPicture makes), then one transfer
+    uint8_t *slab = nullptr;
+    size_t stride = 0, istride = 0;
+    if (slx_track_frames_buffer(m_ctx, n, &slab, &stride, &istride) != SLX_OK) {
+        m_err = slx_last_error(m_ctx);
+        return false;
+    }
+    for (int f = 0; f < n; f++)
+        for (int r = 0; r < dynaCams[f].rows; r++)
+            std::memcpy(slab + (size_t)f * istride + (size_t)r * stride, dynaCams[f].data + (size_t)r * dynaCams[f].step, (size_t)dynaCams[f].cols);
+    if (deltaZ) deltaZ->resize((size_t)n * hw);
+    const bool ok = slx_track_next_batch(m_ctx, slab, stride, istride, n, SLX_MEM_HOST, deltaZ ? deltaZ->data() : nullptr, SLX_MEM_HOST) == SLX_OK &&
+                    slx_synchronize(m_ctx) == SLX_OK;
+    if (!ok) m_err = slx_last_error(m_ctx);
+    if (ok) m_frame = fN0 + n - 1;
+    return ok;
+}
+
 std::vector<double> CCalculation::GetDeltaZ() { return m_frame > 0 ? Fetch(SLX_OUT_DELTAZ) : std::vector<double>(); }
 
 std::vector<double> CCalculation::GetZ() { return Fetch(SLX_OUT_Z); }

@@ -118,6 +118,10 @@ public:
     // FillOtherDeltaProU(fN) + FillCoordinate(fN); afterwards GetZ/GetX/GetY/GetProjectorU/GetDeltaZ/Result refer to frame fN.
     bool StripRegression0(const Image8 &dynaCam0, int recoWindowSize = 21);
     bool CalculateOtherFrame(int fN, const Image8 &dynaCam);
+    // n consecutive frames fN0 .. fN0 + n - 1 in one call (slx_track_next_batch: the host images ride ONE transfer, the frames run
+    // back to back); afterwards the getters refer to the last of them.  deltaZ, when given, receives every frame's deltaZ map
+    // (n x rows x cols, host memory) -- what the reference keeps in m_deltaZ[fN] (R/CCalculation.cpp:772-775).
+    bool CalculateOtherFrames(int fN0, const Image8 *dynaCams, int n, std::vector<double> *deltaZ = nullptr);
     // The whole loop of CalculateOther over the sensor's dynaCam images (group 2): frame fN's point cloud goes to
     // <pointCloudPrefix><fN>.txt like m_pcSucceedName (R/CCalculation.cpp:309-314).  Returns the number of frames done.
     int CalculateOther(CSensor &sensor, const std::string &pointCloudPrefix, int recoWindowSize = 21);

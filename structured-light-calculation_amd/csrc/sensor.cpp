@@ -204,16 +204,48 @@ int CCalculation::CalculateOther(CSensor &sensor, const std::string &pointCloudP
     if (!m_ctx || !m_done) return 0;
     if (!sensor.LoadDatas(2) && sensor.DataNum() == 0) return 0;
     if (!sensor.SetProPicture(0) || !StripRegression0(sensor.GetCamPicture(), recoWindowSize)) return 0;
-    int done = 0;
-    for (int frameNum = 1; frameNum < sensor.DataNum(); frameNum++) {
-        if (!sensor.SetProPicture(frameNum)) break;
-        const Image8 cam = sensor.GetCamPicture();
-        if (cam.empty()) break;                                  // fewer images on disk than DYNAFRAME_MAXNUM
-        if (!CalculateOtherFrame(frameNum, cam)) break;
-        std::ostringstream name;
-        name << pointCloudPrefix << frameNum << ".txt";
-        if (!Result(name.str(), frameNum)) break;
-        done++;
+    // The reference has every dynaCam image in memory before it walks them (LoadDatas, R/CSensorV.cpp:60-133): the images travel to
+    // the device kChunk at a time in ONE transfer (slx_track_stage_frames), and each frame then runs from the device copy -- a
+    // frame's point cloud is written before the next frame starts, as in the reference's loop (R/CCalculation.cpp:222-317).
+    const int kChunk = 8;                                        // 8 images per transfer measured best (tools/track_bench.py --host --batch k --in-place: 46.5 us per 1920x1200 frame; 16-64: 61)
+    int done = 0, frameNum = 1;
+    const int total = sensor.DataNum();
+    while (frameNum < total) {
+        std::vector<Image8> cams;
+        for (int f = frameNum; f < total && (int)cams.size() < kChunk; f++) {
+            if (!sensor.SetProPicture(f)) break;
+            const Image8 cam = sensor.GetCamPicture();
+            if (cam.empty() || cam.rows != m_sp.CAMERA_RESROW || cam.cols != m_sp.CAMERA_RESLINE) break;   // fewer images on disk than DYNAFRAME_MAXNUM
+            cams.push_back(cam);
+        }
+        if (cams.empty()) break;
+        uint8_t *slab = nullptr;
+        size_t stride = 0, istride = 0;
+        const uint8_t *dev = nullptr;
+        if (slx_track_frames_buffer(m_ctx, (int)cams.size(), &slab, &stride, &istride) != SLX_OK) break;
+        for (size_t f = 0; f < cams.size(); f++)
+            for (int r = 0; r < cams[f].rows; r++)
+                std::memcpy(slab + f * istride + (size_t)r * stride, cams[f].data + (size_t)r * cams[f].step, (size_t)cams[f].cols);
+        if (slx_track_stage_frames(m_ctx, slab, stride, istride, (int)cams.size(), &dev) != SLX_OK) break;
+        bool ok = true;
+        for (size_t f = 0; f < cams.size() && ok; f++) {
+            Image8 on_dev;
+            on_dev.data = const_cast<uint8_t *>(dev + f * istride);
+            on_dev.rows = cams[f].rows;
+            on_dev.cols = cams[f].cols;
+            on_dev.step = stride;
+            on_dev.on_device = true;
+            ok = CalculateOtherFrame(frameNum, on_dev);
+            if (!ok) break;
+            std::ostringstream name;
+            name << pointCloudPrefix << frameNum << ".txt";
+            ok = Result(name.str(), frameNum);
+            if (ok) {
+                done++;
+                frameNum++;
+            }
+        }
+        if (!ok || (int)cams.size() < kChunk) break;
     }
     return done;
 }

@@ -66,6 +66,12 @@ struct slx_ctx {
     hipEvent_t ev_track_copied[2] = {nullptr, nullptr}, ev_track_used[2] = {nullptr, nullptr};
     bool track_slot_used[2] = {false, false}, track_slot_waited[2] = {false, false};
     hipStream_t copy_stream = nullptr;
+    // k dynamic frames per transfer (slx_track_stage_frames): two pinned + two device slabs of track_slab_frames images each
+    uint8_t *h_track_slab[2] = {nullptr, nullptr}, *d_track_slab[2] = {nullptr, nullptr};
+    hipEvent_t ev_slab_copied[2] = {nullptr, nullptr}, ev_slab_used[2] = {nullptr, nullptr};
+    bool slab_used[2] = {false, false};
+    int track_slab_frames = 0;
+    unsigned track_slab = 0;
     unsigned track_slot = 0;
     int track_window = 0;
     void *out[SLX_OUT_COUNT] = {};
@@ -306,6 +312,12 @@ void slx_destroy(slx_ctx *ctx)
         if (q) (void)hipFree(q);
     for (uint8_t *h : ctx->h_track_img)
         if (h) (void)hipHostFree(h);
+    for (int i = 0; i < 2; i++) {
+        if (ctx->h_track_slab[i]) (void)hipHostFree(ctx->h_track_slab[i]);
+        if (ctx->d_track_slab[i]) (void)hipFree(ctx->d_track_slab[i]);
+        if (ctx->ev_slab_copied[i]) (void)hipEventDestroy(ctx->ev_slab_copied[i]);
+        if (ctx->ev_slab_used[i]) (void)hipEventDestroy(ctx->ev_slab_used[i]);
+    }
     if (ctx->h_cloud_total) (void)hipHostFree(ctx->h_cloud_total);
     for (hipEvent_t e : {ctx->ev0, ctx->ev1, ctx->ev_done, ctx->ev_track_copied[0], ctx->ev_track_copied[1], ctx->ev_track_used[0], ctx->ev_track_used[1]})
         if (e) (void)hipEventDestroy(e);
@@ -811,18 +823,11 @@ int slx_track_begin(slx_ctx *ctx, const uint8_t *image, size_t stride_bytes, int
     return mark_done(ctx, ctx->stream);
 }
 
-int slx_track_next(slx_ctx *ctx, const uint8_t *image, size_t stride_bytes, int mem_kind)
+// One dynamic frame from a camera image in device memory: StripRegression(fN) + FillOtherDeltaProU(fN) + FillCoordinate(fN)
+// (R/CCalculation.cpp:789-892, 595-663, 666-785) on the context's stream.  deltaz: where this frame's deltaZ plane goes.
+static int track_step(slx_ctx *ctx, const uint8_t *img, size_t istride, double *deltaz)
 {
-    if (!ctx) return SLX_ERR_INVALID_ARG;
     const slx_config &c = ctx->cfg;
-    if (ctx->track_window == 0) return fail(ctx, SLX_ERR_NOT_CONFIGURED, "slx_track_begin has not been called");
-    SLX_HIP(ctx, hipSetDevice(ctx->device));
-    if (int rc0 = order_after_done(ctx, ctx->stream)) return rc0;
-    const uint8_t *img;
-    size_t istride;
-    int slot;
-    int rc = track_image(ctx, image, stride_bytes, mem_kind, &img, &istride, &slot);
-    if (rc != SLX_OK) return rc;
     // the strips of the previous frame move aside; the new ones start from 0 (R/CCalculation.cpp:827-828)
     float *curW = (float *)ctx->out[SLX_OUT_STRIPW], *curB = (float *)ctx->out[SLX_OUT_STRIPB];
     std::swap(curW, ctx->d_stripW_prev);
@@ -835,18 +840,182 @@ int slx_track_next(slx_ctx *ctx, const uint8_t *image, size_t stride_bytes, int 
     if (divisors_in_range && slx_track_fusable(c.width, c.height, ctx->track_window)) {
         e = slx_launch_track_fused(ctx->kp, img, istride, curW, curB, ctx->d_stripW_prev, ctx->d_stripB_prev, (float *)ctx->out[SLX_OUT_DELTAP],
                                    (double *)ctx->out[SLX_OUT_U], (double *)ctx->out[SLX_OUT_Z], (double *)ctx->out[SLX_OUT_X],
-                                   (double *)ctx->out[SLX_OUT_Y], (double *)ctx->out[SLX_OUT_DELTAZ], ctx->stream);
+                                   (double *)ctx->out[SLX_OUT_Y], deltaz, ctx->stream);
     } else {
         e = slx_launch_strip_regression(img, istride, c.width, c.height, ctx->track_window, curW, curB, ctx->stream, ctx->d_stripW_prev,
                                         ctx->d_stripB_prev, ctx->d_deltaP_raw);
         if (e == 0)
             e = slx_launch_track_update(ctx->kp, ctx->d_deltaP_raw, (float *)ctx->out[SLX_OUT_DELTAP], (double *)ctx->out[SLX_OUT_U],
                                         (double *)ctx->out[SLX_OUT_Z], (double *)ctx->out[SLX_OUT_X], (double *)ctx->out[SLX_OUT_Y],
-                                        (double *)ctx->out[SLX_OUT_DELTAZ], ctx->stream);
+                                        deltaz, ctx->stream);
     }
     if (e != 0) return hip_fail(ctx, (hipError_t)e, "dynamic-frame kernels");
+    return SLX_OK;
+}
+
+// A kernel reading `img` has just been queued on the context's stream: when the image lies in one of the staging slabs, that is
+// the work the slab's next transfer has to wait for.
+static int note_slab_read(slx_ctx *ctx, const uint8_t *img)
+{
+    const size_t cap = (size_t)ctx->track_slab_frames * (size_t)ctx->cfg.width * (size_t)ctx->cfg.height;
+    for (int k = 0; k < 2; k++)
+        if (ctx->d_track_slab[k] && img >= ctx->d_track_slab[k] && img < ctx->d_track_slab[k] + cap)
+            SLX_HIP(ctx, hipEventRecord(ctx->ev_slab_used[k], ctx->stream));
+    return SLX_OK;
+}
+
+int slx_track_next(slx_ctx *ctx, const uint8_t *image, size_t stride_bytes, int mem_kind)
+{
+    if (!ctx) return SLX_ERR_INVALID_ARG;
+    if (ctx->track_window == 0) return fail(ctx, SLX_ERR_NOT_CONFIGURED, "slx_track_begin has not been called");
+    SLX_HIP(ctx, hipSetDevice(ctx->device));
+    if (int rc0 = order_after_done(ctx, ctx->stream)) return rc0;
+    const uint8_t *img;
+    size_t istride;
+    int slot;
+    int rc = track_image(ctx, image, stride_bytes, mem_kind, &img, &istride, &slot);
+    if (rc != SLX_OK) return rc;
+    rc = track_step(ctx, img, istride, (double *)ctx->out[SLX_OUT_DELTAZ]);
+    if (rc != SLX_OK) return rc;
     if (slot >= 0) SLX_HIP(ctx, hipEventRecord(ctx->ev_track_used[slot], ctx->stream));
+    if (int rs = note_slab_read(ctx, img)) return rs;
     return mark_done(ctx, ctx->stream);
+}
+
+// The slab pair of slx_track_stage_frames: allocated for at least n frames, slab i's last transfer and the kernels that read it done.
+static int track_slab_ready(slx_ctx *ctx, unsigned i, int n_frames)
+{
+    const size_t bytes = (size_t)ctx->cfg.width * ctx->cfg.height;
+    if (!ctx->copy_stream) SLX_HIP(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+    if (n_frames > ctx->track_slab_frames) {
+        // grow both slabs: nothing may still be using the old ones
+        SLX_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));
+        if (int rc = wait_done_host(ctx)) return rc;
+        SLX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        for (int k = 0; k < 2; k++) {
+            if (ctx->h_track_slab[k]) (void)hipHostFree(ctx->h_track_slab[k]);
+            if (ctx->d_track_slab[k]) (void)hipFree(ctx->d_track_slab[k]);
+            ctx->h_track_slab[k] = ctx->d_track_slab[k] = nullptr;
+            ctx->slab_used[k] = false;
+        }
+        ctx->track_slab_frames = 0;
+        for (int k = 0; k < 2; k++) {
+            SLX_HIP(ctx, hipHostMalloc((void **)&ctx->h_track_slab[k], bytes * (size_t)n_frames, hipHostMallocDefault));
+            SLX_HIP(ctx, hipMalloc((void **)&ctx->d_track_slab[k], bytes * (size_t)n_frames));
+            if (!ctx->ev_slab_copied[k]) SLX_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_slab_copied[k], hipEventDisableTiming));
+            if (!ctx->ev_slab_used[k]) SLX_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_slab_used[k], hipEventDisableTiming));
+        }
+        ctx->track_slab_frames = n_frames;
+    }
+    if (ctx->slab_used[i]) {
+        // slab i was staged two calls ago.  The kernels that read its device copy (slx_track_next_batch, or slx_track_next on an
+        // image inside the slab: both record ev_slab_used after their launches) must be done before the next transfer overwrites
+        // it -- a device-side wait on the copy stream, which leaves the OTHER slab's kernels free to run beside this transfer --
+        // and the slab's own transfer must have left the pinned half before the host writes there
+        SLX_HIP(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->ev_slab_used[i], 0));
+        SLX_HIP(ctx, wait_event_spinning(ctx->ev_slab_copied[i]));
+    }
+    return SLX_OK;
+}
+
+int slx_track_frames_buffer(slx_ctx *ctx, int n_frames, uint8_t **buffer, size_t *stride_bytes, size_t *image_stride_bytes)
+{
+    if (!ctx) return SLX_ERR_INVALID_ARG;
+    if (!buffer) return fail(ctx, SLX_ERR_INVALID_ARG, "buffer is NULL");
+    if (n_frames < 1 || n_frames > SLX_TRACK_MAX_BATCH) return fail(ctx, SLX_ERR_INVALID_ARG, "n_frames must be in [1,%d] (got %d)", SLX_TRACK_MAX_BATCH, n_frames);
+    if (!mode_has_depth(ctx->cfg.mode) || !ctx->out[SLX_OUT_U])
+        return fail(ctx, SLX_ERR_UNAVAILABLE, "dynamic frames need a depth mode created with SLX_OUT_U in aux_outputs");
+    SLX_HIP(ctx, hipSetDevice(ctx->device));
+    const unsigned i = ctx->track_slab & 1u;
+    if (int rc = track_slab_ready(ctx, i, n_frames)) return rc;
+    *buffer = ctx->h_track_slab[i];
+    if (stride_bytes) *stride_bytes = (size_t)ctx->cfg.width;
+    if (image_stride_bytes) *image_stride_bytes = (size_t)ctx->cfg.width * ctx->cfg.height;
+    return SLX_OK;
+}
+
+int slx_track_stage_frames(slx_ctx *ctx, const uint8_t *images, size_t stride_bytes, size_t image_stride_bytes, int n_frames,
+                           const uint8_t **device_images)
+{
+    if (!ctx) return SLX_ERR_INVALID_ARG;
+    const slx_config &c = ctx->cfg;
+    if (!images || !device_images) return fail(ctx, SLX_ERR_INVALID_ARG, "images / device_images is NULL");
+    if (n_frames < 1 || n_frames > SLX_TRACK_MAX_BATCH) return fail(ctx, SLX_ERR_INVALID_ARG, "n_frames must be in [1,%d] (got %d)", SLX_TRACK_MAX_BATCH, n_frames);
+    if (stride_bytes < (size_t)c.width) return fail(ctx, SLX_ERR_INVALID_ARG, "stride %zu is smaller than the width %d", stride_bytes, c.width);
+    if (n_frames > 1 && image_stride_bytes < stride_bytes * (size_t)c.height) return fail(ctx, SLX_ERR_INVALID_ARG, "image stride %zu overlaps images", image_stride_bytes);
+    if (!mode_has_depth(c.mode) || !ctx->out[SLX_OUT_U])
+        return fail(ctx, SLX_ERR_UNAVAILABLE, "dynamic frames need a depth mode created with SLX_OUT_U in aux_outputs");
+    SLX_HIP(ctx, hipSetDevice(ctx->device));
+    const unsigned i = ctx->track_slab & 1u;
+    if (int rc = track_slab_ready(ctx, i, n_frames)) return rc;
+    ctx->track_slab++;
+    const size_t bytes = (size_t)c.width * c.height;
+    // images the caller wrote straight into the slab slx_track_frames_buffer handed out are already where the transfer reads them
+    if (!(images == ctx->h_track_slab[i] && stride_bytes == (size_t)c.width && (n_frames == 1 || image_stride_bytes == bytes)))
+        for (int f = 0; f < n_frames; f++)
+            for (int r = 0; r < c.height; r++)
+                std::memcpy(ctx->h_track_slab[i] + (size_t)f * bytes + (size_t)r * c.width, images + (size_t)f * image_stride_bytes + (size_t)r * stride_bytes,
+                            (size_t)c.width);
+    // ONE transfer for all of them (a 2.3 MB image per transfer pays ~20 us of hand-off between its end and the kernel that waits
+    // for it, every frame; k images pay it once)
+    SLX_HIP(ctx, hipMemcpyAsync(ctx->d_track_slab[i], ctx->h_track_slab[i], bytes * (size_t)n_frames, hipMemcpyHostToDevice, ctx->copy_stream));
+    SLX_HIP(ctx, hipEventRecord(ctx->ev_slab_copied[i], ctx->copy_stream));
+    SLX_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_slab_copied[i], 0));
+    // until a kernel reads the slab, "used" is the point where the stream learnt of the transfer
+    SLX_HIP(ctx, hipEventRecord(ctx->ev_slab_used[i], ctx->stream));
+    ctx->slab_used[i] = true;
+    *device_images = ctx->d_track_slab[i];
+    return SLX_OK;
+}
+
+int slx_track_next_batch(slx_ctx *ctx, const uint8_t *images, size_t stride_bytes, size_t image_stride_bytes, int n_frames, int mem_kind,
+                         double *deltaz_all, int deltaz_mem_kind)
+{
+    if (!ctx) return SLX_ERR_INVALID_ARG;
+    const slx_config &c = ctx->cfg;
+    if (ctx->track_window == 0) return fail(ctx, SLX_ERR_NOT_CONFIGURED, "slx_track_begin has not been called");
+    if (!images) return fail(ctx, SLX_ERR_INVALID_ARG, "images is NULL");
+    if (n_frames < 1 || n_frames > SLX_TRACK_MAX_BATCH) return fail(ctx, SLX_ERR_INVALID_ARG, "n_frames must be in [1,%d] (got %d)", SLX_TRACK_MAX_BATCH, n_frames);
+    if (mem_kind != SLX_MEM_HOST && mem_kind != SLX_MEM_DEVICE) return fail(ctx, SLX_ERR_INVALID_ARG, "unknown mem_kind %d", mem_kind);
+    if (stride_bytes < (size_t)c.width) return fail(ctx, SLX_ERR_INVALID_ARG, "stride %zu is smaller than the width %d", stride_bytes, c.width);
+    if (n_frames > 1 && image_stride_bytes < stride_bytes * (size_t)c.height) return fail(ctx, SLX_ERR_INVALID_ARG, "image stride %zu overlaps images", image_stride_bytes);
+    if (deltaz_all && deltaz_mem_kind != SLX_MEM_HOST && deltaz_mem_kind != SLX_MEM_DEVICE) return fail(ctx, SLX_ERR_INVALID_ARG, "unknown deltaz_mem_kind %d", deltaz_mem_kind);
+    SLX_HIP(ctx, hipSetDevice(ctx->device));
+    if (int rc0 = order_after_done(ctx, ctx->stream)) return rc0;
+    const size_t hw = (size_t)c.width * c.height;
+    // every frame's deltaZ for a host caller: collected in a device buffer of the call, copied out at its end (synchronous, like slx_get_output)
+    double *host_dz = nullptr, *dz_dev = deltaz_all;
+    if (deltaz_all && deltaz_mem_kind == SLX_MEM_HOST) {
+        host_dz = deltaz_all;
+        SLX_HIP(ctx, hipMalloc((void **)&dz_dev, (size_t)n_frames * hw * sizeof(double)));
+    }
+    struct Scratch {                                   // freed on every way out
+        double *p;
+        ~Scratch() { if (p) (void)hipFree(p); }
+    } scratch{host_dz ? dz_dev : nullptr};
+    const uint8_t *dev = images;
+    size_t dstride = stride_bytes, dimage = image_stride_bytes;
+    if (mem_kind == SLX_MEM_HOST) {
+        int rc = slx_track_stage_frames(ctx, images, stride_bytes, image_stride_bytes, n_frames, &dev);
+        if (rc != SLX_OK) return rc;
+        dstride = (size_t)c.width;
+        dimage = (size_t)c.width * c.height;
+    }
+    for (int f = 0; f < n_frames; f++) {
+        // every frame's deltaZ goes straight into its plane of the collection; the last frame's also stays in the context (SLX_OUT_DELTAZ)
+        double *dz = (dz_dev && f + 1 < n_frames) ? dz_dev + (size_t)f * hw : (double *)ctx->out[SLX_OUT_DELTAZ];
+        int rc = track_step(ctx, dev + (size_t)f * dimage, dstride, dz);
+        if (rc != SLX_OK) return rc;
+    }
+    if (int rs = note_slab_read(ctx, dev)) return rs;
+    if (dz_dev)
+        SLX_HIP(ctx, hipMemcpyAsync(dz_dev + (size_t)(n_frames - 1) * hw, ctx->out[SLX_OUT_DELTAZ], hw * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    int rc = mark_done(ctx, ctx->stream);
+    if (rc == SLX_OK && host_dz) {
+        SLX_HIP(ctx, hipMemcpyAsync(host_dz, dz_dev, (size_t)n_frames * hw * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        SLX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return rc;
 }
 
 // ---- frame ingest pipeline ---------------------------------------------------------

@@ -898,6 +898,81 @@ def test_dynamic_frames_fed_through_the_pinned_buffer(api, oracle, synth):
         assert e.value.code == api.ERR_UNAVAILABLE
 
 
+@pytest.mark.parametrize("shape,window", [((64, 200), 21), ((130, 256), 21), ((48, 332), 9)])
+def test_dynamic_frames_in_batches(api, oracle, synth, torch_cuda, shape, window):
+    """slx_track_next_batch / slx_track_stage_frames: k camera images per transfer.  The oracle's loop frame by frame
+    (R/CCalculation.cpp:789-892, 595-663, 666-785); every frame's deltaZ through deltaz_all (device and host), the context's
+    outputs after a batch are the last frame's; batches of different sizes (the slabs grow), images from the pinned slab, strided
+    host images, device images, and the stage-then-step form CCalculation::CalculateOther uses (a point cloud per frame)."""
+    torch = torch_cuda
+    h, w = shape
+    spec = small_spec(synth, "C1x4", w, h)
+    ph, gr, _ = synth.render(spec, "tilted", noise_sigma=2.0)
+    ref0 = oracle.pipeline(spec, ph, gr, want=("z", "U"))
+    n = 14
+    imgs = dyna_images(h, w, n, seed=5 * h + w)
+    # the oracle's frames
+    want = []
+    sw0, sb0 = oracle.strip_regression(imgs[0], window)
+    U, z_prev = ref0["U"], ref0["z"]
+    for f in range(1, n):
+        sw1, sb1 = oracle.strip_regression(imgs[f], window)
+        dP = oracle.delta_p(sw0, sb0, sw1, sb1)
+        U = U + dP.astype(np.float64)
+        tri = oracle.triangulate(spec, U)
+        want.append({"stripW": sw1, "stripB": sb1, "deltaP": dP, "U": U, "z": tri["z"], "x": tri["x"], "y": tri["y"], "deltaZ": tri["z"] - z_prev})
+        sw0, sb0, z_prev = sw1, sb1, tri["z"]
+
+    def check_last(ctx, f):
+        for name, ref in want[f - 1].items():
+            assert np.array_equal(ctx.get_output(name), ref, equal_nan=True), (f, name)
+
+    with api.Context(spec, aux=("U", "x", "y")) as ctx:
+        ctx.set_frames(ph, gr)
+        ctx.decode()
+        with pytest.raises(api.SlxError) as e:
+            ctx.track_next_batch(np.stack(imgs[1:3]))                # before slx_track_begin
+        assert e.value.code == api.ERR_NOT_CONFIGURED
+        ctx.track_begin(imgs[0], window=window)
+        # frames 1-3: one host batch, every deltaZ into a device array
+        dz = torch.full((3, h, w), -7.0, dtype=torch.float64, device="cuda")
+        torch.cuda.synchronize()
+        ctx.track_next_batch(np.stack(imgs[1:4]), dz)
+        ctx.synchronize()
+        check_last(ctx, 3)
+        for k in range(3):
+            assert np.array_equal(dz[k].cpu().numpy(), want[k]["deltaZ"], equal_nan=True), k
+        # frames 4-8: a larger batch (the slabs grow) written straight into the pinned slab, deltaZ into host memory
+        slab = ctx.track_frames_buffer(5)
+        assert slab.shape == (5, h, w)
+        slab[:] = np.stack(imgs[4:9])
+        dzh = np.full((5, h, w), -7.0)
+        ctx.track_next_batch(slab, dzh)
+        check_last(ctx, 8)
+        for k in range(5):
+            assert np.array_equal(dzh[k], want[3 + k]["deltaZ"], equal_nan=True), k
+        # frame 9: a batch of one strided host image, no deltaZ collection
+        wide = np.zeros((1, h, w + 40), dtype=np.uint8)
+        wide[0, :, :w] = imgs[9]
+        ctx.track_next_batch(wide[:, :, :w])
+        check_last(ctx, 9)
+        # frames 10-11: device images, borrowed
+        dev = torch.from_numpy(np.stack(imgs[10:12])).cuda()
+        torch.cuda.synchronize()
+        ctx.track_next_batch(dev)
+        ctx.synchronize()
+        check_last(ctx, 11)
+        # frames 12-13: one transfer, then frame by frame from the device slab, the cloud of each frame in between
+        base = ctx.track_stage_frames(np.stack(imgs[12:14]))
+        for k, f in enumerate((12, 13)):
+            ctx.track_next_device(base + k * h * w)
+            check_last(ctx, f)
+            assert np.array_equal(ctx.get_point_cloud(), oracle.point_cloud(spec, want[f - 1]["z"]))
+        with pytest.raises(api.SlxError) as e:
+            ctx.track_next_batch(np.zeros((0, h, w), dtype=np.uint8))
+        assert e.value.code == api.ERR_INVALID_ARG
+
+
 @pytest.mark.parametrize("shape", [(70, 200), (64, 64), (129, 65), (5, 700)])
 def test_point_cloud_of_a_batch_plane(api, oracle, synth, torch_cuda, shape):
     """slx_point_cloud_of_depth: the cloud (CCalculation::Result's data) of every frame-set of a batch decode, straight from

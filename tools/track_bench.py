@@ -20,6 +20,7 @@ ap.add_argument("--frames", type=int, default=60)
 ap.add_argument("--window", type=int, default=21)
 ap.add_argument("--host", action="store_true", help="feed the camera images from host memory (numpy): the pinned double-buffered path of slx_track_next")
 ap.add_argument("--in-place", action="store_true", help="with --host: write each image into slx_track_image_buffer (the copy into the pinned slot is the producer's, as a camera SDK's would be) -- the timed loop then holds no host copy")
+ap.add_argument("--batch", type=int, default=0, help="with --host: k images per transfer (slx_track_next_batch); with --in-place the producer writes into slx_track_frames_buffer")
 a = ap.parse_args()
 W, H = (int(v) for v in a.size.split("x"))
 spec = dict(synth.make_spec("REF"))
@@ -42,7 +43,22 @@ with api.Context(spec, aux=("U", "x", "y")) as ctx:
     import time
     t0 = time.perf_counter()
     t_buf = t_next = 0.0
-    for i in range(a.frames):
+    import numpy as np
+    if a.batch:
+        assert a.host, "--batch feeds host images"
+        k = a.batch
+        stack = np.stack([imgs[i % 4] for i in range(k)])
+        for _ in range(3):
+            ctx.track_next_batch(stack)
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        a.frames = max(1, a.frames // k) * k
+    for i in range(0 if not a.batch else a.frames // a.batch):
+        if a.in_place:
+            ctx.track_next_batch(ctx.track_frames_buffer(a.batch))   # contents as the producer left them
+        else:
+            ctx.track_next_batch(stack)
+    for i in range(a.frames if not a.batch else 0):
         if a.host and a.in_place:
             ta = time.perf_counter()
             b = ctx.track_image_buffer()                             # contents as the producer left them
@@ -58,7 +74,7 @@ with api.Context(spec, aux=("U", "x", "y")) as ctx:
 # deltaP 4 written; z 8 read; z/x/y 24 written; deltaZ 8 written.  (The unblurred deltaP stays in LDS in the one-launch
 # kernel of the 21-pixel window; other windows take two launches and move 8 more bytes per pixel.)
 bytes_px = 1 + 8 + 8 + 8 + 8 + 4 + 8 + 24 + 8
-print(json.dumps({"metric": "dynamic frames/s (slx_track_next)", "size": a.size, "window": a.window, "images": ("host, written in place into the pinned double buffer" if a.in_place else "host (pinned double buffer)") if a.host else "device", "frames": a.frames,
+print(json.dumps({"metric": "dynamic frames/s (slx_track_next)", "size": a.size, "window": a.window, "batch": a.batch or None, "images": ("host, written in place into the pinned double buffer" if a.in_place else "host (pinned double buffer)") if a.host else "device", "frames": a.frames,
                   "value": 1.0 / dt, "us_per_frame": dt * 1e6, "algorithmic_bytes_per_pixel": bytes_px,
                   "achieved_GBps": bytes_px * W * H / dt / 1e9,
                   **({"host_us_in_image_buffer": t_buf / a.frames * 1e6, "host_us_in_track_next": t_next / a.frames * 1e6} if a.host and a.in_place else {})}))
