@@ -219,6 +219,8 @@ def traffic_probe_child(args):
     spec = synth.make_spec(args.config)
     device = torch.device("cuda", 0)
     phase, gray = make_batch(torch, synth, spec, args.sets_per_gpu, device, seed=0x5EED + 4)
+    if phase.shape[1] == 0:
+        phase = None
     z = torch.empty((args.sets_per_gpu, spec["height"], spec["width"]), dtype=torch.float64, device=device)
     torch.cuda.synchronize()
     with api.Context(spec, device=0) as ctx:
@@ -234,7 +236,7 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     # the chip needs ~100 launches (~35 ms) of this kernel after an idle spell before its clock settles
     # (tools/ramp.py: 504, 359, 331, 325, 317, 316 ... us per launch in blocks of 25), hence the warm-up default
-    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--steps", type=int, default=1000)      # 0.3 s of launches: the ramp of the warm-up launches weighs < 10 % in a kernel trace of the command
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--sets-per-gpu", type=int, default=32)
     ap.add_argument("--config", default="C4")
@@ -434,6 +436,8 @@ def run_rank(args):
 
     t0 = time.perf_counter()
     phase_full, gray_full = make_batch(torch, synth, full_spec, args.sets_per_gpu, device, seed=0x5EED + 4 + rank)
+    if full_spec["mode"] in (synth.MODE_PHASE_ONLY, synth.MODE_GRAY_ONLY) and (world > 1 or not args.no_cpu_baseline):
+        raise SystemExit("bench: --config %s (a decoder object alone) is a profiling workload: N = 1 with --no-cpu-baseline" % args.config)
     if spec is full_spec:
         phase, gray = phase_full, gray_full
     else:
@@ -444,7 +448,9 @@ def run_rank(args):
     torch.cuda.synchronize()
     if rank == 0:
         log("[bench] rendered %d frame-sets (%.2f GB in, %.2f GB out per step) in %.1f s" %
-            (n_sets, phase.numel() / 1e9, z.numel() * 8 / 1e9, time.perf_counter() - t0))
+            (n_sets, (phase.numel() + (0 if gray is None else gray.numel())) / 1e9, z.numel() * 8 / 1e9, time.perf_counter() - t0))
+    if phase.shape[1] == 0:
+        phase = None                       # the Gray decoder alone has no phase planes
 
     ctx = api.Context(spec, device=dev_index)
     ctx.set_variant(args.variant)
@@ -475,9 +481,14 @@ def run_rank(args):
     # The chip needs ~100 launches of this kernel after an idle spell before its clock settles (tools/ramp.py).  When the
     # caller asks for fewer warm-up steps than that, the difference runs here, untimed and reported as "settle_launches",
     # so that a short --warmup still measures the settled clock.
-    settle = max(0, 100 - args.warmup)
-    for _ in range(settle):
-        step()
+    # ... and by TIME: until this workload has kept the chip busy for 100 ms (a count is not enough for short steps, and a 20-step
+    # timed region is a 6 ms window: it has to sit on the settled clock, not on the last part of the ramp).
+    settle, t_settle = 0, time.perf_counter()
+    while settle < max(0, 100 - args.warmup) or time.perf_counter() - t_settle < 0.100:
+        for _ in range(20):
+            step()
+        torch.cuda.synchronize()
+        settle += 20
     for _ in range(args.warmup):
         step()
     fence()
