@@ -140,13 +140,6 @@ def cpu_baseline(O, spec, phase_np, gray_np=None, budget_s=12.0):
 OTHER_SETS = {"C3": 16, "C5": 4, "REF": 32, "C2": 80}
 
 
-def kernel_name(spec, variant):
-    if spec["mode"] in (0, 1) and variant in (0, 2) and spec["n_steps"] == 4 and (spec["mode"] == 0 or spec["gray_bits"] == 6):
-        return "slx_decoder_strip_kernel<mode %d>" % spec["mode"]
-    strip = variant in (0, 2) and ((spec["mode"] == 3 and spec["n_steps"] in (4, 8)) or (spec["mode"] in (2, 4) and spec["n_steps"] == 4))
-    return ("slx_strip_kernel" if strip else "slx_fused_kernel") + "<mode %d, F=%d, N=%d>" % (spec["mode"], spec["n_freq"], spec["n_steps"])
-
-
 def traffic_entry(config, n_sets):
     """HBM bytes per launch from the committed PMC capture (not measured in this run): value, provenance."""
     tp = os.path.join(ROOT, "profiles", "traffic.json")
@@ -197,7 +190,7 @@ def traffic_probe(args, config=None, sets=None):
             for fn in files:                         # the profiler may write one file per process: every one of them is read
                 with open(fn) as fh:
                     vals += [float(row["Counter_Value"]) for row in csv.DictReader(fh)
-                             if row["Counter_Name"] == counter and ("slx_strip_kernel" in row["Kernel_Name"] or "slx_fused_kernel" in row["Kernel_Name"])]
+                             if row["Counter_Name"] == counter and any(k in row["Kernel_Name"] for k in ("slx_strip_kernel", "slx_stream_kernel", "slx_decoder_strip_kernel", "slx_fused_kernel"))]
             if not vals:
                 return None, "no dispatch of the decode kernel in the %s pass" % counter
             got[counter] = (sum(vals) / len(vals), len(vals))
@@ -534,7 +527,7 @@ def run_rank(args):
                        "kernel_variant": args.variant, "settle_launches": settle, "tuning": tune or None},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
-                         "kernel": kernel_name(spec, args.variant), "launch_ms": kernel_ms_max,
+                         "kernel": ctx.last_kernel(), "launch_ms": kernel_ms_max,
                          "algorithmic_bytes_per_launch": bytes_per_launch},
             "achieved_hbm_gbps_per_gpu": achieved, "kernel_only": kernel_only,
             # rccl_world_size: ncclCommCount of the communicator the gather ran on (slx_comm_info asks RCCL), null when no RCCL
@@ -771,6 +764,7 @@ def run_rank(args):
                         n_launch = max(30, min(args.steps, 60)) * (4 if sets == 1 else 1)
                         blocks = sorted(timed(ostep, n_launch, on=own_stream(octx))[1] for _ in range(5))
                         oms = blocks[2]
+                        okernel = octx.last_kernel()
                     obytes = sets * oH * oW * (synth.algorithmic_bytes_per_pixel(ospec) + aux_bpp)
                     otraffic, osource = (None, "not measured") if aux or sets == 1 else traffic_entry(name, sets)
                     if label in live_other:
@@ -783,7 +777,7 @@ def run_rank(args):
                                     "outputs": [primary] + list(aux), "bytes_per_pixel": synth.algorithmic_bytes_per_pixel(ospec) + aux_bpp,
                                     "roofline": {"bound": "hbm", "achieved": obytes / (oms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                                  "frac": obytes / (oms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "traffic": otraffic, "traffic_source": osource,
-                                                 "kernel": kernel_name(ospec, args.variant), "algorithmic_bytes_per_launch": obytes},
+                                                 "kernel": okernel, "algorithmic_bytes_per_launch": obytes},
                                     "parity_vs_oracle": ok}
                     if sets == 1:
                         other[label]["note"] = "back-to-back dependent launches: launch_ms includes the gap between two launches"

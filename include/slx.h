@@ -272,9 +272,14 @@ enum slx_tuning_key {
     SLX_TUNE_PLAIN_ORDER = 6,  /* 1: Gray-mask work items in plain order instead of XCD-grouped         */
     SLX_TUNE_TIERS = 7,        /* tiers of ever shorter work items towards the end of a launch, 1..4    */
     SLX_TUNE_WEAVE = 8,        /* rows woven into one row group (a lane's rows are that far apart), 1..64 */
-    SLX_TUNE_COUNT = 9
+    SLX_TUNE_STREAM = 9,       /* stream kernel (resident waves, short items from queues): 0 automatic, 1 never, 2 whenever possible */
+    SLX_TUNE_STREAM_ROWS = 10, /* its rows per work item, 2..16                                          */
+    SLX_TUNE_COUNT = 11
 };
 int slx_set_tuning(slx_ctx *ctx, int key, int value);
+/* Which kernel the context's last decode launch was and how its work was cut ("slx_stream_kernel: resident waves, 2-row items from
+ * queues", "slx_strip_kernel: 16-row items, 8 rows per row group", "slx_fused_kernel" ...): for bench lines and profiles. */
+int slx_last_kernel(slx_ctx *ctx, char *buf, size_t buf_bytes);
 
 /* ---- frame ingest pipeline: the live loop around the path -------------------------------------
  * Role of CSensor::GetCamPicture -> CDecode*::SetMat -> Decode in a capture loop (R/CSensorV.cpp:171-179,

@@ -30,7 +30,7 @@ SYMBOLS = [
     "slx_validate_config", "slx_create", "slx_destroy", "slx_last_error", "slx_set_gray_lut",
     "slx_set_frame", "slx_decode", "slx_decode_batch", "slx_synchronize", "slx_get_stream", "slx_get_output",
     "slx_get_depth", "slx_get_point_cloud", "slx_point_cloud_of_depth", "slx_track_begin", "slx_track_next", "slx_track_image_buffer", "slx_track_next_batch", "slx_track_stage_frames", "slx_track_frames_buffer", "slx_output_device_ptr", "slx_get_calibration", "slx_enable_timing",
-    "slx_last_decode_ms", "slx_debug_stamps", "slx_set_variant", "slx_set_tuning", "slx_read_bmp_gray", "slx_read_pgm_gray", "slx_read_calibration_yaml", "slx_version",
+    "slx_last_decode_ms", "slx_debug_stamps", "slx_set_variant", "slx_set_tuning", "slx_last_kernel", "slx_read_bmp_gray", "slx_read_pgm_gray", "slx_read_calibration_yaml", "slx_version",
     "slx_decode_batch_ex", "slx_comm_unique_id", "slx_comm_create", "slx_comm_adopt", "slx_comm_destroy", "slx_comm_info", "slx_comm_last_error",
     "slx_comm_synchronize", "slx_gather_depth", "slx_decode_gather", "slx_gather_plan",
     "slx_pipe_create", "slx_pipe_destroy", "slx_pipe_layout", "slx_pipe_acquire", "slx_pipe_submit", "slx_pipe_collect", "slx_pipe_last_error",
@@ -135,6 +135,7 @@ def lib():
         L.slx_last_decode_ms.argtypes = [vp, C.POINTER(C.c_float)]
         L.slx_set_variant.argtypes = [vp, C.c_int]
         L.slx_set_tuning.argtypes = [vp, C.c_int, C.c_int]
+        L.slx_last_kernel.argtypes = [vp, C.c_char_p, sz]
         L.slx_debug_stamps.argtypes = [vp, vp, sz]
         L.slx_read_bmp_gray.argtypes = [C.c_char_p, vp, sz, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.slx_read_pgm_gray.argtypes = [C.c_char_p, vp, sz, C.POINTER(C.c_int), C.POINTER(C.c_int)]
@@ -446,6 +447,12 @@ class Context:
     def set_variant(self, v):
         self._check(lib().slx_set_variant(self._h, int(v)))
 
+    def last_kernel(self):
+        """The kernel the last decode launch of this context ran as, and how its work was cut (slx_last_kernel)."""
+        buf = C.create_string_buffer(160)
+        self._check(lib().slx_last_kernel(self._h, buf, 160))
+        return buf.value.decode()
+
     def set_tuning(self, **kv):
         """Launch-geometry overrides of the fast kernel (slx_set_tuning): strip_rows, tail_pct, tail_rows, gray_plain,
         strip_waves, lds_pad_kib, plain_order; 0 = automatic."""
@@ -454,7 +461,7 @@ class Context:
 
 
 VARIANT_AUTO, VARIANT_GENERIC, VARIANT_STRIP, VARIANT_GENERIC_FAST = range(4)
-TUNE_KEYS = {"strip_rows": 0, "tail_pct": 1, "tail_rows": 2, "gray_plain": 3, "strip_waves": 4, "lds_pad_kib": 5, "plain_order": 6, "tiers": 7, "weave": 8}
+TUNE_KEYS = {"strip_rows": 0, "tail_pct": 1, "tail_rows": 2, "gray_plain": 3, "strip_waves": 4, "lds_pad_kib": 5, "plain_order": 6, "tiers": 7, "weave": 8, "stream": 9, "stream_rows": 10}
 
 
 class Pipe:

@@ -82,6 +82,7 @@ struct slx_ctx {
     bool decoded = false;
     int variant = 0;
     SlxTuning tune{};
+    SlxStreamState stream_state;               // queue counters of the stream kernel (device words), allocated on first use
     std::string err;
 };
 
@@ -307,6 +308,7 @@ void slx_destroy(slx_ctx *ctx)
     for (void *o : ctx->out)
         if (o) (void)hipFree(o);
     if (ctx->d_lut) (void)hipFree(ctx->d_lut);
+    if (ctx->stream_state.counters) (void)hipFree(ctx->stream_state.counters);
     for (void *q : {(void *)ctx->d_cloud_counts, (void *)ctx->d_cloud_tiles, (void *)ctx->d_cloud, (void *)ctx->d_stripW_prev,
                     (void *)ctx->d_stripB_prev, (void *)ctx->d_deltaP_raw, (void *)ctx->d_track_img[0], (void *)ctx->d_track_img[1]})
         if (q) (void)hipFree(q);
@@ -516,7 +518,13 @@ static int launch(slx_ctx *ctx, SlxKParams &kp, int n_sets, bool aux, void *stre
     // context's stream, an earlier decode on a caller's stream)
     if (int rc2 = order_after_done(ctx, s)) return rc2;
     if (ctx->timed) SLX_HIP(ctx, hipEventRecord(ctx->ev0, s));
-    int e = slx_launch_fused(kp, c.mode, aux, n_sets, ctx->variant, s, &ctx->tune);
+    if (!ctx->stream_state.counters && c.mode == SLX_MODE_MULTIFREQ && n_sets > 1) {
+        // queue counters of the stream kernel: zeroed by the launcher whenever the geometry they count for changes
+        SLX_HIP(ctx, hipMalloc((void **)&ctx->stream_state.counters, (size_t)SLX_STREAM_MAX_QUEUES * 32u * sizeof(unsigned)));
+        ctx->stream_state.key = 0;
+    }
+    int e = slx_launch_fused(kp, c.mode, aux, n_sets, ctx->variant, s, &ctx->tune, &ctx->stream_state);
+    if (e != 0) ctx->stream_state.key = 0;      // whatever a failed launch left in the counters is not trusted
     if (e != 0) return hip_fail(ctx, (hipError_t)e, "kernel launch");
     if (ctx->timed) SLX_HIP(ctx, hipEventRecord(ctx->ev1, s));
     return mark_done(ctx, s);
@@ -1248,6 +1256,17 @@ int slx_debug_stamps(slx_ctx *ctx, unsigned long long *device_words, size_t n_wo
     return SLX_OK;
 }
 
+int slx_last_kernel(slx_ctx *ctx, char *buf, size_t buf_bytes)
+{
+    if (!ctx || !buf || buf_bytes == 0) return SLX_ERR_INVALID_ARG;
+    const SlxStreamState &st = ctx->stream_state;
+    static const char *const names[] = {"none", "slx_fused_kernel", "slx_strip_kernel", "slx_stream_kernel", "slx_decoder_strip_kernel"};
+    if (st.last_kind == 3) snprintf(buf, buf_bytes, "%s: resident waves, %d-row items from queues", names[3], st.last_rows);
+    else if (st.last_kind == 2 || st.last_kind == 4) snprintf(buf, buf_bytes, "%s: %d-row items, %d rows per row group", names[st.last_kind], st.last_rows, st.last_weave);
+    else snprintf(buf, buf_bytes, "%s", names[st.last_kind >= 0 && st.last_kind <= 4 ? st.last_kind : 0]);
+    return SLX_OK;
+}
+
 int slx_set_variant(slx_ctx *ctx, int variant)
 {
     if (!ctx) return SLX_ERR_INVALID_ARG;
@@ -1271,7 +1290,7 @@ int slx_set_tuning(slx_ctx *ctx, int key, int value)
     SlxTuning &t = ctx->tune;
     const Range r[SLX_TUNE_COUNT] = {{&t.strip_rows, 0, 32}, {&t.tail_pct, -1, 99}, {&t.tail_rows, 0, 32}, {&t.gray_plain, 0, 1},
                                      {&t.strip_waves, 0, 4}, {&t.lds_pad_kib, 0, 128}, {&t.plain_order, 0, 1}, {&t.tiers, 0, SLX_MAX_TIERS},
-                                     {&t.weave, 0, 64}};
+                                     {&t.weave, 0, 64}, {&t.stream, 0, 2}, {&t.stream_rows, 0, 16}};
     if (key < 0 || key >= SLX_TUNE_COUNT) return fail(ctx, SLX_ERR_INVALID_ARG, "unknown tuning key %d", key);
     if (value < r[key].lo || value > r[key].hi) return fail(ctx, SLX_ERR_INVALID_ARG, "tuning key %d takes values in [%d,%d] (got %d)", key, r[key].lo, r[key].hi, value);
     *r[key].field = value;

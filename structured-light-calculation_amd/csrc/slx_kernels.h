@@ -62,6 +62,13 @@ struct SlxKParams {
     unsigned tier_first_wg[SLX_MAX_TIERS], tier_wgs[SLX_MAX_TIERS];
     int fast_arith;                             // generic kernel: use the bit-identical cheap unwrap / in-range division (host-checked)
     int plain_order;                            // Gray-mask strip kernel: items in plain order instead of XCD-grouped (slx_set_tuning, A/B only)
+    // ---- stream kernel (slx_stream_kernel): resident waves take short items from per-column queues
+    unsigned *sq_counters;                      // device: one word per queue, 32 words (128 B) apart; null = no stream kernel for this context
+    unsigned sq_queues, sq_m;                   // queues = chunks_per_group * sq_m; queue q serves chunk column q % chunks_per_group, row groups = q / chunks_per_group (mod sq_m)
+    unsigned sq_groups_per_set, sq_groups_total;// row groups (sq_rows * interleave rows each) per frame-set, and in the launch
+    unsigned sq_rows;                           // rows per item, >= 2
+    unsigned sq_magic;                          // floor(2^32 / sq_groups_per_set) + 1: G / groups_per_set = mulhi(G, magic) for every G of the launch
+    unsigned sq_epoch;                          // launches of this geometry since the counters were zeroed
     unsigned n_cus;                             // compute units of the context's device (0: 256, an unpartitioned MI355X); sizes "one round of items"
     unsigned long long *stamps;                 // diagnostics: 4 words per work item (s_memtime / s_memrealtime at start, end) or null
     unsigned long long stamp_items;             // items the stamp buffer has room for
@@ -116,6 +123,8 @@ struct SlxTuning {
     int lds_pad_kib;     // extra LDS per workgroup (lowers the occupancy), 0..128
     int plain_order;     // 1: Gray-mask items in plain order instead of XCD-grouped
     int weave;           // rows woven into one row group, rounded down to a multiple of the smallest legal count, 1..64
+    int stream;          // stream kernel: 0 automatic, 1 never, 2 whenever it can run
+    int stream_rows;     // its rows per item, 2..16
 };
 
 // Waves per SIMD the VGPR count of a strip-kernel instantiation allows (host-side table, checked against the compiled kernels
@@ -132,6 +141,7 @@ struct SlxLaunchPlan {
     SlxKParams kp;
     int mode, aux;
     int strip;               // 1: slx_strip_kernel, 0: slx_fused_kernel
+    int stream;              // 1: slx_stream_kernel (kp.sq_* filled in except sq_epoch)
     int gray_ring_bits;      // strip kernel: 6 when the Gray planes ride the DMA ring, else 0
     unsigned grid_x, grid_y, block;
     size_t lds_bytes;
@@ -140,7 +150,17 @@ int slx_plan_launch(const SlxKParams &kp, int mode, bool aux, int n_sets, int va
 
 // Launches the fused kernel for `n_sets` frame-sets on `stream` (hipStream_t).
 // Returns 0, or a hipError_t value.  `variant` selects a kernel variant, `tune` (may be null) the item geometry.
-int slx_launch_fused(const SlxKParams &kp, int mode, bool aux, int n_sets, int variant, void *stream, const SlxTuning *tune = nullptr);
+// Host-side record of a context's queue counters (slx_stream_kernel): the geometry they were last zeroed for and the launches since.
+#define SLX_STREAM_MAX_QUEUES 256
+struct SlxStreamState {
+    unsigned *counters = nullptr;               // device, SLX_STREAM_MAX_QUEUES * 32 words
+    unsigned long long key = 0;                 // geometry the counters count for (0: none yet)
+    unsigned epoch = 0;
+    // what the last launch was (slx_last_kernel): 0 none, 1 slx_fused_kernel, 2 slx_strip_kernel, 3 slx_stream_kernel, 4 slx_decoder_strip_kernel
+    int last_kind = 0, last_rows = 0, last_weave = 0;
+};
+int slx_launch_fused(const SlxKParams &kp, int mode, bool aux, int n_sets, int variant, void *stream, const SlxTuning *tune = nullptr,
+                     SlxStreamState *stream_state = nullptr);
 
 // For the other translation units of the library (slx_comm.cpp): the context's device and its own stream.
 extern "C" int slx_internal_device(const slx_ctx *ctx);

@@ -665,6 +665,16 @@ __device__ __forceinline__ uint32_t swar_gray_to_binary_u8(uint32_t g)
     return g;
 }
 
+// Wave-uniform values that hipcc's divergence analysis no longer proves uniform once they are carried around a loop and updated
+// under a (uniform) condition: told so, they stay in scalar registers -- a buffer descriptor must be in SGPRs.
+__device__ __forceinline__ unsigned uniform_u32(unsigned v) { return __builtin_amdgcn_readfirstlane(v); }
+template <typename T>
+__device__ __forceinline__ T *uniform_ptr(T *ptr)
+{
+    const unsigned long long b = reinterpret_cast<unsigned long long>(ptr);
+    return reinterpret_cast<T *>((unsigned long long)uniform_u32((unsigned)b) | ((unsigned long long)uniform_u32((unsigned)(b >> 32)) << 32));
+}
+
 // f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>): a loop whose index is a constant expression inside the
 // body (the immediate offset of a buffer load must be one)
 template <int N, int K = 0, typename Fn>
@@ -1239,6 +1249,257 @@ __global__ __launch_bounds__(256) void slx_strip_kernel(const SlxKParams p)
 }
 
 // ------------------------------------------------------------------------------------------
+// Stream kernel (round 4): the 3 x 4-step class (Gray-free, depth only) with work handed out in ADDRESS ORDER to resident waves.
+//
+// What round 4 measured: the strip kernel's launch is its memory skeleton plus a tenth of its VALU time,
+// and the skeleton is 13 % faster with 2-row items than with 16-row items -- the memory system likes the chip's accesses to
+// advance through ONE frame-set in order -- while the arithmetic needs long items, because what an item sets up (lane geometry
+// by integer division, the column terms of cC / cD, descriptors) costs a third of a row.  Here a wave sets that state up once per
+// LAUNCH and then takes short items (R rows of one 64-quad chunk column) from a queue until the queue is empty:
+//   * queue q = (chunk column c, residue j): its k-th item is row group G = k m + j of the batch's frame-sets laid end to end
+//     (G -> frame-set, group by one scalar multiply-high), always of column c -- so the wave's per-column state never changes;
+//   * a ticket is ONE scalar atomic (s_atomic_add ... glc: old value to an SGPR, counted by lgkmcnt, no vector register, not in
+//     the vmcnt sequence the DMA ring counts) issued just before the step's wait for its DMA chunk, so its latency hides there;
+//   * the queues' fronts advance together: at any moment the resident waves hold a band of consecutive row groups of one or two
+//     frame-sets, whatever the speed of the single waves (oldest-first arbitration makes them unequal: a slow wave simply takes
+//     fewer items) -- the footprint of short items with the start-up cost of one item per wave;
+//   * the DMA ring (two chunks ahead), the counted waits, the staged lane-contiguous stores are the strip kernel's, carried
+//     across item boundaries: the request side runs two rows ahead of the compute side and crosses into the next item first.
+// Counters: one 32-bit word per queue, 128 bytes apart (p.sq_counters); a launch adds exactly K_q + W_q to counter q (K_q items,
+// one failing ticket per wave), so launch number e of a geometry starts at e (K_q + W_q) and nothing is reset between launches
+// (the host zeroes them when the geometry changes, slx_launch_fused).
+template <int F>
+__global__ __launch_bounds__(256) void slx_stream_kernel(const SlxKParams p)
+{
+    constexpr int NPH = F * 4;                     // planes of a row = one ring chunk
+    constexpr unsigned ROW_DW = NPH * 64;
+    constexpr int NZ = 2;
+    typedef double vec2 __attribute__((ext_vector_type(2)));
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) void lds_void;
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds_raw[];
+    const unsigned t = threadIdx.x;
+    const unsigned lane = t & 63u;
+    const unsigned wave_in_wg = __builtin_amdgcn_readfirstlane(t >> 6);
+    uint32_t *ring = lds_raw + wave_in_wg * (2u * ROW_DW + 512u);
+    vec2 *stage = reinterpret_cast<vec2 *>(ring + 2u * ROW_DW);
+
+    // ---- this wave's queue
+    const unsigned waves_per_wg = blockDim.x >> 6;
+    const unsigned wave_id = blockIdx.x * waves_per_wg + wave_in_wg, total_waves = gridDim.x * waves_per_wg;
+    const unsigned NQ = p.sq_queues, m = p.sq_m, cpg = p.chunks_per_group;
+    const unsigned q = wave_id % NQ;
+    const unsigned c = q % cpg, j = q / cpg;
+    const unsigned Kq = p.sq_groups_total > j ? (p.sq_groups_total - j + m - 1u) / m : 0u;     // items of this queue
+    const unsigned Wq = (total_waves - q + NQ - 1u) / NQ;                                       // waves that poll it
+    const unsigned ticket0 = p.sq_epoch * (Kq + Wq);                                            // this launch's first ticket
+    unsigned *ctr = p.sq_counters + (size_t)q * 32u;
+    auto fetch_issue = [&](unsigned &raw) {        // the ticket arrives with the next s_waitcnt lgkmcnt(0)
+        asm volatile("s_mov_b32 %0, 1\n\ts_atomic_add %0, %1, 0x0 glc" : "=&s"(raw) : "s"(ctr) : "memory");
+    };
+    auto fetch_wait = [&](unsigned &raw) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(raw)::"memory"); };
+
+    // ---- per-column state, once per launch
+    const unsigned W = (unsigned)p.width, H = (unsigned)p.height;
+    const unsigned row_stride = (unsigned)p.row_stride, il = p.interleave, R = p.sq_rows;
+    const unsigned QR = p.quads_per_row;
+    const unsigned idx = c * 64u + lane;                           // < il * QR: chunks_per_group * 64 is exactly that
+    const unsigned sub = idx / QR, cq = idx - sub * QR;            // row within the row group, quad column
+    unsigned out_lane[2];                                          // byte offset of store slot k within the group's first row ... (+ sub rows)
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        const unsigned slot = (unsigned)k * 64u + lane, vidx = c * 64u + (slot >> 1);
+        const unsigned vsub = vidx / QR, vcq = vidx - vsub * QR;
+        out_lane[k] = (vsub * W + vcq * SLX_QUAD + (slot & 1u) * 2u) * 8u;
+    }
+    const unsigned dma_lane = sub * row_stride + cq * SLX_QUAD;
+    const unsigned dma_last = (H - 1u) * row_stride + cq * SLX_QUAD;     // rows past the tile: harmless re-read of the last row
+    const unsigned dma_step = il * row_stride, out_step = il * W * 8u;
+    float Tf[F];
+#pragma unroll
+    for (int f = 0; f < F; f++) Tf[f] = (float)p.period[f];
+    double hb[F];
+#pragma unroll
+    for (int f = 0; f < F; f++) {
+        hb[f] = p.half_biased[f];
+        asm volatile("" : "+v"(hb[f]));
+    }
+    double aC[SLX_QUAD], aD[SLX_QUAD];
+#pragma unroll
+    for (int jx = 0; jx < SLX_QUAD; jx++) {
+        const double a = ((double)(int)(cq * SLX_QUAD + jx) - p.cx) * p.fv;
+        aC[jx] = a * p.P00;
+        aD[jx] = a * p.P20;
+    }
+
+    // ---- items: ticket -> (frame-set, first row of the row group)
+    struct Item { unsigned valid, set, row_base; };
+    auto decode = [&](unsigned raw) {
+        Item it;
+        const unsigned k = raw - ticket0;
+        it.valid = k < Kq ? 1u : 0u;
+        const unsigned G = it.valid ? k * m + j : 0u;
+        it.set = p.sq_groups_per_set == 1u ? G : __umulhi(G, p.sq_magic);   // G / groups_per_set (exact for G * groups_per_set < 2^32: slx_plan.cpp)
+        it.row_base = (G - it.set * p.sq_groups_per_set) * R * il;
+        return it;
+    };
+    unsigned raw;
+    fetch_issue(raw);
+    fetch_wait(raw);
+    Item A = decode(raw), B{0u, 0u, 0u};
+    if (!A.valid) return;
+
+    // request side (two chunks ahead): its item, rows of it already requested, descriptor, lane offset of the next row to request
+    Item D = A;
+    unsigned dri = 0;
+    __amdgpu_buffer_rsrc_t drsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(p.plane_base + (size_t)D.set * p.phase_set_stride), 0, 0xFFFFFFFFu, 0x00020000);
+    unsigned dma_off = dma_lane + D.row_base * row_stride;
+    auto next_plane = [](unsigned &so, unsigned step) { asm volatile("s_add_u32 %0, %0, %1" : "+s"(so) : "s"(step) : "scc"); };
+    auto issue_chunk = [&](unsigned slot) {
+        const unsigned voff = dma_off < dma_last ? dma_off : dma_last;
+        uint32_t *dst = ring + slot * ROW_DW;
+        unsigned so = p.phase_first;
+        if (p.dma_imm) {
+            static_for<NPH>([&](auto k) {
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(drsrc, (lds_void *)dst, 4, voff, so, decltype(k)::value * 256, 2 /* nt */);
+                if (decltype(k)::value + 1 < NPH) next_plane(so, p.phase_step - 256u);
+            });
+        } else {
+#pragma unroll
+            for (int k = 0; k < NPH; k++) {
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(drsrc, (lds_void *)(dst + k * 64), 4, voff, so, 0, 2 /* nt */);
+                if (k + 1 < NPH) next_plane(so, p.phase_step);
+            }
+        }
+        dma_off += dma_step;
+        dri = uniform_u32(dri + 1u);
+    };
+    // the request side steps into item `to` (its first row comes next)
+    auto request_moves_to = [&](const Item &to) {
+        D = to;
+        dri = 0;
+        if (to.valid) {
+            drsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(uniform_ptr(p.plane_base + (size_t)to.set * p.phase_set_stride)), 0, 0xFFFFFFFFu, 0x00020000);
+            dma_off = dma_lane + to.row_base * row_stride;
+        }
+    };
+
+    // compute side: item A, row ri of it; where its rows are stored
+    unsigned ri = 0;
+    unsigned row = A.row_base + sub;
+    __amdgpu_buffer_rsrc_t zrsrc = __builtin_amdgcn_make_buffer_rsrc(p.z + (size_t)A.set * p.out_set_stride, 0, H * W * 8u, 0x00020000);
+    unsigned out_boff[2] = {out_lane[0] + A.row_base * W * 8u, out_lane[1] + A.row_base * W * 8u};
+    // the staged row waiting for its (one step late) stores
+    __amdgpu_buffer_rsrc_t prsrc = zrsrc;
+    unsigned pend_off[2] = {0xFFFFFFF0u, 0xFFFFFFF0u};
+
+    issue_chunk(0);                                                // rows 0 and 1 of the first item (R >= 2)
+    issue_chunk(1);
+    unsigned ahead = 2;                                            // chunks requested and not yet waited for
+    for (unsigned s = 0;; s++) {
+        const unsigned slot = s & 1u;
+        if (ri == 0) fetch_issue(raw);                             // the ticket of the item after this one; lands below
+        // counted wait for chunk s (vmcnt retires in issue order): L(s) | Z(s-2) L(s+1) | wait -- as in slx_strip_kernel
+        if (ahead < 2u) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (s >= 2u) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPH + NZ) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPH) : "memory");
+        ahead--;
+        if (s > 0) {                                               // last row's stores, one step late
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                const u32x4 v = *reinterpret_cast<const u32x4 *>(stage + k * 64 + lane);
+                __builtin_amdgcn_raw_buffer_store_b128(v, prsrc, pend_off[k], 0, 2 /* nt */);
+            }
+        }
+        float pix[F][SLX_QUAD];
+        if (row < H) {
+            const uint32_t *src = ring + slot * ROW_DW + lane;
+#pragma unroll
+            for (int f = 0; f < F; f++) {
+                const uint32_t w0 = src[(f * 4 + 0) * 64], w1 = src[(f * 4 + 1) * 64];
+                const uint32_t w2 = src[(f * 4 + 2) * 64], w3 = src[(f * 4 + 3) * 64];
+                const f32x2 kUp = {0x1p126f, 0x1p126f};
+                const F32x2x2 px = wrapped_pix_from_diffs<true>(
+                    F32x2x2{f32x2{byte_diff_denorm<0>(w0, w2), byte_diff_denorm<1>(w0, w2)} * kUp, f32x2{byte_diff_denorm<2>(w0, w2), byte_diff_denorm<3>(w0, w2)} * kUp},
+                    F32x2x2{f32x2{byte_diff_denorm<0>(w1, w3), byte_diff_denorm<1>(w1, w3)} * kUp, f32x2{byte_diff_denorm<2>(w1, w3), byte_diff_denorm<3>(w1, w3)} * kUp}, Tf[f]);
+                pix[f][0] = px.a.x;
+                pix[f][1] = px.a.y;
+                pix[f][2] = px.b.x;
+                pix[f][3] = px.b.y;
+            }
+        }
+        // the slot is free once it has been read -- and the ticket requested above has arrived with the same wait
+        if (ri == 0) {
+            fetch_wait(raw);
+            B = decode(raw);
+        } else {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        // chunk s + 2: the request side's next row, in this item or the first row of the next one
+        if (D.valid && dri == R) request_moves_to(B);
+        if (D.valid) {
+            issue_chunk(slot);
+            ahead++;
+        }
+        if (row < H) {
+            double z[SLX_QUAD];
+            const double vc = (double)((int)row + p.row_offset) - p.cy;
+            const double vf = vc * p.fu;
+            const double tvC = vf * p.P01, tvD = vf * p.P21;
+#pragma unroll
+            for (int jx = 0; jx < SLX_QUAD; jx++) {
+#if SLX_EXP & 8
+                double Uf = (double)((pix[0][jx] + pix[F - 1][jx]) + pix[F > 1 ? 1 : 0][jx]);   // TIMING DIAGNOSTIC ONLY: no unwrap
+#else
+                double Uf = (double)pix[0][jx];
+#pragma unroll
+                for (int f = 1; f < F; f++) {
+                    int kk;
+                    Uf = unwrap_stage<true>(Uf, (double)pix[f][jx], p.period[f], p.inv_period[f], hb[f], kk);
+                }
+#endif
+                const double cC = (aC[jx] + tvC) + p.K1;
+                const double cD = (aD[jx] + tvD) + p.K2;
+#if SLX_EXP & 4
+                z[jx] = Uf + cC + cD;                              // TIMING DIAGNOSTIC ONLY: no triangulation
+#else
+                z[jx] = tri_depth<true>(Uf, cC, cD, p.cA, p.cB, p.fov_min, p.fov_max, true);
+#endif
+            }
+            stage[2 * lane + 0] = vec2{z[0], z[1]};
+            stage[2 * lane + 1] = vec2{z[2], z[3]};
+
+        }
+        // this row's stores go out at the top of the next step
+        prsrc = zrsrc;
+        pend_off[0] = out_boff[0];
+        pend_off[1] = out_boff[1];
+        __builtin_amdgcn_wave_barrier();
+        // next row of the item, or the next item
+        ri = uniform_u32(ri + 1u);
+        if (ri == R) {
+            if (!B.valid) break;
+            A = B;
+            ri = 0;
+            row = A.row_base + sub;
+            zrsrc = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(p.z + (size_t)A.set * p.out_set_stride), 0, H * W * 8u, 0x00020000);
+            out_boff[0] = out_lane[0] + A.row_base * W * 8u;
+            out_boff[1] = out_lane[1] + A.row_base * W * 8u;
+        } else {
+            row += il;
+            out_boff[0] += out_step;
+            out_boff[1] += out_step;
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        const u32x4 v = *reinterpret_cast<const u32x4 *>(stage + k * 64 + lane);
+        __builtin_amdgcn_raw_buffer_store_b128(v, prsrc, pend_off[k], 0, 2 /* nt */);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // The reference's decoder objects on the strip path: what CDecodePhase::Decode (R/CDecodePhase.cpp:83-96 -> CountResult :48-80:
 // four 8-bit planes in, the wrapped phase in projector pixels out as CV_64FC1) and CDecodeGray::Decode (R/CDecodeGray.cpp:108-139
 // -> Grey2Bin :150-176, CountResult :179-204: 2 G planes in, the stripe's left edge out as CV_64FC1) compute, for a host loop that
@@ -1594,13 +1855,33 @@ int slx_launch_cloud_write(const SlxKParams &kp, const double *z, const unsigned
 }
 
 // Launches a plan of slx_plan_launch (slx_plan.cpp: kernel choice, work items, grid -- host arithmetic only).
-int slx_launch_fused(const SlxKParams &kp_in, int mode, bool aux, int n_sets, int variant, void *stream, const SlxTuning *tune)
+int slx_launch_fused(const SlxKParams &kp_in, int mode, bool aux, int n_sets, int variant, void *stream, const SlxTuning *tune, SlxStreamState *st)
 {
     SlxLaunchPlan plan;
-    if (slx_plan_launch(kp_in, mode, aux, n_sets, variant, tune, &plan) != 0) return (int)hipErrorInvalidValue;
-    const SlxKParams &kp = plan.kp;
+    SlxKParams kq = kp_in;
+    kq.sq_counters = (st && variant != SLX_VARIANT_GENERIC && variant != SLX_VARIANT_GENERIC_FAST) ? st->counters : nullptr;
+    if (slx_plan_launch(kq, mode, aux, n_sets, variant, tune, &plan) != 0) return (int)hipErrorInvalidValue;
+    SlxKParams &kp = plan.kp;
     kernel_fn fn;
-    if (!plan.strip) {
+    if (plan.stream) {
+        // the counters count for ONE geometry: zero them when it changes (or before they could wrap), else carry on from the last launch
+        const unsigned long long key = ((unsigned long long)kp.sq_queues << 52) ^ ((unsigned long long)kp.sq_m << 44) ^ ((unsigned long long)kp.sq_groups_total << 12) ^
+                                       ((unsigned long long)plan.grid_x << 3) ^ ((unsigned long long)(plan.block / 64u) << 1) ^ 1ull;
+        const unsigned long long per_launch = (unsigned long long)kp.sq_groups_total / kp.sq_m + 2ull + ((unsigned long long)plan.grid_x * (plan.block / 64u)) / kp.sq_queues + 2ull;
+        if (st->key != key || ((unsigned long long)st->epoch + 2ull) * per_launch >= (1ull << 31)) {
+            const hipError_t e = hipMemsetAsync(st->counters, 0, (size_t)SLX_STREAM_MAX_QUEUES * 32u * sizeof(unsigned), (hipStream_t)stream);
+            if (e != hipSuccess) return (int)e;
+            st->key = key;
+            st->epoch = 0;
+        }
+        kp.sq_epoch = st->epoch++;
+        switch (kp.n_freq) {
+        case 1: fn = slx_stream_kernel<1>; break;
+        case 2: fn = slx_stream_kernel<2>; break;
+        case 3: fn = slx_stream_kernel<3>; break;
+        default: fn = slx_stream_kernel<4>; break;
+        }
+    } else if (!plan.strip) {
         fn = pick(mode, kp.n_freq, kp.n_steps == 4, aux);
     } else if (mode == SLX_MODE_PHASE_ONLY || mode == SLX_MODE_GRAY_ONLY) {
         fn = mode == SLX_MODE_PHASE_ONLY ? slx_decoder_strip_kernel<SLX_MODE_PHASE_ONLY> : slx_decoder_strip_kernel<SLX_MODE_GRAY_ONLY>;
@@ -1612,6 +1893,11 @@ int slx_launch_fused(const SlxKParams &kp_in, int mode, bool aux, int n_sets, in
                  : (gb ? pick_strip<SLX_MODE_GRAY_PHASE, 6>(1, aux) : pick_strip<SLX_MODE_GRAY_PHASE, 0>(1, aux));
     }
     if (!fn) return (int)hipErrorInvalidValue;
+    if (st) {
+        st->last_kind = plan.stream ? 3 : !plan.strip ? 1 : (mode == SLX_MODE_PHASE_ONLY || mode == SLX_MODE_GRAY_ONLY) ? 4 : 2;
+        st->last_rows = plan.stream ? (int)kp.sq_rows : plan.strip ? (int)kp.tier_rows[0] : 0;
+        st->last_weave = plan.strip ? (int)kp.interleave : 0;
+    }
     // operand shapes were validated by the caller (slx_api.cpp: check_launch_shapes), slx_strip_eligible and the plan
     hipLaunchKernelGGL(fn, dim3(plan.grid_x, plan.grid_y, 1), dim3(plan.block, 1, 1), plan.lds_bytes, (hipStream_t)stream, kp);
     return (int)hipGetLastError();

@@ -143,6 +143,7 @@ int slx_plan_launch(const SlxKParams &kp_in, int mode, bool aux, int n_sets, int
     plan->mode = mode;
     plan->aux = aux ? 1 : 0;
     plan->gray_ring_bits = 0;
+    plan->stream = 0;
     const SlxTuning none{};
     const SlxTuning &tn = tune ? *tune : none;
     const bool can_strip = slx_strip_eligible(kp_in, mode, aux);
@@ -207,6 +208,47 @@ int slx_plan_launch(const SlxKParams &kp_in, int mode, bool aux, int n_sets, int
         gb = 6;
         kp.gray_step = (unsigned)(kp.gray[1] - kp.gray[0]);
         if (kp.gray_step < 256u) kp.dma_imm = 0;
+    }
+    // Stream kernel (slx_kernels.hip: slx_stream_kernel): the Gray-free 4-step depth-only class, launches that fill the chip many times over
+    plan->stream = 0;
+    if (!decoder && mode == SLX_MODE_MULTIFREQ && kp.n_steps == 4 && !aux && kp.sq_counters && tn.stream != 1 && tn.weave <= 1) {
+        const unsigned il = 64u / g;                                     // no weave: the queues hand the rows out in order anyway
+        const unsigned cpg = il * QR / 64u;
+        const unsigned R = (tn.stream_rows >= 2 && tn.stream_rows <= 16) ? (unsigned)tn.stream_rows : 2u;   // measured: 2 rows 270, 4: 274, 8: 284, 16: 302 us (C4 x 32)
+        const unsigned gps = ((unsigned)kp.height + R * il - 1u) / (R * il);
+        const unsigned long long groups_total = (unsigned long long)gps * (unsigned)n_sets;
+        const unsigned cus = kp.n_cus ? kp.n_cus : 256u;
+        // resident waves per CU: 16 (4 per SIMD) in 4-wave workgroups; experiments: strip_waves = w makes w-wave workgroups and as many
+        // of them as the CU's 160 KiB of LDS hold (1-wave workgroups: 20 waves per CU = 5 per SIMD)
+        const unsigned lds_w0 = 2u * (unsigned)kp.n_freq * 4u * 256u + 2048u;
+        const unsigned wpw = (tn.strip_waves >= 1 && tn.strip_waves <= 4) ? (unsigned)tn.strip_waves : 4u;
+        const unsigned per_cu = std::min(32u, wpw * (160u * 1024u / (wpw * lds_w0)));
+        const unsigned long long waves = (unsigned long long)cus * (tn.strip_waves ? per_cu : 16u);
+        const unsigned m = cpg <= 255u ? 255u / cpg : 0u;
+        const bool big = groups_total * cpg >= 8ull * waves;               // >= 8 items per resident wave
+        if (m >= 1 && cpg * m <= SLX_STREAM_MAX_QUEUES && groups_total * gps < (1ull << 32) && groups_total < (1ull << 31) &&
+            (tn.stream == 2 ? groups_total * cpg >= 1 : big)) {
+            kp.interleave = il;
+            kp.chunks_per_group = cpg;
+            kp.sq_queues = cpg * m;
+            kp.sq_m = m;
+            kp.sq_rows = R;
+            kp.sq_groups_per_set = gps;
+            kp.sq_groups_total = (unsigned)groups_total;
+            kp.sq_magic = (unsigned)((1ull << 32) / gps) + 1u;
+            kp.n_tiers = 0;
+            const unsigned lds_w = 2u * (unsigned)kp.n_freq * 4u * 256u + 2048u;
+            const unsigned long long items = groups_total * cpg;
+            const unsigned long long want_waves = std::min<unsigned long long>(waves, items);
+            plan->strip = 1;
+            plan->stream = 1;
+            plan->gray_ring_bits = 0;
+            plan->block = 64u * wpw;
+            plan->grid_x = (unsigned)((want_waves + wpw - 1ull) / wpw);
+            plan->grid_y = 1;
+            plan->lds_bytes = wpw * lds_w;
+            return 0;
+        }
     }
     // LDS per wave: 2 ring slots (max(4 n_freq, 2 gb) planes with 4 steps, 8 planes with 8 steps, 256 B each) + 2 KiB of depth staging
     const unsigned ring_planes = mode == SLX_MODE_GRAY_ONLY ? 12u : kp.n_steps == 4 ? std::max((unsigned)kp.n_freq * 4u, 2u * (unsigned)gb) : 8u;

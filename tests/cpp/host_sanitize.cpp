@@ -17,7 +17,7 @@
 #include "slx.h"
 #include "slx_kernels.h"
 
-static int g_fail = 0, g_strip_plans = 0, g_generic_plans = 0;
+static int g_fail = 0, g_strip_plans = 0, g_generic_plans = 0, g_stream_plans = 0;
 #define CHECK(cond)                                                           \
     do {                                                                      \
         if (!(cond)) {                                                        \
@@ -232,8 +232,65 @@ static void check_plan(int w, int h, int n_sets, int mode, int F, int N, int G, 
     }
 }
 
+// The stream kernel's plan: every (row group, chunk column) of the launch belongs to exactly one queue position, the scalar
+// multiply-high that turns a group number into (frame-set, group) is exact for every group, the groups cover the tile.
+static void check_stream_plan(int w, int h, int n_sets, int F, int rows)
+{
+    SlxKParams kp;
+    std::memset(&kp, 0, sizeof kp);
+    kp.width = w; kp.height = h; kp.quads_per_row = (unsigned)((w + 3) / 4); kp.n_quads = kp.quads_per_row * (unsigned)h;
+    kp.n_freq = F; kp.n_steps = 4; kp.aligned = (w % 4) == 0; kp.row_stride = (size_t)w;
+    for (int f = 0; f < F; f++) kp.period[f] = 1920 >> (3 * f);
+    kp.cx = w / 2.0; kp.cy = h / 2.0; kp.fu = kp.fv = 1200; kp.P00 = 1; kp.P01 = .1; kp.P20 = .01; kp.P21 = .02; kp.K1 = 5; kp.K2 = 7; kp.cA = 3; kp.cB = 2;
+    kp.out_set_stride = (size_t)w * (size_t)h;
+    static uint8_t arena[1];
+    static unsigned counters[1];
+    static double out_arena[2];
+    const size_t plane = (size_t)w * (size_t)h;
+    for (int i = 0; i < F * 4; i++) kp.phase[i] = arena + (size_t)i * plane;
+    kp.phase_set_stride = (size_t)(F * 4) * plane;
+    kp.z = out_arena;
+    kp.sq_counters = counters;
+    SlxTuning tn;
+    std::memset(&tn, 0, sizeof tn);
+    tn.stream = 2;
+    tn.stream_rows = rows;
+    SlxLaunchPlan plan;
+    if (slx_plan_launch(kp, SLX_MODE_MULTIFREQ, false, n_sets, SLX_VARIANT_AUTO, &tn, &plan) != 0) return;
+    if (!plan.stream) return;
+    g_stream_plans++;
+    const SlxKParams &q = plan.kp;
+    CHECK(q.sq_rows >= 2 && q.sq_rows <= 16 && q.sq_m >= 1 && q.sq_queues == q.chunks_per_group * q.sq_m && q.sq_queues <= SLX_STREAM_MAX_QUEUES);
+    CHECK(q.chunks_per_group * 64u == q.interleave * q.quads_per_row);
+    CHECK((unsigned long long)q.sq_groups_per_set * q.sq_rows * q.interleave >= (unsigned)h);
+    CHECK((unsigned long long)(q.sq_groups_per_set - 1) * q.sq_rows * q.interleave < (unsigned)h);          // the last group starts inside the tile
+    CHECK(q.sq_groups_total == q.sq_groups_per_set * (unsigned)n_sets);
+    CHECK(plan.block == 256 && plan.grid_x >= 1 && plan.grid_x <= 1024 && plan.lds_bytes <= 160u * 1024u);
+    // every group is some queue's k-th item exactly once, and the multiply-high division is exact
+    unsigned long long seen = 0;
+    for (unsigned j = 0; j < q.sq_m; j++) {
+        const unsigned Kq = q.sq_groups_total > j ? (q.sq_groups_total - j + q.sq_m - 1u) / q.sq_m : 0u;
+        for (unsigned k = 0; k < Kq; k += (Kq > 4096u ? 97u : 1u)) {
+            const unsigned G = k * q.sq_m + j;
+            CHECK(G < q.sq_groups_total);
+            const unsigned set = q.sq_groups_per_set == 1u ? G : (unsigned)(((unsigned long long)G * q.sq_magic) >> 32);   // as slx_stream_kernel
+            CHECK(set == G / q.sq_groups_per_set && set < (unsigned)n_sets);
+        }
+        seen += Kq;
+    }
+    CHECK(seen == q.sq_groups_total);
+    // the largest offsets the kernel forms in 32 bits
+    CHECK((unsigned long long)((unsigned)h + q.sq_rows * q.interleave) * (unsigned)w * 8ull < (1ull << 32));
+}
+
 static void test_plans()
 {
+    for (int w : {1920, 1280, 640, 4096, 516, 64, 252})
+        for (int h : {1200, 720, 150, 37, 7, 3000})
+            for (int n : {1, 2, 9, 32, 256, 4000})
+                for (int rows : {0, 2, 3, 4, 16})
+                    if ((unsigned long long)w * h * 12ull * (unsigned)n < (1ull << 40)) check_stream_plan(w, h, n, 3, rows);
+    CHECK(g_stream_plans > 300);
     std::mt19937 rng(11);
     const int shapes[][2] = {{1920, 1200}, {1280, 1024}, {1280, 720}, {640, 480}, {4096, 3000}, {4, 1}, {8, 1200}, {500, 5}, {1920, 150}, {1920, 37}, {4096, 130}, {64, 20}, {252, 3000}, {4092, 17}};
     for (const auto &s : shapes)

@@ -8,7 +8,7 @@
 
 namespace { constexpr int kNoDevice = (int)hipErrorNoDevice; }
 
-int slx_launch_fused(const SlxKParams &, int, bool, int, int, void *, const SlxTuning *) { return kNoDevice; }
+int slx_launch_fused(const SlxKParams &, int, bool, int, int, void *, const SlxTuning *, SlxStreamState *) { return kNoDevice; }
 int slx_launch_cloud_count(const SlxKParams &, const double *, unsigned *, unsigned *, void *) { return kNoDevice; }
 int slx_launch_cloud_write(const SlxKParams &, const double *, const unsigned *, const unsigned *, double *, unsigned *, unsigned *, void *) { return kNoDevice; }
 int slx_launch_strip_regression(const uint8_t *, size_t, int, int, int, float *, float *, void *, const float *, const float *, float *) { return kNoDevice; }

@@ -117,6 +117,42 @@ def test_gray_only(api, oracle, synth, bits, width):
     assert np.array_equal(got, ref)
 
 
+@pytest.mark.parametrize("name,shape,n_sets", [("C4", (516, 71), 9), ("C2", (320, 33), 40), ("C1", (192, 150), 16), ("C4", (1920, 150), 6)])
+def test_stream_kernel_geometries_and_repeated_launches(api, oracle, synth, torch_cuda, name, shape, n_sets):
+    """slx_stream_kernel (resident waves taking short items from per-column queues): every rows-per-item choice on ragged tiles
+    against the oracle; the queue counters carry over from launch to launch of one geometry (three launches each) and are zeroed
+    when the geometry changes (item length, frame-set count, back and forth); a launch on a caller's stream in between;
+    slx_last_kernel says which kernel ran."""
+    torch = torch_cuda
+    spec = small_spec(synth, name, *shape)
+    H, W = spec["height"], spec["width"]
+    sets = [synth.random_planes(spec, seed=7000 + s)[0] for s in range(n_sets)]
+    refs = [oracle.pipeline(spec, p, None, want=("z",))["z"] for p in sets]
+    ph = torch.from_numpy(np.stack(sets)).cuda()
+    side = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    with api.Context(spec) as ctx:
+        ctx.set_variant(2)
+        for rows, n in ((2, n_sets), (3, n_sets), (2, n_sets), (7, n_sets - 1), (16, 2), (0, n_sets), (4, n_sets)):
+            ctx.set_tuning(stream=2, stream_rows=rows)
+            for rep in range(3):
+                z = torch.full((n, H, W), -7.0, dtype=torch.float64, device="cuda")
+                torch.cuda.synchronize()
+                ctx.decode_batch(n, ph[:n], None, z, stream=side.cuda_stream if rep == 1 else None)
+                ctx.synchronize()
+                torch.cuda.synchronize()
+                assert ctx.last_kernel().startswith("slx_stream_kernel"), ctx.last_kernel()
+                for k in range(n):
+                    assert np.array_equal(z[k].cpu().numpy(), refs[k], equal_nan=True), (rows, n, rep, k)
+        ctx.set_tuning(stream=1)
+        z = torch.full((n_sets, H, W), -7.0, dtype=torch.float64, device="cuda")
+        torch.cuda.synchronize()
+        ctx.decode_batch(n_sets, ph, None, z)
+        ctx.synchronize()
+        assert ctx.last_kernel().startswith("slx_strip_kernel")
+        assert np.array_equal(z[0].cpu().numpy(), refs[0], equal_nan=True)
+
+
 def test_gray_and_phase_groups_far_apart_in_memory(api, oracle, synth, torch_cuda):
     """The two plane groups of a batch are separate allocations and may sit anywhere: here more than 2 GiB apart, in either order
     (the Gray planes ride the DMA ring through a descriptor of their own; round 3's single descriptor made such a launch fall back
