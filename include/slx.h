@@ -230,7 +230,8 @@ int slx_track_image_buffer(slx_ctx *ctx, uint8_t **buffer, size_t *stride_bytes)
  *  slx_track_stage_frames = only the transfer: the images land in a device slab of the context (*device_images, width bytes per row,
  *                           height x width per image), for a loop that needs every frame's outputs (CCalculation::CalculateOther
  *                           writes a point cloud per frame): slx_track_next(ctx, *device_images + f * height * width, width,
- *                           SLX_MEM_DEVICE) per frame.  The slab stays valid until the second staging call after this one.
+ *                           SLX_MEM_DEVICE) per frame.  The slab stays valid until the second staging call after this one -- or
+ *                           until a staging / buffer call asks for more frames than any call before it (the slabs then grow).
  *  slx_track_frames_buffer= the pinned slab the NEXT staging call (or host-fed batch) of up to n_frames images copies from, for a
  *                           producer that can write there directly (passing it back skips the library's own copy). */
 #define SLX_TRACK_MAX_BATCH 256
