@@ -94,6 +94,27 @@ def load_oracle():
     return O
 
 
+def cgroup_cpu_quota():
+    """CPUs' worth of time the process's cgroup grants (cgroup v2 cpu.max, v1 cfs quota), or None when unlimited / unknown."""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else float(q) / float(per)
+    except Exception:
+        pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else q / per
+    except Exception:
+        return None
+
+
+def usable_cpus():
+    n = len(os.sched_getaffinity(0))
+    q = cgroup_cpu_quota()
+    return max(1, min(n, int(q + 0.5))) if q else n
+
+
 def cpu_baseline(O, spec, phase_np, gray_np=None, budget_s=12.0):
     """The oracle (CPU restatement, reference loop order, one thread) timed on whole frame-sets of
     the same workload until ~budget_s of CPU work; then once more on all host cores."""
@@ -113,7 +134,9 @@ def cpu_baseline(O, spec, phase_np, gray_np=None, budget_s=12.0):
                 break
     except OSError:
         pass
-    host = {"cpu_model": model, "host_logical_cpus": os.cpu_count(), "cpus_this_process_may_use": len(os.sched_getaffinity(0))}
+    quota = cgroup_cpu_quota()
+    host = {"cpu_model": model, "host_logical_cpus": os.cpu_count(), "cpus_in_affinity_mask": len(os.sched_getaffinity(0)),
+            "cgroup_cpu_quota": quota, "cpus_this_process_may_use": usable_cpus()}
     single = {"value": n / dt, "unit": "frames/s", "cores": 1, "kind": "port", **host,
               "sample": "%d frame-sets of %dx%d (%s), oracle/slx_oracle.c single thread, reference loop order, %.1f s" % (
                   n, spec["width"], spec["height"], spec["name"], dt)}
@@ -128,8 +151,10 @@ def cpu_baseline(O, spec, phase_np, gray_np=None, budget_s=12.0):
                 break
         return {"value": m / dt2, "unit": "frames/s", "cores": cores, "kind": "port", **host,
                 "sample": "%d frame-sets, row-parallel OpenMP on %d threads, %.1f s" % (m, cores, dt2)}
-    # every CPU this process may use; and, beside it, 16 threads -- the 1-GPU box's nominal share of its host (rounds 1-3 reported that figure)
-    usable = len(os.sched_getaffinity(0))
+    # every CPU this process may use -- the affinity mask capped by the cgroup's CPU quota (a 1-GPU box shows all 256 logical CPUs of its
+    # host in the mask and grants 16 CPUs' worth of time: 256 threads there only time-slice) -- and, beside it when that is more than
+    # 16, the 16-thread figure rounds 1-3 reported
+    usable = usable_cpus()
     multi = row_parallel(usable, budget_s / 3)
     if usable > 16:
         multi["with_16_threads"] = row_parallel(16, budget_s / 4)
@@ -704,7 +729,7 @@ def run_rank(args):
             sample = phase[: min(4, n_sets)].cpu().numpy()
             gsample = gray[: min(4, n_sets)].cpu().numpy() if gray is not None else None
             cpu_single, cpu_multi = cpu_baseline(O, spec, sample, gsample)
-            ref = O.pipeline(spec, sample[0], None if gsample is None else gsample[0], want=("z",), threads=min(len(os.sched_getaffinity(0)), 16))["z"]
+            ref = O.pipeline(spec, sample[0], None if gsample is None else gsample[0], want=("z",), threads=min(usable_cpus(), 16))["z"]
             got = z[0].cpu().numpy()
             parity = bool(np.array_equal(got, ref, equal_nan=True))
             if not parity:
@@ -718,7 +743,7 @@ def run_rank(args):
             #                (R/CCalculation.cpp:756-771); its OWN bytes, 20 + 24 + 8 = 52 B/px, never mixed into the 20 B/px figure
             #   C4x1, REFx1  ONE frame-set per launch: the call the reference makes (CCalculation::CalculateFirst)
             other = {}
-            threads = min(len(os.sched_getaffinity(0)), 16)
+            threads = min(usable_cpus(), 16)
             for label, name, sets, aux in (("C3", "C3", OTHER_SETS["C3"], ()), ("C5", "C5", OTHER_SETS["C5"], ()), ("REF", "REF", OTHER_SETS["REF"], ()),
                                            ("C2", "C2", OTHER_SETS["C2"], ()),
                                            ("C4+xyUk", "C4", 16, ("x", "y", "U", "k")), ("C4x1", "C4", 1, ()), ("REFx1", "REF", 1, ()),
