@@ -165,6 +165,74 @@ def cpu_baseline(O, spec, phase_np, gray_np=None, budget_s=12.0):
 OTHER_SETS = {"C3": 16, "C5": 4, "REF": 32, "C2": 80}
 
 
+SMI_CMD = ["/opt/rocm/bin/rocm-smi", "--showpower", "--showclocks", "--showmaxpower", "--json"]
+
+
+def smi_sample(device_index):
+    """One reading of the card's power management (sysfs through rocm-smi, no GPU context): socket power, its cap, shader clock.
+    None when the tool is missing or prints something else."""
+    import re
+    import subprocess
+    try:
+        out = subprocess.run(SMI_CMD[:1] + ["-d", str(device_index)] + SMI_CMD[1:], capture_output=True, text=True, timeout=10).stdout
+        card = json.loads(out[out.index("{"):])
+        card = card.get("card%d" % device_index, card)
+    except Exception:
+        return None
+    got = {}
+    for key, val in card.items():
+        m = re.search(r"-?\d+(\.\d+)?", str(val))
+        if not m:
+            continue
+        if key.startswith("Current Socket"):
+            got["socket_w"] = float(m.group(0))
+        elif key.startswith("Max Graphics Package Power"):
+            got["cap_w"] = float(m.group(0))
+        elif key.startswith("sclk clock speed"):
+            got["sclk_mhz"] = float(m.group(0))
+    return got or None
+
+
+def power_window(step, sync, device_index, seconds=1.5):
+    """What the card's power management does under THIS workload: `step` launched back to back for `seconds` (after the timed
+    region, never inside it) while a thread reads rocm-smi.  The Gray-free 4-step kernels sit on the 1400 W cap and the shader
+    clock falls from 2.4 to ~1.8 GHz (tools/power_probe.py) -- that clock, not the nominal one, is what the
+    launch time has to be read against."""
+    import statistics
+    import threading
+    if not os.path.exists(SMI_CMD[0]):
+        return None
+    samples, stop = [], threading.Event()
+
+    def reader():
+        while not stop.is_set():
+            got = smi_sample(device_index)
+            if got:
+                samples.append(got)
+            stop.wait(0.1)
+    th = threading.Thread(target=reader, daemon=True)
+    t0 = time.perf_counter()
+    for _ in range(50):
+        step()
+    th.start()
+    while time.perf_counter() - t0 < seconds:
+        for _ in range(50):
+            step()
+        sync()
+    stop.set()
+    th.join(15)
+    samples = samples[1:] if len(samples) > 2 else samples       # the first reading may straddle the start
+    if not samples:
+        return None
+    out = {"window_s": round(time.perf_counter() - t0, 2), "samples": len(samples), "source": "rocm-smi while the headline step runs back to back, after the timed region"}
+    for key in ("socket_w", "cap_w", "sclk_mhz"):
+        vals = [smp[key] for smp in samples if key in smp]
+        out[key] = statistics.median(vals) if vals else None
+    if out.get("socket_w") and out.get("cap_w"):
+        out["at_power_cap"] = bool(out["socket_w"] >= 0.98 * out["cap_w"])
+    return out
+
+
 def traffic_entry(config, n_sets):
     """HBM bytes per launch from the committed PMC capture (not measured in this run): value, provenance."""
     tp = os.path.join(ROOT, "profiles", "traffic.json")
@@ -265,6 +333,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-traffic-probe", action="store_true",
                     help="N = 1: do not measure roofline.traffic in this run (two short child runs of this script under `rocprofv3 --pmc`, "
                          "before this process touches the GPU); the committed capture of profiles/traffic.json is replayed instead")
+    ap.add_argument("--no-power-probe", action="store_true",
+                    help="N = 1: do not read the card's power management (socket power, cap, shader clock; rocm-smi) while the headline step runs "
+                         "back to back for 1.5 s after the timed region (reported as `power`)")
     ap.add_argument("--traffic-probe-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--no-gather", action="store_true",
                     help="N > 1: skip the gather timings (decode + RCCL gather of the depth maps to rank 0, reported as with_gather)")
@@ -513,6 +584,12 @@ def run_rank(args):
     t_local, kernel_ms = timed(step, args.steps)      # HIP events on the stream the kernel is launched on
     fence()
     t_max, kernel_ms_max = max_over_ranks([t_local, kernel_ms])
+    power = None
+    if world == 1 and not args.no_power_probe:
+        try:
+            power = power_window(step, torch.cuda.synchronize, dev_index)
+        except Exception as e:                      # a reading beside the measurement, never a reason to lose the measurement
+            power = {"error": "%s: %s" % (type(e).__name__, e)}
 
     def make_result(gather, cpu_single=None, cpu_multi=None, parity=None, other=None, headline=None):
         """N = 1: `value` is the decode (there is nothing to gather).  N > 1: `value` is north_star's split END TO END -- every
@@ -554,7 +631,7 @@ def run_rank(args):
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": ctx.last_kernel(), "launch_ms": kernel_ms_max,
                          "algorithmic_bytes_per_launch": bytes_per_launch},
-            "achieved_hbm_gbps_per_gpu": achieved, "kernel_only": kernel_only,
+            "achieved_hbm_gbps_per_gpu": achieved, "kernel_only": kernel_only, "power": power,
             # rccl_world_size: ncclCommCount of the communicator the gather ran on (slx_comm_info asks RCCL), null when no RCCL
             # communicator existed (N = 1, --no-gather, the one-GPU gloo rehearsal); torch's own count sits beside it
             "rccl_world_size": rccl_info["world"], "rccl_rank_of_rank0": rccl_info["rank"], "torch_world_size": (dist.get_world_size() if world > 1 else 1),
