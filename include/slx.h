@@ -27,6 +27,7 @@
  *                                                           one rank per GPU, the final depth-map gather over RCCL
  *   cv::FileStorage (calibration) R/CCalculation.cpp:124  -> slx_read_calibration_yaml
  *   cv::imread (CSensor)          R/CSensorV.cpp:111      -> slx_read_bmp_gray / slx_read_pgm_gray (+ slx::CSensor, csrc/sensor.hpp)
+ *   CCalculation::Result (file)   R/CCalculation.cpp:323  -> slx_get_point_cloud + slx_write_point_cloud_text
  *   CSensor::GetCamPicture loop   R/CSensorV.cpp:171      -> slx_pipe_* (pinned host slots, copy/decode overlap)
  *   CCalculation::Result          R/CCalculation.cpp:323  -> slx_get_point_cloud / slx_point_cloud_of_depth (+ slx::CCalculation::Result text writer)
  *   CCalculation::CalculateOther  R/CCalculation.cpp:208  -> slx_track_begin / slx_track_next (+ slx::CCalculation::CalculateOther)
@@ -366,6 +367,11 @@ int slx_decode_gather(slx_comm *comm, slx_ctx *ctx, const slx_shard *shards, int
 int slx_read_bmp_gray(const char *path, uint8_t *pixels, size_t capacity, int *rows, int *cols);
 /* Same contract for a binary PGM (P5, maxval <= 255), the other 8-bit format cv::imread takes. */
 int slx_read_pgm_gray(const char *path, uint8_t *pixels, size_t capacity, int *rows, int *cols);
+/* The point-cloud text file of CCalculation::Result (R/CCalculation.cpp:323-357): "x y z\n" per point, every number as
+ * `ostream << double` prints it (%g, 6 significant digits) -- the same bytes as that loop, formatted by several threads and
+ * written without its flush per line (2.27 M points: 0.1 s instead of 3.6 s).  xyz: host memory, 3 doubles per point, the
+ * layout slx_get_point_cloud fills.  SLX_ERR_UNAVAILABLE: the file cannot be written. */
+int slx_write_point_cloud_text(const char *path, const double *xyz, size_t n_points);
 /* CamMat, ProMat, R, T of the cv::FileStorage YAML Init reads (R/CCalculation.cpp:124-132; format of R/Result.yml). */
 int slx_read_calibration_yaml(const char *path, double cam[9], double pro[9], double rot[9], double trans[3]);
 

@@ -30,7 +30,7 @@ SYMBOLS = [
     "slx_validate_config", "slx_create", "slx_destroy", "slx_last_error", "slx_set_gray_lut",
     "slx_set_frame", "slx_decode", "slx_decode_batch", "slx_synchronize", "slx_get_stream", "slx_get_output",
     "slx_get_depth", "slx_get_point_cloud", "slx_point_cloud_of_depth", "slx_track_begin", "slx_track_next", "slx_track_image_buffer", "slx_track_next_batch", "slx_track_stage_frames", "slx_track_frames_buffer", "slx_output_device_ptr", "slx_get_calibration", "slx_enable_timing",
-    "slx_last_decode_ms", "slx_debug_stamps", "slx_set_variant", "slx_set_tuning", "slx_last_kernel", "slx_read_bmp_gray", "slx_read_pgm_gray", "slx_read_calibration_yaml", "slx_version",
+    "slx_last_decode_ms", "slx_debug_stamps", "slx_set_variant", "slx_set_tuning", "slx_last_kernel", "slx_read_bmp_gray", "slx_read_pgm_gray", "slx_read_calibration_yaml", "slx_write_point_cloud_text", "slx_version",
     "slx_decode_batch_ex", "slx_comm_unique_id", "slx_comm_create", "slx_comm_adopt", "slx_comm_destroy", "slx_comm_info", "slx_comm_last_error",
     "slx_comm_synchronize", "slx_gather_depth", "slx_decode_gather", "slx_gather_plan",
     "slx_pipe_create", "slx_pipe_destroy", "slx_pipe_layout", "slx_pipe_acquire", "slx_pipe_submit", "slx_pipe_collect", "slx_pipe_last_error",
@@ -140,6 +140,7 @@ def lib():
         L.slx_read_bmp_gray.argtypes = [C.c_char_p, vp, sz, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.slx_read_pgm_gray.argtypes = [C.c_char_p, vp, sz, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.slx_read_calibration_yaml.argtypes = [C.c_char_p] + [C.POINTER(C.c_double)] * 4
+        L.slx_write_point_cloud_text.argtypes = [C.c_char_p, vp, sz]
         L.slx_pipe_create.argtypes = [vp, C.POINTER(SlxPipeConfig), C.POINTER(vp)]
         L.slx_pipe_destroy.argtypes = [vp]
         L.slx_pipe_destroy.restype = None
@@ -633,6 +634,17 @@ def read_bmp_gray(path):
 def read_pgm_gray(path):
     """uint8 [rows, cols] of a binary PGM (P5, maxval <= 255)."""
     return _read_gray_file(lib().slx_read_pgm_gray, path)
+
+
+def write_point_cloud_text(path, xyz):
+    """The text file CCalculation::Result writes (R/CCalculation.cpp:323-357): "x y z" per line, numbers as `ostream << double`
+    prints them.  xyz: float64 [n, 3] (what Context.point_cloud returns)."""
+    a = np.ascontiguousarray(xyz, dtype=np.float64)
+    if a.ndim != 2 or a.shape[1] != 3:
+        raise ValueError("xyz must be [n, 3]")
+    rc = lib().slx_write_point_cloud_text(os.fsencode(path), a.ctypes.data if a.size else None, a.shape[0])
+    if rc != OK:
+        raise SlxError(rc, "cannot write %s" % path)
 
 
 def read_calibration_yaml(path):

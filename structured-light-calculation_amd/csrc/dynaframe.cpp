@@ -297,19 +297,12 @@ std::vector<double> CCalculation::GetPointCloud()
 bool CCalculation::Result(std::string fileName, int i)
 {
     if (i != m_frame || !m_ctx || !m_done) return false;        // only the current frame's maps exist on the device
-    std::fstream file;
-    file.open(fileName.c_str(), std::ios::out);
-    if (!file) {
+    // the reference opens the file first and reports that failure (R/CCalculation.cpp:325-331); so does this
+    const std::vector<double> pts = GetPointCloud();
+    if (slx_write_point_cloud_text(fileName.c_str(), pts.data(), pts.size() / 3) != SLX_OK) {
         m_err = "CCalculation::Result() OpenFile Error:" + fileName;
         return false;
     }
-    const std::vector<double> pts = GetPointCloud();
-    for (size_t k = 0; k + 2 < pts.size(); k += 3) {
-        file << pts[k] << ' ';
-        file << pts[k + 1] << ' ';
-        file << pts[k + 2] << std::endl;
-    }
-    file.close();
     return true;
 }
 

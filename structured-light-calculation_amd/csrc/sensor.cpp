@@ -1,12 +1,16 @@
 // sensor.cpp -- see sensor.hpp.  Host-only file I/O; nothing here touches the GPU.
 #include "sensor.hpp"
 
+#include <algorithm>
+#include <charconv>
+#include <cmath>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <sstream>
+#include <thread>
 
 namespace slx {
 
@@ -291,6 +295,62 @@ bool ReadPgmGray(const std::string &path, std::vector<uint8_t> &pixels, int &row
     return true;
 }
 
+namespace {
+
+constexpr size_t kNumberChars = 24;        // "-1.23457e-308" is 13; a non-finite value printed by snprintf stays far below this too
+constexpr size_t kLineChars = 3 * kNumberChars + 3;
+
+// one number as `ostream << double` prints it; returns the end
+char *put_number(char *out, double v)
+{
+    if (std::isfinite(v)) return std::to_chars(out, out + kNumberChars, v, std::chars_format::general, 6).ptr;
+    return out + std::snprintf(out, kNumberChars, "%g", v);          // nan / inf with their signs: the C library's own spelling
+}
+
+size_t format_points(const double *xyz, size_t n, char *out)
+{
+    char *o = out;
+    for (size_t i = 0; i < n; i++) {
+        o = put_number(o, xyz[3 * i + 0]);
+        *o++ = ' ';
+        o = put_number(o, xyz[3 * i + 1]);
+        *o++ = ' ';
+        o = put_number(o, xyz[3 * i + 2]);
+        *o++ = '\n';
+    }
+    return (size_t)(o - out);
+}
+
+}  // namespace
+
+bool WritePointCloudText(const std::string &path, const double *xyz, size_t n_points)
+{
+    if (n_points && !xyz) return false;
+    std::FILE *f = std::fopen(path.c_str(), "w");
+    if (!f) return false;
+    // rounds of at most `threads` blocks of 64 Ki points: ~6 MB of text per block, so a 12-million-point cloud never holds more
+    // than ~100 MB of it; formatting is ~80 ns per number, the write of a round a few milliseconds
+    constexpr size_t kBlock = 65536;
+    const unsigned hw = std::thread::hardware_concurrency();
+    const size_t threads = std::max<size_t>(1, std::min<size_t>({hw ? hw : 1u, 16u, (n_points + kBlock - 1) / kBlock}));
+    std::vector<std::vector<char>> text(threads);
+    std::vector<size_t> len(threads, 0);
+    bool ok = true;
+    for (size_t first = 0; first < n_points && ok; first += threads * kBlock) {
+        auto work = [&](size_t t) {
+            const size_t a = std::min(n_points, first + t * kBlock), b = std::min(n_points, a + kBlock);
+            text[t].resize((b - a) * kLineChars);
+            len[t] = format_points(xyz + 3 * a, b - a, text[t].data());
+        };
+        std::vector<std::thread> pool;
+        for (size_t t = 1; t < threads; t++) pool.emplace_back(work, t);
+        work(0);
+        for (std::thread &th : pool) th.join();
+        for (size_t t = 0; t < threads && ok; t++) ok = len[t] == 0 || std::fwrite(text[t].data(), 1, len[t], f) == len[t];
+    }
+    return (std::fclose(f) == 0) && ok;
+}
+
 }  // namespace slx
 
 // ---- plain-C access to the file readers (declared in include/slx.h) ----
@@ -322,6 +382,12 @@ int slx_read_pgm_gray(const char *path, uint8_t *pixels, size_t capacity, int *r
     if (capacity < px.size()) return SLX_ERR_INVALID_ARG;
     std::memcpy(pixels, px.data(), px.size());
     return SLX_OK;
+}
+
+int slx_write_point_cloud_text(const char *path, const double *xyz, size_t n_points)
+{
+    if (!path || (n_points && !xyz)) return SLX_ERR_INVALID_ARG;
+    return slx::WritePointCloudText(path, xyz, n_points) ? SLX_OK : SLX_ERR_UNAVAILABLE;
 }
 
 int slx_read_calibration_yaml(const char *path, double cam[9], double pro[9], double rot[9], double trans[3])

@@ -27,6 +27,12 @@ bool ReadPgmGray(const std::string &path, std::vector<uint8_t> &pixels, int &row
 // The calibration file Init reads: YAML 1.0 with !!opencv-matrix blocks named CamMat, ProMat, R, T.
 bool ReadCalibrationYaml(const std::string &path, Calibration &calib);
 
+// The text file CCalculation::Result writes (R/CCalculation.cpp:323-357): one "x y z" line per point, every number as
+// `ostream << double` prints it (precision 6, %g).  Same bytes as that loop, without its flush per line: the numbers are formatted
+// by std::to_chars(general, 6) -- specified to give printf("%.6g")'s characters, which is what operator<< gives -- by several
+// threads into memory, and written out in order.  xyz: 3 doubles per point.  False when the file cannot be written.
+bool WritePointCloudText(const std::string &path, const double *xyz, size_t n_points);
+
 class CSensor {
 public:
     explicit CSensor(const StaticParameters &sp = StaticParameters(), int dynaFrameMaxNum = 100);

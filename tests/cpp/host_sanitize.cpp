@@ -8,6 +8,9 @@
 #include <cstdio>
 #include <cstring>
 #include <fstream>
+#include <iterator>
+#include <limits>
+#include <sstream>
 #include <random>
 #include <string>
 #include <vector>
@@ -143,6 +146,51 @@ static void test_yaml_and_gray_table(const std::string &dir)
     std::vector<int16_t> lut;
     CHECK(slx::ReadGrayCodeFile(g, 8, lut) && lut.size() == 8 && lut[1] == 1);
     CHECK(!slx::ReadGrayCodeFile(dir + "/none.txt", 8, lut));
+}
+
+// The point-cloud text file against the loop it replaces (R/CCalculation.cpp:351-353: `file << x << ' ' << y << ' ' << z << endl`):
+// the same bytes for ordinary coordinates, every exponent range, values that round up to the next power of ten at six digits,
+// zeros, infinities and NaNs of both signs, and for point counts on and around the writer's block size.
+static void test_point_cloud_text(const std::string &dir)
+{
+    const std::string p = dir + "/cloud.txt";
+    auto reference = [](const std::vector<double> &xyz) {
+        std::ostringstream os;
+        for (size_t k = 0; k + 2 < xyz.size(); k += 3) {
+            os << xyz[k] << ' ';
+            os << xyz[k + 1] << ' ';
+            os << xyz[k + 2] << std::endl;
+        }
+        return os.str();
+    };
+    auto file_bytes = [&]() {
+        std::ifstream f(p.c_str(), std::ios::in | std::ios::binary);
+        return std::string((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+    };
+    const double inf = std::numeric_limits<double>::infinity(), nan = std::numeric_limits<double>::quiet_NaN();
+    std::vector<double> special = {0.0, -0.0, 1.0, -1.0, 999999.5, 999999.4, 0.0001, 0.00009999995, 0.000099999949, 123456.5, 1234565.0, 1e-5, 1e5, 1e6, 1e-300, -1e300,
+                                   5e-324, -5e-324, 1.7976931348623157e308, inf, -inf, nan, -nan, 0.1, 2.5, 3.5, 1234.5678, -987.654321, 100000.5, 99999.95, 0.30000000000000004, 123.4565,
+                                   123.4575, 1e21, 1e22, 1e23};
+    while (special.size() % 3) special.push_back(42.0);
+    CHECK(slx::WritePointCloudText(p, special.data(), special.size() / 3) && file_bytes() == reference(special));
+    uint64_t x = 88172645463325252ull;
+    auto next = [&]() { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return x; };
+    for (size_t n : {(size_t)0, (size_t)1, (size_t)2, (size_t)65535, (size_t)65536, (size_t)65537, (size_t)200001}) {
+        std::vector<double> xyz(3 * n);
+        for (size_t i = 0; i < xyz.size(); i++) {
+            const uint64_t r = next();
+            if (i % 7 == 0) {                                             // any bit pattern: every exponent, denormals, NaNs
+                std::memcpy(&xyz[i], &r, sizeof r);
+            } else {                                                      // the range a depth map lives in
+                xyz[i] = ((double)(r >> 11) / 9007199254740992.0 - 0.3) * 1500.0;
+            }
+        }
+        CHECK(slx_write_point_cloud_text(p.c_str(), n ? xyz.data() : nullptr, n) == SLX_OK);
+        CHECK(file_bytes() == reference(xyz));
+    }
+    CHECK(slx_write_point_cloud_text(nullptr, nullptr, 0) == SLX_ERR_INVALID_ARG);
+    CHECK(slx_write_point_cloud_text(p.c_str(), nullptr, 5) == SLX_ERR_INVALID_ARG);
+    CHECK(slx_write_point_cloud_text((dir + "/no/such/directory/cloud.txt").c_str(), special.data(), 1) == SLX_ERR_UNAVAILABLE);
 }
 
 static slx_config base_config(int w, int h, int mode, int F, int N, int G)
@@ -359,6 +407,7 @@ int main(int argc, char **argv)
     test_bmp(dir);
     test_pgm(dir);
     test_yaml_and_gray_table(dir);
+    test_point_cloud_text(dir);
     test_validate_and_create();
     test_plans();
     test_gather_plans();

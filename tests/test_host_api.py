@@ -222,3 +222,24 @@ def test_calibration_yaml_reader(api, synth, tmp_path, golden_dir):
     (tmp_path / "short.yml").write_text(text.replace("ProMat", "Other"))
     with pytest.raises(api.SlxError):
         api.read_calibration_yaml(str(tmp_path / "short.yml"))
+
+
+def test_point_cloud_text_writer(api, tmp_path):
+    """CCalculation::Result's file (R/CCalculation.cpp:351-353: `file << x << ' ' << y << ' ' << z << endl`): operator<< prints a double
+    as printf("%g") does, and so does Python's "%g" for finite values.  (The C++ test in tests/cpp/host_sanitize.cpp compares with
+    operator<< itself, NaNs and all, under ASan.)"""
+    rng = np.random.default_rng(7)
+    xyz = (rng.random((70001, 3)) - 0.3) * 1500.0
+    xyz[::5] = rng.standard_normal((xyz[::5].shape[0], 3)) * 10.0 ** rng.integers(-12, 12, size=(xyz[::5].shape[0], 1))
+    xyz[:6] = [[0.0, -0.0, 1.0], [999999.5, 999999.4, 0.0001], [0.00009999995, 123456.5, 1234565.0], [1e-300, -1e300, 5e-324],
+               [np.inf, -np.inf, 2.5], [100000.5, 99999.95, 123.4565]]
+    path = str(tmp_path / "cloud.txt")
+    api.write_point_cloud_text(path, xyz)
+    want = "".join("%g %g %g\n" % tuple(p) for p in xyz)
+    assert open(path).read() == want
+    api.write_point_cloud_text(path, np.empty((0, 3)))
+    assert open(path).read() == ""
+    with pytest.raises(ValueError):
+        api.write_point_cloud_text(path, np.zeros((4, 2)))
+    with pytest.raises(api.SlxError):
+        api.write_point_cloud_text(str(tmp_path / "no" / "such" / "dir" / "cloud.txt"), xyz[:1])
