@@ -832,10 +832,9 @@ def run_rank(args):
                 try:
                     ospec = synth.make_spec(name)
                     oH, oW = ospec["height"], ospec["width"]
-                    # fresh allocations for every entry: tensors carved out of blocks the caching allocator kept from earlier entries sit
-                    # on whatever physical backing those blocks had, and the wide kernels (x, y, U, k beside z: 17 streams per wave) run
-                    # 15-18 % slower on an unlucky one (tools/aux_layout.py: 316-320 us on separately allocated tensors in 9 of 9 runs,
-                    # 317-377 us on one 1.5 GB arena with the same offsets) -- that was the run-to-run bimodality of C4+xyUk
+                    # fresh allocations for every entry, not blocks the caching allocator kept from the entries before: the wide kernel
+                    # (x, y, U, k beside z: 17 streams per wave) has two speeds 15-18 % apart depending on the physical backing of its
+                    # buffers (tools/aux_layout.py).  This removes one source of that, not the effect
                     torch.cuda.empty_cache()
                     oph, ogr = make_batch(torch, synth, ospec, sets, device, seed=0x5EED + sum(map(ord, label)))
                     if oph.shape[1] == 0:
