@@ -584,6 +584,43 @@ def run_rank(args):
     t_local, kernel_ms = timed(step, args.steps)      # HIP events on the stream the kernel is launched on
     fence()
     t_max, kernel_ms_max = max_over_ranks([t_local, kernel_ms])
+    # the fraction of the nominal peak AND of what a plain device copy reaches on this box -- torch's copy
+    # kernel over the depth maps of one launch (read + write of 0.59 GB), after the timed region, 30 copies behind 5 untimed ones
+    device_copy = None
+    if world == 1:
+        try:
+            z2 = torch.empty_like(z)
+            for _ in range(5):
+                z2.copy_(z)
+            c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            c0.record()
+            for _ in range(30):
+                z2.copy_(z)
+            c1.record()
+            torch.cuda.synchronize()
+            copy_gbps = 2.0 * z.numel() * z.element_size() * 30 / (c0.elapsed_time(c1) * 1e-3) / 1e9
+            device_copy = {"gbps": copy_gbps, "frac_of_peak": copy_gbps / HBM_PEAK_GBPS,
+                           "what": "torch copy_ of one launch's depth maps, read + write counted, 30 copies"}
+            del z2
+        except Exception as e:
+            device_copy = {"error": "%s: %s" % (type(e).__name__, e)}
+    # ... and of what the launch's ACCESS PATTERN reaches with the arithmetic left out (tools/membench: 12 u8 planes of 32 frame-sets of
+    # 1920x1200 read with dword loads, one f64 plane written with lane-contiguous nontemporal stores; its "F" row is a plain 16-byte
+    # copy of the same bytes), a child process of its own, C4 x 32 only (the pattern is compiled in)
+    access_pattern = None
+    membench = os.path.join(ROOT, "tools", "membench")
+    if world == 1 and args.config == "C4" and args.sets_per_gpu == 32 and os.path.exists(membench):
+        try:
+            import re
+            import subprocess
+            out = subprocess.run([membench], capture_output=True, text=True, timeout=120).stdout
+            rows = {m.group(1).strip(): float(m.group(2)) * 1e3 for m in re.finditer(r"^(\S+)\s.*?([0-9.]+) TB/s\s*$", out, re.M)}
+            if "B'" in rows:
+                access_pattern = {"gbps": rows["B'"], "copy16_gbps": rows.get("F"), "best_gbps": max(rows.values()),
+                                  "what": "tools/membench B': the headline launch's bytes, dword loads + lane-contiguous nontemporal stores, no arithmetic; "
+                                          "copy16: a plain 16-byte copy of the same number of bytes"}
+        except Exception as e:
+            access_pattern = {"error": "%s: %s" % (type(e).__name__, e)}
     power = None
     if world == 1 and not args.no_power_probe:
         try:
@@ -630,7 +667,10 @@ def run_rank(args):
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": ctx.last_kernel(), "launch_ms": kernel_ms_max,
-                         "algorithmic_bytes_per_launch": bytes_per_launch},
+                         "algorithmic_bytes_per_launch": bytes_per_launch,
+                         "device_copy": device_copy, "access_pattern": access_pattern,
+                         "frac_of_access_pattern": (achieved / access_pattern["gbps"]) if access_pattern and access_pattern.get("gbps") else None,
+                         "frac_of_device_copy": (achieved / device_copy["gbps"]) if device_copy and device_copy.get("gbps") else None},
             "achieved_hbm_gbps_per_gpu": achieved, "kernel_only": kernel_only, "power": power,
             # rccl_world_size: ncclCommCount of the communicator the gather ran on (slx_comm_info asks RCCL), null when no RCCL
             # communicator existed (N = 1, --no-gather, the one-GPU gloo rehearsal); torch's own count sits beside it
