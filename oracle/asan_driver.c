@@ -82,8 +82,11 @@ int main(void)
         }
     }
     /* the tracker and its blur on a few shapes */
-    for (int k = 0; k < 6; k++) {
-        const int w = 23 + (int)(rnd() % 80), h = 22 + (int)(rnd() % 60), win = 21;
+    /* ... including images the window does not fit in (fewer rows or columns than the window: strips of zeros, no access
+     * outside the image -- tools/fuzz_track.py found the reference's out-of-image reads restated here) and other windows */
+    for (int k = 0; k < 40; k++) {
+        const int w = k < 6 ? 23 + (int)(rnd() % 80) : 1 + (int)(rnd() % 70), h = k < 6 ? 22 + (int)(rnd() % 60) : 1 + (int)(rnd() % 50);
+        const int win = k < 6 ? 21 : 1 + 2 * (int)(rnd() % 16);
         uint8_t *cam = malloc((size_t)w * h);
         for (int i = 0; i < w * h; i++) cam[i] = (uint8_t)rnd();
         float *W0 = calloc((size_t)w * h, 4), *B0 = calloc((size_t)w * h, 4), *W1 = calloc((size_t)w * h, 4), *B1 = calloc((size_t)w * h, 4), *dP = calloc((size_t)w * h, 4);

@@ -309,6 +309,12 @@ size_t slxo_point_cloud(const slxo_config *cfg, const double *z, double *xyz)
 void slxo_strip_regression(const uint8_t *cam, size_t stride, int W, int H, int win, float *stripW, float *stripB)
 {
     const int hw = win / 2;
+    memset(stripW, 0, sizeof(float) * (size_t)W * H);                                /* :827-828 */
+    memset(stripB, 0, sizeof(float) * (size_t)W * H);
+    /* An image without an interior (no column or no row a whole window fits around): the reference's loops over w are empty when
+     * W <= 2 hw, and when only H <= 2 hw its first loop reads rows past the image (:810, undefined behaviour there).  The strips
+     * stay 0 here, which is what the product defines for that case (csrc/slx_track.hip: slx_launch_strip_regression_only). */
+    if (win < 1 || H <= 2 * hw || W <= 2 * hw) return;
     float *valSum = (float *)calloc((size_t)W * H, sizeof(float));                 /* :799-801 setTo(0) */
     for (int w = hw; w < W - hw; w++) {                                              /* :802 */
         float sum = 0;
@@ -321,8 +327,6 @@ void slxo_strip_regression(const uint8_t *cam, size_t stride, int W, int H, int 
             valSum[(size_t)h * W + w] = valSum[(size_t)(h - 1) * W + w]
                 - (float)cam[(size_t)(h - hw - 1) * stride + w]
                 + (float)cam[(size_t)(h + hw) * stride + w];                         /* :820-822 */
-    memset(stripW, 0, sizeof(float) * (size_t)W * H);                                /* :827-828 */
-    memset(stripB, 0, sizeof(float) * (size_t)W * H);
     for (int h = hw; h < H - hw; h++) {
         for (int w = hw; w < W - hw; w++) {
             float max = valSum[(size_t)h * W + w], maxIdx = 0;                       /* :834-837 */
