@@ -104,8 +104,66 @@ def run_case(case, seed):
     return kernel, bad
 
 
+def run_big(seed):
+    """FUZZ_PROFILE=big: launches that fill the chip many times over -- where the planner takes the stream kernel by itself -- on random
+    widths / heights / frame-set counts of the Gray-free 4-step class: the automatic plan, the strip kernel (stream=1) and the stream
+    kernel with another item length must agree bit for bit on every frame-set, and three frame-sets are compared with the oracle."""
+    rng = np.random.default_rng(seed)
+    W = int(rng.integers(64, 513)) * 4
+    H = int(rng.integers(150, 1301))
+    F = int(rng.integers(1, 5))
+    n = int(max(2, min(48, rng.integers(20, 120) * 1000000 // (W * H))))
+    periods = [min(W, 1 << 14)]
+    for _ in range(F - 1):
+        periods.append(max(2, periods[-1] // int(rng.integers(2, 11))))
+    spec = {"name": "fuzz", "width": W, "height": H, "row_offset": int(rng.integers(0, 2000)) if rng.random() < 0.3 else 0, "proj_width": W, "mode": 3,
+            "n_freq": F, "n_steps": 4, "periods": periods, "gray_bits": 0, "gray_stripe": 0, "gray_lut": None,
+            "fov_min": 100.0, "fov_max": 1000.0, "calib": synth.scaled_calibration(W, H, W)}
+    g = torch.Generator(device="cuda")
+    g.manual_seed(seed)
+    ph = torch.randint(0, 256, (n, 4 * F, H, W), dtype=torch.uint8, device="cuda", generator=g)
+    outs = []
+    kernels = []
+    torch.cuda.synchronize()
+    with api.Context(spec) as ctx:
+        for tune in ({}, {"stream": 1}, {"stream": 2, "stream_rows": int(rng.choice([2, 3, 4, 7]))}):
+            ctx.set_tuning(stream=0, stream_rows=0)
+            if tune:
+                ctx.set_tuning(**tune)
+            z = torch.full((n, H, W), -7.0, dtype=torch.float64, device="cuda")
+            torch.cuda.synchronize()
+            for rep in range(2):                                     # twice: the queue counters carry over
+                ctx.decode_batch(n, ph, None, z)
+            ctx.synchronize()
+            torch.cuda.synchronize()
+            outs.append(z)
+            kernels.append(ctx.last_kernel().split(":")[0])
+    bad = []
+    for a in (1, 2):
+        if not torch.equal(outs[0].view(torch.int64), outs[a].view(torch.int64)):
+            bad.append(("plan %d differs from the automatic plan" % a, kernels))
+    for s_ in sorted({0, n - 1, int(rng.integers(0, n))}):
+        ref = O.pipeline(spec, ph[s_].cpu().numpy(), None, want=("z",), threads=16)["z"]
+        if not np.array_equal(outs[0][s_].cpu().numpy(), ref, equal_nan=True):
+            bad.append(("frame-set %d differs from the oracle" % s_, kernels))
+    return "big: " + " / ".join(kernels), bad, {"W": W, "H": H, "F": F, "n_sets": n, "periods": periods}
+
+
 t_end = time.time() + budget
 stats, failures, i = {}, 0, 0
+while PROFILE == "big" and time.time() < t_end:
+    seed = seed0 * 100003 + i
+    i += 1
+    try:
+        label, bad, what = run_big(seed)
+        if bad:
+            failures += 1
+            print(json.dumps({"MISMATCH": str(bad[:4]), "seed": seed, "case": what}), flush=True)
+    except Exception as e:
+        failures += 1
+        label = "error"
+        print(json.dumps({"ERROR": "%s: %s" % (type(e).__name__, e), "seed": seed}), flush=True)
+    stats[label] = stats.get(label, 0) + 1
 while time.time() < t_end:
     seed = seed0 * 100003 + i
     i += 1
