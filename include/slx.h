@@ -137,7 +137,9 @@ int slx_set_gray_lut(slx_ctx *ctx, const int16_t *lut, size_t n);
 /* Hands over input plane `idx` of `group` (GRAY: 2b = pattern, 2b+1 = inverse of bit b,
  * bit 0 = LSB; PHASE: f*N + k).  SLX_MEM_HOST: the bytes are copied to the device before
  * the call returns to the caller's buffer being reusable (deep copy, like pic.copyTo).
- * SLX_MEM_DEVICE: the pointer is borrowed until the next decode has completed. */
+ * SLX_MEM_DEVICE: the pointer is borrowed until the next decode has completed.  Frames may come with any row strides;
+ * when the planes of a decode do not all share one (the kernels take one), the odd ones are copied to the context's
+ * staging pitch on the device at decode time, as SetMat copies every image -- a common stride avoids that copy. */
 int slx_set_frame(slx_ctx *ctx, int group, int idx, const uint8_t *data, size_t stride_bytes,
                   int mem_kind);
 

@@ -535,15 +535,38 @@ int slx_decode(slx_ctx *ctx, void *stream)
     if (!ctx) return SLX_ERR_INVALID_ARG;
     SlxKParams kp = ctx->kp;
     size_t stride = 0;
+    bool mixed = false;
     for (auto *v : {&ctx->phase, &ctx->gray}) {
         for (size_t i = 0; i < v->size(); i++) {
             const Plane &p = (*v)[i];
             if (!p.set) return fail(ctx, SLX_ERR_MISSING_FRAME, "%s plane %zu was never set", v == &ctx->phase ? "phase" : "gray", i);
             if (stride == 0) stride = p.stride;
-            if (p.stride != stride)
-                return fail(ctx, SLX_ERR_INVALID_ARG, "all input planes of one decode must share one row stride (%zu vs %zu); "
-                            "host frames are staged at pitch %zu", p.stride, stride, ctx->staging_pitch);
+            mixed = mixed || p.stride != stride;
             (v == &ctx->phase ? kp.phase : kp.gray)[i] = p.dev;
+        }
+    }
+    if (mixed) {
+        // The kernels take ONE row stride for all planes of a decode.  Frames of different pitches (device images borrowed from
+        // several buffers, or mixed with host frames, which sit in the staging slab at its pitch) are brought to the staging pitch
+        // the way SetMat brings every image into the decoder (pic.copyTo, R/CDecodePhase.cpp:114): a device-to-device copy into
+        // the plane's own staging slot, on the decode's stream, ahead of the launch.  The borrowed pointer stays what it was.
+        SLX_HIP(ctx, hipSetDevice(ctx->device));
+        hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+        if (int rc0 = order_after_done(ctx, s)) return rc0;            // the last decode may still read the staging slots
+        stride = ctx->staging_pitch;
+        for (auto *v : {&ctx->phase, &ctx->gray}) {
+            for (size_t i = 0; i < v->size(); i++) {
+                Plane &p = (*v)[i];
+                if (p.stride == stride) continue;
+                if (!p.owned) {
+                    uint8_t *&slab = v == &ctx->gray ? ctx->gray_slab : ctx->phase_slab;
+                    const size_t plane_bytes = ctx->staging_pitch * (size_t)ctx->cfg.height;
+                    if (!slab) SLX_HIP(ctx, hipMalloc((void **)&slab, plane_bytes * v->size()));
+                    p.owned = slab + i * plane_bytes;
+                }
+                SLX_HIP(ctx, hipMemcpy2DAsync(p.owned, stride, p.dev, p.stride, (size_t)ctx->cfg.width, (size_t)ctx->cfg.height, hipMemcpyDeviceToDevice, s));
+                (v == &ctx->phase ? kp.phase : kp.gray)[i] = p.owned;
+            }
         }
     }
     kp.row_stride = stride;

@@ -651,6 +651,39 @@ def test_device_frames_strides_and_batch(api, oracle, synth, torch_cuda):
                 assert np.array_equal(zb[s], ref[s], equal_nan=True), (pitch, s)
 
 
+def test_frames_of_different_row_strides_in_one_decode(api, oracle, synth, torch_cuda):
+    """SetMat takes any image (pic.copyTo, R/CDecodePhase.cpp:114): host frames (staged at the width rounded up to 4), strided host
+    frames and device frames borrowed from buffers of three different pitches, mixed within ONE frame-set and changed between
+    decodes -- on the context's stream and on a caller's.  (tools/fuzz_api.py met the error this used to be.)"""
+    torch = torch_cuda
+    side = torch.cuda.Stream()
+    for name, w, h in (("C3", 124, 64), ("C1x4", 156, 9), ("C2", 78, 33), ("C3", 61, 40)):
+        spec = small_spec(synth, name, w, h)
+        ph, gr = synth.random_planes(spec, seed=w + h)
+        with api.Context(spec) as ctx:
+            keep = []
+            for rnd in range(3):
+                for grp, planes in ((api.GROUP_PHASE, ph), (api.GROUP_GRAY, gr)):
+                    for i in range(0 if planes is None else planes.shape[0]):
+                        planes[i] = np.random.default_rng(1000 * rnd + 37 * i + grp).integers(0, 256, size=(h, w), dtype=np.uint8)
+                        how = (i + rnd + grp) % 4
+                        if how == 0:
+                            ctx.set_frame(grp, i, planes[i])
+                        elif how == 1:
+                            wide = np.zeros((h, w + 12), dtype=np.uint8)
+                            wide[:, :w] = planes[i]
+                            ctx.set_frame(grp, i, wide[:, :w])
+                        else:
+                            dev = torch.zeros((h, w + (0, 0, 4, 64)[how] + 8 * rnd), dtype=torch.uint8, device="cuda")
+                            dev[:, :w] = torch.from_numpy(planes[i]).cuda()
+                            keep.append(dev)
+                            ctx.set_frame(grp, i, dev[:, :w])
+                torch.cuda.synchronize()
+                ctx.decode(stream=side.cuda_stream if rnd == 1 else None)
+                ref = oracle.pipeline(spec, ph, gr, want=("z",))["z"]
+                assert np.array_equal(ctx.get_depth(), ref, equal_nan=True), (name, w, h, rnd)
+
+
 def test_decode_on_caller_stream_and_timing(api, oracle, synth, torch_cuda):
     torch = torch_cuda
     spec = small_spec(synth, "C2", 256, 64)
