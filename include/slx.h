@@ -295,7 +295,8 @@ int slx_last_kernel(slx_ctx *ctx, char *buf, size_t buf_bytes);
  * Slot life cycle: acquire (host fills the pinned input) -> submit -> collect (oldest submitted first; the host reads
  * the pinned result) -> the slot is free again at its next acquire.  acquire fails with SLX_ERR_NOT_CONFIGURED when every
  * slot is submitted or collected-but-not-yet-reused in an order that leaves none free (collect first).
- * One pipe per context; the context's own frames / outputs (slx_set_frame, slx_decode) are not touched. */
+ * One pipe per context; the context's own frames / outputs (slx_set_frame, slx_decode) are not touched.  A pipe is used
+ * only while its context lives; it may be DESTROYED before or after it. */
 typedef struct slx_pipe slx_pipe;
 typedef struct {
     int slots;            /* >= 2 */

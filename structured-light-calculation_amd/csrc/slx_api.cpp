@@ -1067,6 +1067,7 @@ struct slx_pipe {
         unsigned long long ticket = 0;                             // submit order
     };
     slx_ctx *ctx = nullptr;
+    int device = 0;                                                // the context's device, kept here: slx_pipe_destroy may run after slx_destroy
     slx_pipe_config cfg{};
     std::vector<Slot> slot;
     hipStream_t s_in = nullptr, s_dec = nullptr, s_out = nullptr;
@@ -1103,7 +1104,7 @@ int pipe_fail(slx_pipe *p, int code, const char *fmt, ...)
 void slx_pipe_destroy(slx_pipe *p)
 {
     if (!p) return;
-    (void)hipSetDevice(p->ctx->device);
+    (void)hipSetDevice(p->device);                                 // not through p->ctx: the context may be gone already
     for (hipStream_t s : {p->s_in, p->s_dec, p->s_out})
         if (s) (void)hipStreamSynchronize(s);
     for (auto &sl : p->slot) {
@@ -1127,6 +1128,7 @@ int slx_pipe_create(slx_ctx *ctx, const slx_pipe_config *cfg, slx_pipe **out)
     if (cfg->sets_per_slot < 1 || cfg->sets_per_slot > 4096) return fail(ctx, SLX_ERR_INVALID_ARG, "sets_per_slot must be in [1,4096] (got %d)", cfg->sets_per_slot);
     slx_pipe *p = new slx_pipe;
     p->ctx = ctx;
+    p->device = ctx->device;
     p->cfg = *cfg;
     p->n_phase = (int)ctx->phase.size();
     p->n_gray = (int)ctx->gray.size();

@@ -772,6 +772,30 @@ def test_pipe_destroyed_before_its_context(api, oracle, synth):
     assert np.array_equal(got.reshape(ref.shape), ref, equal_nan=True)
 
 
+def test_context_destroyed_before_its_pipe(api, oracle, synth):
+    """The other order: the context goes first, with a slot of the pipe still in flight; the pipe is destroyed afterwards (it
+    keeps the device number itself and waits for its own streams) and a second context on the same device works on."""
+    spec = small_spec(synth, "C2", 128, 40)
+    ph, _ = synth.random_planes(spec, seed=78)
+    ref = oracle.pipeline(spec, ph, None, want=("z",))["z"]
+    ctx = api.Context(spec)
+    pipe = api.Pipe(ctx, slots=3, sets_per_slot=2, host_result=True)
+    W = spec["width"]
+    for _ in range(2):
+        buf = pipe.acquire()
+        buf[0, :, :, :W] = ph
+        buf[1, :, :, :W] = ph
+        pipe.submit(2)
+    got = np.array(pipe.collect(), copy=True)
+    ctx.close()                         # one slot is still submitted
+    pipe.close()
+    assert np.array_equal(got[0], ref, equal_nan=True) and np.array_equal(got[1], ref, equal_nan=True)
+    with api.Context(spec) as again:
+        again.set_frames(ph, None)
+        again.decode()
+        assert np.array_equal(again.get_depth(), ref, equal_nan=True)
+
+
 def test_error_paths_on_device(api, synth):
     spec = small_spec(synth, "C1x4", 32, 8)
     ph, gr = synth.random_planes(spec, seed=1)

@@ -62,13 +62,17 @@ def one_case(seed):
     trk = None                                                       # tracker model: dict(sw, sb, window) once begun
     side = torch.cuda.Stream()
     ctx = api.Context(spec, aux=aux)
+    # the ingest pipe of the same context, used in between (include/slx.h: the context's own frames / outputs are not touched)
+    pipe, pipe_slots, pipe_sets = None, int(rng.integers(2, 5)), int(rng.integers(1, 4))
+    pipe_free, pipe_acquired, pipe_queue = 0, None, []               # model: free slots, the acquired slot's buffer, submitted slots' references
+    primary = "z"
     try:
         if rng.random() < 0.5:
             expect_error(lambda: ctx.decode(), "decode without frames")
         expect_error(lambda: ctx.get_output("z"), "get_output before any decode")
         n_ops = int(rng.integers(8, 40))
         for _ in range(n_ops):
-            op = int(rng.integers(0, 12))
+            op = int(rng.integers(0, 16))
             have_all = all(f is not None for f in frames["p"]) and all(f is not None for f in frames["g"])
             if op <= 2:                                              # a frame, or all of them
                 targets = [(g, i) for g in ("p", "g") for i in range(len(frames[g]))]
@@ -193,12 +197,67 @@ def one_case(seed):
                     ctx.synchronize()
                 else:
                     ctx.enable_timing(bool(rng.random() < 0.5))
+            elif op >= 12:                                           # the ingest pipe
+                if pipe is None:
+                    host_result = bool(rng.random() < 0.7)
+                    pipe = api.Pipe(ctx, slots=pipe_slots, sets_per_slot=pipe_sets, host_result=host_result)
+                    pipe_free = pipe_slots
+                    say("pipe", pipe_slots, pipe_sets, host_result)
+                    expect_error(lambda: pipe.collect(), "collect with nothing submitted")
+                    expect_error(lambda: pipe.submit(), "submit without an acquired slot")
+                    continue
+                what = int(rng.integers(0, 3))
+                if what == 0 and pipe_acquired is None:
+                    if pipe_free == 0:
+                        expect_error(lambda: pipe.acquire(), "acquire with every slot in flight")
+                        continue
+                    buf = pipe.acquire()
+                    pipe_free -= 1
+                    n = int(rng.integers(1, pipe_sets + 1))
+                    data = rng.integers(0, 256, size=(n, pipe.n_planes, h, w), dtype=np.uint8)
+                    buf[:n, :, :, :w] = data
+                    pipe_acquired = data
+                    say("pipe.acquire", n)
+                elif what == 1 and pipe_acquired is not None:
+                    n = pipe_acquired.shape[0]
+                    if rng.random() < 0.1:
+                        expect_error(lambda: pipe.submit(pipe_sets + 1), "more frame-sets than the slot holds")
+                    pipe.submit(n)
+                    refs = [O.pipeline(spec, pipe_acquired[s_, :n_phase] if n_phase else None, pipe_acquired[s_, n_phase:] if n_gray else None, want=(primary,))[primary]
+                            for s_ in range(n)]
+                    pipe_queue.append(refs)
+                    pipe_acquired = None
+                    say("pipe.submit", n)
+                elif what == 2 and pipe_queue:
+                    refs = pipe_queue.pop(0)
+                    got = pipe.collect()
+                    if pipe.host_result:
+                        if got.shape[0] != len(refs):
+                            raise Mismatch("pipe.collect gave %d frame-sets, %d were submitted" % (got.shape[0], len(refs)))
+                        for s_ in range(len(refs)):
+                            same("pipe result %d" % s_, got[s_], refs[s_])
+                    else:
+                        addr, n = got
+                        if n != len(refs):
+                            raise Mismatch("pipe.collect gave %d frame-sets, %d were submitted" % (n, len(refs)))
+                        dev = torch.empty((n, h, w), dtype=torch.float64, device="cuda")
+                        torch.cuda.synchronize()
+                        import ctypes
+                        hip = ctypes.CDLL("libamdhip64.so")
+                        if hip.hipMemcpy(ctypes.c_void_p(dev.data_ptr()), ctypes.c_void_p(addr), ctypes.c_size_t(n * h * w * 8), 3) != 0:
+                            raise Mismatch("hipMemcpy of the pipe's device result failed")
+                        for s_ in range(n):
+                            same("pipe device result %d" % s_, dev[s_].cpu().numpy(), refs[s_])
+                    pipe_free += 1
+                    say("pipe.collect")
         if cur is not None:                                           # whatever happened: the planes at the end
             for p in planes:
                 same("final get_output(%s)" % p, ctx.get_output(p), cur[p])
     except (Mismatch, api.SlxError) as e:
         return {"seed": seed, "config": name, "w": w, "h": h, "planes": planes, "what": "%s: %s" % (type(e).__name__, e), "last_calls": log[-12:]}
     finally:
+        if pipe is not None and rng.random() < 0.7:                  # else: the context goes first (slx_destroy handles a live pipe)
+            pipe.close()
         ctx.close()
     return None
 
