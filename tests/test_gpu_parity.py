@@ -796,6 +796,53 @@ def test_context_destroyed_before_its_pipe(api, oracle, synth):
         assert np.array_equal(again.get_depth(), ref, equal_nan=True)
 
 
+def test_contexts_on_concurrent_host_threads(api, oracle, synth, torch_cuda):
+    """One context per host thread (the library keeps no state outside a context but a thread-local error string; ctypes drops
+    the GIL during a call, so the calls really overlap): four threads, four configurations, host-fed single decodes, batch
+    decodes on a stream of their own, read-backs and point clouds interleaved, every result against the oracle."""
+    import threading
+    torch = torch_cuda
+    jobs = []
+    for k, (name, w, h) in enumerate((("C2", 256, 48), ("C3", 200, 40), ("C1x4", 128, 64), ("C5", 192, 33))):
+        spec = small_spec(synth, name, w, h)
+        sets = [synth.random_planes(spec, seed=900 + 10 * k + s) for s in range(3)]
+        refs = [oracle.pipeline(spec, p, g, want=("z",))["z"] for p, g in sets]
+        jobs.append((spec, sets, refs))
+    errors = []
+
+    def worker(spec, sets, refs):
+        try:
+            H, W = spec["height"], spec["width"]
+            stream = torch.cuda.Stream()
+            dev_p = torch.from_numpy(np.stack([p for p, _ in sets])).cuda()
+            dev_g = None if sets[0][1] is None else torch.from_numpy(np.stack([g for _, g in sets])).cuda()
+            torch.cuda.synchronize()
+            with api.Context(spec) as ctx:
+                for rep in range(12):
+                    s = rep % len(sets)
+                    ctx.set_frames(*sets[s])
+                    ctx.decode()
+                    assert np.array_equal(ctx.get_depth(), refs[s], equal_nan=True), ("decode", spec["name"], rep)
+                    if rep % 3 == 0:
+                        assert np.array_equal(ctx.get_point_cloud(), oracle.point_cloud(spec, refs[s])), ("cloud", spec["name"], rep)
+                    z = torch.full((len(sets), H, W), -1.0, dtype=torch.float64, device="cuda")
+                    torch.cuda.synchronize()
+                    ctx.decode_batch(len(sets), dev_p, dev_g, z, stream=stream.cuda_stream)
+                    stream.synchronize()
+                    for q in range(len(sets)):
+                        assert np.array_equal(z[q].cpu().numpy(), refs[q], equal_nan=True), ("batch", spec["name"], rep, q)
+        except BaseException as e:                # reported by the main thread
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=worker, args=j) for j in jobs]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(300)
+    assert not errors, errors
+    assert not any(t.is_alive() for t in threads)
+
+
 def test_error_paths_on_device(api, synth):
     spec = small_spec(synth, "C1x4", 32, 8)
     ph, gr = synth.random_planes(spec, seed=1)
