@@ -372,7 +372,7 @@ int slx_read_bmp_gray(const char *path, uint8_t *pixels, size_t capacity, int *r
 int slx_read_pgm_gray(const char *path, uint8_t *pixels, size_t capacity, int *rows, int *cols);
 /* The point-cloud text file of CCalculation::Result (R/CCalculation.cpp:323-357): "x y z\n" per point, every number as
  * `ostream << double` prints it (%g, 6 significant digits) -- the same bytes as that loop, formatted by several threads and
- * written without its flush per line (2.27 M points: 0.1 s instead of 3.6 s).  xyz: host memory, 3 doubles per point, the
+ * written without its flush per line (2.27 M points: 0.06 s instead of 3.6 s).  xyz: host memory, 3 doubles per point, the
  * layout slx_get_point_cloud fills.  SLX_ERR_UNAVAILABLE: the file cannot be written. */
 int slx_write_point_cloud_text(const char *path, const double *xyz, size_t n_points);
 /* CamMat, ProMat, R, T of the cv::FileStorage YAML Init reads (R/CCalculation.cpp:124-132; format of R/Result.yml). */

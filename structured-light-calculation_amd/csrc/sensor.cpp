@@ -2,6 +2,7 @@
 #include "sensor.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <charconv>
 #include <cmath>
 #include <cstdint>
@@ -300,9 +301,99 @@ namespace {
 constexpr size_t kNumberChars = 24;        // "-1.23457e-308" is 13; a non-finite value printed by snprintf stays far below this too
 constexpr size_t kLineChars = 3 * kNumberChars + 3;
 
+// One double as printf("%.6g") / `ostream << double` prints it, for the magnitudes a point cloud holds (1e-5 <= |v| < 1e15, and
+// zero), by exact integer arithmetic: the six significant digits are round-half-even of the EXACT binary value scaled by a power
+// of ten (a 128-bit product shifted, or a 64-bit quotient), which is what a correctly rounding printf computes.  Returns the
+// number of characters written, or 0 for a value outside that range (denormals, huge, tiny, non-finite): the caller falls back
+// to std::to_chars.  ~4 x faster than to_chars(general, 6) -- formatting IS the cost of CCalculation::Result.
+struct Digits3 {
+    char t[1000][3];
+    constexpr Digits3() : t()
+    {
+        for (int i = 0; i < 1000; i++) {
+            t[i][0] = (char)('0' + i / 100);
+            t[i][1] = (char)('0' + i / 10 % 10);
+            t[i][2] = (char)('0' + i % 10);
+        }
+    }
+};
+static constexpr Digits3 kDigits3{};
+
+static inline int fmt_g6_fast(double v, char *out)
+{
+    uint64_t bits;
+    std::memcpy(&bits, &v, sizeof bits);
+    char *o = out;
+    if (bits >> 63) *o++ = '-';
+    const uint64_t mag = bits & 0x7fffffffffffffffull;
+    if (mag == 0) { *o++ = '0'; return (int)(o - out); }
+    const int bexp = (int)(mag >> 52);
+    // 1e-5 > 2^-17, 1e15 < 2^50: binary exponents outside [-17, 49] never belong to the range
+    const int k = bexp - 1023;
+    if (k < -17 || k > 49) return 0;
+    const double a = v < 0 ? -v : v;
+    if (!(a >= 1e-5 && a < 1e15)) return 0;
+    const uint64_t m = (mag & 0x000fffffffffffffull) | 0x0010000000000000ull;     // a = m * 2^(k - 52), exactly
+    const int s = 52 - k;                                                          // > 0 in this range: a = m / 2^s
+    static const uint64_t kPow10[20] = {1ull, 10ull, 100ull, 1000ull, 10000ull, 100000ull, 1000000ull, 10000000ull, 100000000ull, 1000000000ull,
+                                        10000000000ull, 100000000000ull, 1000000000000ull, 10000000000000ull, 100000000000000ull,
+                                        1000000000000000ull, 10000000000000000ull, 100000000000000000ull, 1000000000000000000ull,
+                                        10000000000000000000ull};
+    int X = (k * 1233) >> 12;                                                      // floor(k log10 2) for k >= 0, within one of floor(log10 a) always
+    if (k < 0) X = -(((-k) * 1233 + 4095) >> 12);
+    uint64_t q;
+    for (;;) {                                                                     // at most two corrections of the estimate
+        const int p = 5 - X;                                                       // digits = a * 10^p, wanted in [10^5, 10^6)
+        bool up;                                                                   // round the integer part q up?
+        if (p >= 0) {
+            const unsigned __int128 T = (unsigned __int128)m * kPow10[p];          // p <= 10: T < 2^87
+            q = (uint64_t)(T >> s);
+            if (q < 100000ull) { X--; continue; }
+            if (q >= 1000000ull) { X++; continue; }
+            const unsigned __int128 rem = T & ((((unsigned __int128)1) << s) - 1), half = ((unsigned __int128)1) << (s - 1);
+            up = rem > half || (rem == half && (q & 1ull));
+        } else {
+            const uint64_t D = kPow10[-p] << s;                                    // -p <= 9, s <= 33: < 2^63
+            q = m / D;
+            if (q < 100000ull) { X--; continue; }
+            if (q >= 1000000ull) { X++; continue; }
+            const uint64_t rem = m - q * D;
+            up = 2 * rem > D || (2 * rem == D && (q & 1ull));
+        }
+        if (up && ++q == 1000000ull) { q = 100000ull; X++; }
+        break;
+    }
+    char d[6];
+    {
+        const uint32_t q32 = (uint32_t)q, hi = q32 / 1000u, lo = q32 - hi * 1000u;  // two table look-ups instead of six divisions
+        std::memcpy(d, kDigits3.t[hi], 3);
+        std::memcpy(d + 3, kDigits3.t[lo], 3);
+    }
+    int nd = 6;
+    while (nd > 1 && d[nd - 1] == '0') nd--;                                       // %g drops trailing zeros
+    if (X < -4 || X >= 6) {                                                        // scientific
+        *o++ = d[0];
+        if (nd > 1) { *o++ = '.'; for (int i = 1; i < nd; i++) *o++ = d[i]; }
+        *o++ = 'e';
+        int e = X;
+        if (e < 0) { *o++ = '-'; e = -e; } else *o++ = '+';
+        *o++ = (char)('0' + e / 10);
+        *o++ = (char)('0' + e % 10);
+    } else if (X >= 0) {
+        for (int i = 0; i <= X; i++) *o++ = i < nd ? d[i] : '0';
+        if (nd > X + 1) { *o++ = '.'; for (int i = X + 1; i < nd; i++) *o++ = d[i]; }
+    } else {
+        *o++ = '0'; *o++ = '.';
+        for (int i = 0; i < -X - 1; i++) *o++ = '0';
+        for (int i = 0; i < nd; i++) *o++ = d[i];
+    }
+    return (int)(o - out);
+}
+
 // one number as `ostream << double` prints it; returns the end
 char *put_number(char *out, double v)
 {
+    if (const int n = fmt_g6_fast(v, out)) return out + n;
     if (std::isfinite(v)) return std::to_chars(out, out + kNumberChars, v, std::chars_format::general, 6).ptr;
     return out + std::snprintf(out, kNumberChars, "%g", v);          // nan / inf with their signs: the C library's own spelling
 }
@@ -333,21 +424,29 @@ bool WritePointCloudText(const std::string &path, const double *xyz, size_t n_po
     constexpr size_t kBlock = 65536;
     const unsigned hw = std::thread::hardware_concurrency();
     const size_t threads = std::max<size_t>(1, std::min<size_t>({hw ? hw : 1u, 16u, (n_points + kBlock - 1) / kBlock}));
-    std::vector<std::vector<char>> text(threads);
-    std::vector<size_t> len(threads, 0);
-    bool ok = true;
-    for (size_t first = 0; first < n_points && ok; first += threads * kBlock) {
-        auto work = [&](size_t t) {
+    // two sets of buffers: while one round's text is written out (a thread of its own), the next round is formatted
+    std::vector<std::vector<char>> text[2] = {std::vector<std::vector<char>>(threads), std::vector<std::vector<char>>(threads)};
+    std::vector<size_t> len[2] = {std::vector<size_t>(threads, 0), std::vector<size_t>(threads, 0)};
+    std::atomic<bool> ok{true};
+    std::thread writer;
+    int cur = 0;
+    for (size_t first = 0; first < n_points && ok; first += threads * kBlock, cur ^= 1) {
+        auto work = [&, cur](size_t t) {
             const size_t a = std::min(n_points, first + t * kBlock), b = std::min(n_points, a + kBlock);
-            text[t].resize((b - a) * kLineChars);
-            len[t] = format_points(xyz + 3 * a, b - a, text[t].data());
+            text[cur][t].resize((b - a) * kLineChars);
+            len[cur][t] = format_points(xyz + 3 * a, b - a, text[cur][t].data());
         };
         std::vector<std::thread> pool;
         for (size_t t = 1; t < threads; t++) pool.emplace_back(work, t);
         work(0);
         for (std::thread &th : pool) th.join();
-        for (size_t t = 0; t < threads && ok; t++) ok = len[t] == 0 || std::fwrite(text[t].data(), 1, len[t], f) == len[t];
+        if (writer.joinable()) writer.join();                     // the round before: its buffers (the other set) are free again after this
+        writer = std::thread([&, cur] {
+            for (size_t t = 0; t < threads && ok; t++)
+                if (len[cur][t] && std::fwrite(text[cur][t].data(), 1, len[cur][t], f) != len[cur][t]) ok = false;
+        });
     }
+    if (writer.joinable()) writer.join();
     return (std::fclose(f) == 0) && ok;
 }
 

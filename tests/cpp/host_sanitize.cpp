@@ -173,6 +173,17 @@ static void test_point_cloud_text(const std::string &dir)
                                    123.4575, 1e21, 1e22, 1e23};
     while (special.size() % 3) special.push_back(42.0);
     CHECK(slx::WritePointCloudText(p, special.data(), special.size() / 3) && file_bytes() == reference(special));
+    // values that sit EXACTLY on a rounding boundary at six significant digits (the integer-arithmetic formatter rounds half to
+    // even on the exact binary value, like printf): 1000005, 1000015, ... and their binary scalings, both signs
+    {
+        std::vector<double> ties;
+        for (long i = 0; i < 30000; i++) {
+            const double base = (double)(1000005 + 10 * i);
+            for (double v : {base, -base, base / 16, base * 8, base / 1024, base / 65536.0, base / 1048576.0 / 64, base * 1024 * 1024, base / 1073741824.0 / 128}) ties.push_back(v);
+        }
+        while (ties.size() % 3) ties.push_back(0.5);
+        CHECK(slx::WritePointCloudText(p, ties.data(), ties.size() / 3) && file_bytes() == reference(ties));
+    }
     uint64_t x = 88172645463325252ull;
     auto next = [&]() { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return x; };
     for (size_t n : {(size_t)0, (size_t)1, (size_t)2, (size_t)65535, (size_t)65536, (size_t)65537, (size_t)200001}) {
