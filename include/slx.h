@@ -200,6 +200,10 @@ int slx_get_depth(slx_ctx *ctx, double *z, int mem_kind);
  * xyz: room for `capacity_points` triples (host or device per mem_kind); *n_points receives the number of valid points
  * (also when it exceeds the capacity, in which case SLX_ERR_INVALID_ARG is returned and nothing is copied). */
 int slx_get_point_cloud(slx_ctx *ctx, double *xyz, size_t capacity_points, size_t *n_points, int mem_kind);
+/* The same cloud in pinned host memory that the CONTEXT owns: no buffer to size, no call to learn the count first.  *xyz stays
+ * valid until the next point-cloud call on this context (or its destruction); the caller only reads it.  What
+ * slx::CCalculation::Result formats its text file from. */
+int slx_get_point_cloud_view(slx_ctx *ctx, const double **xyz, size_t *n_points);
 /* The same for any depth map of the context's geometry in device memory (height x width f64, contiguous): one plane of
  * slx_decode_batch's output, so that a batch host loop gets CCalculation::Result's data per frame-set without another
  * decode.  Ordered after the context's last launch (whatever stream it ran on); `depth` is borrowed until the call returns. */

@@ -298,8 +298,10 @@ bool CCalculation::Result(std::string fileName, int i)
 {
     if (i != m_frame || !m_ctx || !m_done) return false;        // only the current frame's maps exist on the device
     // the reference opens the file first and reports that failure (R/CCalculation.cpp:325-331); so does this
-    const std::vector<double> pts = GetPointCloud();
-    if (slx_write_point_cloud_text(fileName.c_str(), pts.data(), pts.size() / 3) != SLX_OK) {
+    const double *pts = nullptr;                                   // pinned memory of the context: no vector to size and zero first
+    size_t n = 0;
+    if (slx_get_point_cloud_view(m_ctx, &pts, &n) != SLX_OK) n = 0;      // (as before: a cloud that cannot be had is an empty file)
+    if (slx_write_point_cloud_text(fileName.c_str(), pts, n) != SLX_OK) {
         m_err = "CCalculation::Result() OpenFile Error:" + fileName;
         return false;
     }

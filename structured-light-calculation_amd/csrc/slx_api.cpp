@@ -56,6 +56,7 @@ struct slx_ctx {
     uint8_t *phase_slab = nullptr, *gray_slab = nullptr;
     unsigned *d_cloud_counts = nullptr, *d_cloud_tiles = nullptr;   // slx_cloud_entries() / slx_cloud_tiles() + 1, point-cloud compaction
     double *d_cloud = nullptr;
+    double *h_cloud = nullptr;                                        // pinned, one triple per pixel: slx_get_point_cloud_view
     unsigned *h_cloud_total = nullptr;                                // pinned: the write kernel stores the point count here
     size_t cloud_capacity = 0;
     // dynamic-frame tracker: previous frame's strips, unblurred deltaP, staged camera image
@@ -321,6 +322,7 @@ void slx_destroy(slx_ctx *ctx)
         if (ctx->ev_slab_used[i]) (void)hipEventDestroy(ctx->ev_slab_used[i]);
     }
     if (ctx->h_cloud_total) (void)hipHostFree(ctx->h_cloud_total);
+    if (ctx->h_cloud) (void)hipHostFree(ctx->h_cloud);
     for (hipEvent_t e : {ctx->ev0, ctx->ev1, ctx->ev_done, ctx->ev_track_copied[0], ctx->ev_track_copied[1], ctx->ev_track_used[0], ctx->ev_track_used[1]})
         if (e) (void)hipEventDestroy(e);
     if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
@@ -738,6 +740,26 @@ int slx_point_cloud_of_depth(slx_ctx *ctx, const double *depth, double *xyz, siz
         return SLX_OK;                                              // already written and waited for
     }
     SLX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return SLX_OK;
+}
+
+int slx_get_point_cloud_view(slx_ctx *ctx, const double **xyz, size_t *n_points)
+{
+    if (!ctx || !xyz || !n_points) return SLX_ERR_INVALID_ARG;
+    *xyz = nullptr;
+    *n_points = 0;
+    if (!mode_has_depth(ctx->cfg.mode)) return fail(ctx, SLX_ERR_UNAVAILABLE, "mode %d produces no depth", ctx->cfg.mode);
+    if (!ctx->decoded) return fail(ctx, SLX_ERR_NOT_DECODED, "no decode has run yet");
+    SLX_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t all = (size_t)ctx->cfg.width * (size_t)ctx->cfg.height;
+    if (!ctx->h_cloud) SLX_HIP(ctx, hipHostMalloc((void **)&ctx->h_cloud, all * 3 * sizeof(double), hipHostMallocDefault));
+    // one pass over the device (count, write into the context's device buffer, the total in a pinned word), one copy of exactly
+    // the points into pinned memory: no second pass to learn the size first, no pageable bounce, nothing to zero
+    size_t n = 0;
+    const int rc = slx_point_cloud_of_depth(ctx, (const double *)ctx->out[SLX_OUT_Z], ctx->h_cloud, all, &n, SLX_MEM_HOST);
+    if (rc != SLX_OK) return rc;
+    *xyz = ctx->h_cloud;
+    *n_points = n;
     return SLX_OK;
 }
 

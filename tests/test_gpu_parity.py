@@ -903,13 +903,18 @@ def test_point_cloud(api, oracle, synth, name, shape):
         ctx.set_frames(ph, gr)
         ctx.decode()
         got = ctx.get_point_cloud()
+        view = ctx.get_point_cloud_view()                  # the same cloud in the context's pinned memory, twice (the buffer is reused)
+        assert not view.flags.writeable and np.array_equal(view, ref)
+        assert np.array_equal(np.array(ctx.get_point_cloud_view()), ref)
     assert got.shape == ref.shape and ref.shape[0] > 0
     assert np.array_equal(got, ref)
     # nothing in the FOV -> an empty cloud, not an error
     with api.Context(dict(spec, fov_min=1e9, fov_max=2e9)) as ctx:
+        with pytest.raises(api.SlxError):
+            ctx.get_point_cloud_view()                     # before any decode
         ctx.set_frames(ph, gr)
         ctx.decode()
-        assert ctx.get_point_cloud().shape == (0, 3)
+        assert ctx.get_point_cloud().shape == (0, 3) and ctx.get_point_cloud_view().shape == (0, 3)
 
 
 # ------------------------------------------------------------------ dynamic frames (CCalculation::CalculateOther)

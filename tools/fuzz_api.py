@@ -123,7 +123,7 @@ def one_case(seed):
                 if bogus and rng.random() < 0.3:
                     expect_error(lambda: ctx.get_output(bogus[0]), "a plane that was not enabled (%s)" % bogus[0])
             elif op == 6 and cur is not None:
-                same("point cloud", ctx.get_point_cloud(), O.point_cloud(spec, cur["z"]))
+                same("point cloud", ctx.get_point_cloud() if rng.random() < 0.5 else np.array(ctx.get_point_cloud_view()), O.point_cloud(spec, cur["z"]))
                 say("cloud")
             elif op == 7:                                            # a batch decode into the caller's buffers, context planes untouched
                 n = int(rng.integers(1, 4))
