@@ -149,8 +149,82 @@ def run_big(seed):
     return "big: " + " / ".join(kernels), bad, {"W": W, "H": H, "F": F, "n_sets": n, "periods": periods}
 
 
+def run_bigstrip(seed):
+    """FUZZ_PROFILE=bigstrip: the strip kernel's other classes at scale -- Gray + phase (the reference's mode), the Gray mask, 8 steps,
+    with and without the optional planes -- on random widths / heights / frame-set counts: the automatic plan and two random launch
+    geometries (rows per item, weave, tiers, waves per workgroup, Gray planes off the ring) must agree bit for bit on every plane of
+    every frame-set, and three frame-sets are compared with the oracle."""
+    rng = np.random.default_rng(seed)
+    kind = str(rng.choice(["gray_phase", "mask", "eight", "four_aux"]))
+    W = int(rng.integers(32, 385)) * 4
+    H = int(rng.integers(60, 900))
+    n = int(max(2, min(24, rng.integers(8, 60) * 1000000 // (W * H))))
+    pw = int(rng.choice([W, 1280, 1920]))
+    if kind == "gray_phase":
+        mode, G, n_steps, periods = 2, 6, 4, [max(2, pw // 32)]
+    else:
+        F = int(rng.integers(1, 5))
+        periods = [min(pw, 1 << 14)]
+        for _ in range(F - 1):
+            periods.append(max(2, periods[-1] // int(rng.integers(2, 11))))
+        mode, G, n_steps = (4, int(rng.choice([6, 6, 4])), 4) if kind == "mask" else (3, 0, 8 if kind == "eight" else 4)
+    spec = {"name": "fuzz", "width": W, "height": H, "row_offset": 0, "proj_width": pw, "mode": mode, "n_freq": len(periods), "n_steps": n_steps,
+            "periods": periods, "gray_bits": G, "gray_stripe": max(1, pw // (1 << G)) if G else 0, "gray_lut": synth.standard_gray_lut(G) if G else None,
+            "fov_min": 100.0, "fov_max": 1000.0, "calib": synth.scaled_calibration(W, H, pw)}
+    n_phase, n_gray = synth.n_planes(spec)
+    g = torch.Generator(device="cuda")
+    g.manual_seed(seed)
+    ph = torch.randint(0, 256, (n, n_phase, H, W), dtype=torch.uint8, device="cuda", generator=g)
+    gr = torch.randint(0, 256, (n, n_gray, H, W), dtype=torch.uint8, device="cuda", generator=g) if n_gray else None
+    aux = [p for p in ("x", "y", "U") if rng.random() < 0.5] if (kind == "four_aux" or rng.random() < 0.25) else []
+    if aux and mode in (3, 4) and rng.random() < 0.5:
+        aux.append("mask")
+    dts = {"z": torch.float64, "x": torch.float64, "y": torch.float64, "U": torch.float64, "mask": torch.uint8}
+    results, kernels = [], []
+    torch.cuda.synchronize()
+    with api.Context(spec) as ctx:
+        ctx.set_variant(2)
+        for t in range(3):
+            ctx.set_tuning(strip_rows=0, weave=0, tiers=0, strip_waves=0, tail_pct=0, gray_plain=0, stream=1)
+            if t:
+                ctx.set_tuning(strip_rows=int(rng.choice([1, 2, 3, 5, 8, 12, 16])), weave=int(rng.choice([0, 1, 2, 4, 8])), tiers=int(rng.integers(0, 4)),
+                               strip_waves=int(rng.choice([0, 0, 1, 2, 4])), tail_pct=int(rng.choice([0, 10, 40])), gray_plain=int(rng.random() < 0.2))
+            outs = {name: torch.full((n, H, W), 5 if name == "mask" else -7, dtype=dts[name], device="cuda") for name in ["z"] + aux}
+            torch.cuda.synchronize()
+            ctx.decode_batch_ex(n, ph, gr, **outs)
+            ctx.synchronize()
+            torch.cuda.synchronize()
+            results.append(outs)
+            kernels.append(ctx.last_kernel().split(":")[1].strip()[:28])
+    bad = []
+    for t in (1, 2):
+        for name in ["z"] + aux:
+            a, b = results[0][name], results[t][name]
+            if not torch.equal(a.view(torch.int64) if a.dtype == torch.float64 else a, b.view(torch.int64) if b.dtype == torch.float64 else b):
+                bad.append(("plan %d: %s differs from the automatic plan" % (t, name), kernels))
+    for s_ in sorted({0, n - 1, int(rng.integers(0, n))}):
+        ref = O.pipeline(spec, ph[s_].cpu().numpy(), None if gr is None else gr[s_].cpu().numpy(), want=tuple(["z"] + aux), threads=16)
+        for name in ["z"] + aux:
+            if not np.array_equal(results[0][name][s_].cpu().numpy(), ref[name], equal_nan=True):
+                bad.append(("frame-set %d: %s differs from the oracle" % (s_, name), kernels))
+    return "bigstrip: " + kind + (" +aux" if aux else ""), bad, {"kind": kind, "W": W, "H": H, "n_sets": n, "periods": periods, "aux": aux}
+
+
 t_end = time.time() + budget
 stats, failures, i = {}, 0, 0
+while PROFILE == "bigstrip" and time.time() < t_end:
+    seed = seed0 * 100003 + i
+    i += 1
+    try:
+        label, bad, what = run_bigstrip(seed)
+        if bad:
+            failures += 1
+            print(json.dumps({"MISMATCH": str(bad[:4]), "seed": seed, "case": what}), flush=True)
+    except Exception as e:
+        failures += 1
+        label = "error"
+        print(json.dumps({"ERROR": "%s: %s" % (type(e).__name__, e), "seed": seed}), flush=True)
+    stats[label] = stats.get(label, 0) + 1
 while PROFILE == "big" and time.time() < t_end:
     seed = seed0 * 100003 + i
     i += 1
