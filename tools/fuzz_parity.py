@@ -21,7 +21,7 @@ print("fuzz_parity: %.0f s, seed %d" % (budget, seed0), flush=True)
 
 
 def make_case(rng):
-    mode = int(rng.choice([2, 3, 3, 3, 4, 4]))
+    mode = int(rng.choice([2, 3, 3, 3, 4, 4, 0, 1]))        # 0 / 1: the decoder objects alone (CDecodePhase::Decode -> pix, CDecodeGray::Decode -> gray)
     strip = PROFILE == "strip"
     W = int(rng.integers(1, 321 if strip else 161)) * 4 if (strip or rng.random() < 0.75) else int(rng.integers(4, 700))
     H = int(rng.integers(1, 420 if strip else 140))
@@ -31,6 +31,10 @@ def make_case(rng):
         G = int(rng.integers(1, 9))
         periods = [max(2, pw // (1 << max(G - 1, 0)))]
         n_steps = 4
+    elif mode == 1:
+        G = int(rng.choice([6, 6, 1, 3, 8, 10]))
+        periods = []
+        n_steps = 4
     else:
         F = int(rng.integers(1, 5))
         periods = [min(pw, 1 << 14)]
@@ -38,6 +42,8 @@ def make_case(rng):
             periods.append(max(2, periods[-1] // int(rng.integers(2, 11))))
         n_steps = int(rng.choice([4, 4, 4, 4, 8, 8] if strip else [4, 4, 4, 4, 3, 5, 8, 8, 16]))
         G = int(rng.choice([6, 6, 6, 1, 3, 5, 8])) if mode == 4 else 0
+        if mode == 0 and rng.random() < 0.6:
+            periods, n_steps = periods[:1], 4                      # the reference's decoder: one frequency, four steps (the DMA-ring kernel)
     spec = {"name": "fuzz", "width": W, "height": H, "row_offset": int(rng.integers(0, 3000)) if rng.random() < 0.3 else 0, "proj_width": pw, "mode": mode,
             "n_freq": len(periods), "n_steps": n_steps, "periods": periods, "gray_bits": G,
             "gray_stripe": max(1, pw // (1 << G)) if G else 0, "gray_lut": synth.standard_gray_lut(G) if G else None,
@@ -50,7 +56,7 @@ def make_case(rng):
                              ("tiers", [0, 1, 2, 3]), ("tail_pct", [0, 10, 30]), ("strip_waves", [0, 1, 2, 4]), ("gray_plain", [0, 0, 1]), ("plain_order", [0, 1])):
             if rng.random() < 0.4:
                 case["tune"][key] = int(rng.choice(choices))
-    if rng.random() < 0.5:
+    if rng.random() < 0.5 and mode >= 2:
         pool = ["x", "y", "U"] + (["mask"] if mode in (3, 4) else []) + (["k"] if mode in (3, 4) and len(periods) > 1 else [])
         case["aux"] = [p for p in pool if rng.random() < 0.6]
     return case
@@ -77,7 +83,8 @@ def run_case(case, seed):
         pstride += 1
     per = pstride or hw
     F = spec["n_freq"]
-    outs, shapes = {}, {"z": (1, torch.float64), "x": (1, torch.float64), "y": (1, torch.float64), "U": (1, torch.float64), "mask": (1, torch.uint8), "k": (max(F - 1, 1), torch.int32)}
+    primary = {0: "pix", 1: "gray"}.get(spec["mode"], "z")     # what the batch call's first output holds
+    outs, shapes = {}, {"z": (F if primary == "pix" else 1, torch.float64), "x": (1, torch.float64), "y": (1, torch.float64), "U": (1, torch.float64), "mask": (1, torch.uint8), "k": (max(F - 1, 1), torch.int32)}
     for name in ["z"] + case["aux"]:
         planes_per_set, dt = shapes[name]
         outs[name] = torch.full((n * planes_per_set * per + 64,), -7 if dt != torch.uint8 else 9, dtype=dt, device="cuda")
@@ -92,13 +99,15 @@ def run_case(case, seed):
     torch.cuda.synchronize()
     bad = []
     for s in range(n):
-        ref = O.pipeline(spec, None if ph_h is None else ph_h[s][..., :W], None if gr_h is None else gr_h[s][..., :W], want=tuple(["z"] + case["aux"]))
+        ref = O.pipeline(spec, None if ph_h is None else ph_h[s][..., :W], None if gr_h is None else gr_h[s][..., :W], want=tuple([primary] + case["aux"]))
+        ref["z"] = ref[primary]
         for name in ["z"] + case["aux"]:
             pps = shapes[name][0]
             got = outs[name].cpu().numpy()
-            for q in range(F - 1 if name == "k" else 1):
+            stacked = name == "k" or (name == "z" and primary == "pix")
+            for q in range((F - 1 if name == "k" else F) if stacked else 1):
                 g = got[(s * pps + q) * per:(s * pps + q) * per + hw].reshape(H, W)
-                r = ref[name][q] if name == "k" else ref[name]
+                r = ref[name][q] if stacked else ref[name]
                 if not np.array_equal(g, r, equal_nan=True):
                     bad.append((s, name, q, int(np.sum(~((g == r) | ((g != g) & (r != r)))))))
     return kernel, bad
