@@ -158,6 +158,64 @@ def run_big(seed):
     return "big: " + " / ".join(kernels), bad, {"W": W, "H": H, "F": F, "n_sets": n, "periods": periods}
 
 
+def run_calib(seed):
+    """FUZZ_PROFILE=calib: the triangulation's exactness arguments under calibrations nobody would ship -- entries of the camera /
+    projector matrices, the rotation and the translation scaled by powers of two up to 2^+-40, negated, zeroed; FOV windows that
+    are negative, huge, a single value, or empty of points -- on small tiles, every kernel variant, z / x / y / U against the oracle
+    (divisions by zero and by denormals, infinities and NaNs in the depth included: the oracle divides the IEEE way)."""
+    rng = np.random.default_rng(seed)
+    name = str(rng.choice(["C2", "C1x4", "C3", "C1"]))
+    spec = dict(synth.make_spec(name))
+    W = int(rng.integers(4, 60)) * 4
+    H = int(rng.integers(2, 60))
+    spec["width"], spec["height"] = W, H
+    cal = synth.scaled_calibration(W, H, spec["proj_width"])
+    span = int(rng.choice([3, 12, 40]))                              # mild, strong, absurd
+    for key in ("cam", "pro", "rot", "trans"):
+        vals = list(cal[key])
+        for i in range(len(vals)):
+            r = rng.random()
+            if r < 0.08:
+                vals[i] = 0.0
+            elif r < 0.25:
+                vals[i] = vals[i] * float(2.0 ** int(rng.integers(-span, span + 1)))
+            elif r < 0.33:
+                vals[i] = -vals[i]
+            elif r < 0.36:
+                vals[i] = float(rng.normal()) * float(2.0 ** int(rng.integers(-20, 21)))
+        cal[key] = vals
+    spec["calib"] = cal
+    kind = rng.random()
+    if kind < 0.25:
+        lo = float(rng.normal()) * 10.0 ** int(rng.integers(-3, 8))
+        spec["fov_min"], spec["fov_max"] = lo, lo + abs(float(rng.normal())) * 10.0 ** int(rng.integers(-3, 8))
+    elif kind < 0.35:
+        spec["fov_min"] = spec["fov_max"] = float(rng.normal()) * 100.0
+    elif kind < 0.45:
+        spec["fov_min"], spec["fov_max"] = -1e300, 1e300
+    spec["row_offset"] = int(rng.integers(0, 5000)) if rng.random() < 0.3 else 0
+    ph, gr = synth.random_planes(spec, seed)
+    if rng.random() < 0.3:                                           # structured input: flat planes make U hit exact values (0 among them)
+        ph = np.full_like(ph, int(rng.integers(0, 256)))
+    wants = ("z", "x", "y", "U")
+    ref = O.pipeline(spec, ph, gr, want=wants)
+    bad = []
+    label = "calib: variants"
+    for variant in (0, 1, 3, 2):
+        try:
+            got = api.decode_frameset(spec, ph, gr, want=wants, variant=variant)
+            label += " %d" % variant
+        except api.SlxError as e:
+            if variant == 0:
+                label = "calib: refused (%s)" % str(e)[14:60]
+                break
+            continue                                                 # a variant may decline the operands; the automatic one may only refuse the config
+        for n_ in wants:
+            if not np.array_equal(got[n_], ref[n_], equal_nan=True):
+                bad.append(("variant %d: %s differs in %d elements" % (variant, n_, int(np.sum(~((got[n_] == ref[n_]) | ((got[n_] != got[n_]) & (ref[n_] != ref[n_])))))), name))
+    return label, bad, {"config": name, "W": W, "H": H, "fov": [spec["fov_min"], spec["fov_max"]], "calib": cal}
+
+
 def run_bigstrip(seed):
     """FUZZ_PROFILE=bigstrip: the strip kernel's other classes at scale -- Gray + phase (the reference's mode), the Gray mask, 8 steps,
     with and without the optional planes -- on random widths / heights / frame-set counts: the automatic plan and two random launch
@@ -221,6 +279,21 @@ def run_bigstrip(seed):
 
 t_end = time.time() + budget
 stats, failures, i = {}, 0, 0
+while PROFILE == "calib" and time.time() < t_end:
+    seed = seed0 * 100003 + i
+    i += 1
+    try:
+        label, bad, what = run_calib(seed)
+        if bad:
+            failures += 1
+            print(json.dumps({"MISMATCH": str(bad[:4]), "seed": seed, "case": what}), flush=True)
+    except Exception as e:
+        failures += 1
+        label = "error"
+        print(json.dumps({"ERROR": "%s: %s" % (type(e).__name__, e), "seed": seed}), flush=True)
+    stats[label] = stats.get(label, 0) + 1
+    if failures >= 15:
+        break
 while PROFILE == "bigstrip" and time.time() < t_end:
     seed = seed0 * 100003 + i
     i += 1
