@@ -33,7 +33,7 @@ constexpr int ITER = 16384;
         const TYPE lane = (TYPE)(threadIdx.x & 63u), wave = (TYPE)(blockIdx.x & 7u);                  \
         TYPE a[8], b = (BEXPR), c = (CEXPR);                                                          \
         for (int k = 0; k < 8; k++) a[k] = (TYPE)1 + (lane * (TYPE)8 + (TYPE)k) * (TYPE)(1.0 / 520.0) + wave * (TYPE)(1.0 / 16384.0); \
-        for (int i = 0; i < iters; i++) { BODY8(INS) }                                                \
+        for (int i = 0; i < iters; i += 8) { BODY8(INS) BODY8(INS) BODY8(INS) BODY8(INS) BODY8(INS) BODY8(INS) BODY8(INS) BODY8(INS) }   \
         TYPE s = 0;                                                                                   \
         for (int k = 0; k < 8; k++) s += a[k];                                                        \
         if (s == (TYPE)12345) out[0] = s;                                                             \
@@ -81,7 +81,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
             const float v = 1.f + (lane * 8.f + (float)k) * (1.f / 520.f) + wave * (1.f / 16384.f);   \
             a[k] = f32x2{v, 3.f - v};                                                                 \
         }                                                                                             \
-        for (int i = 0; i < iters; i++) { BODY8(INS) }                                                \
+        for (int i = 0; i < iters; i += 8) { BODY8(INS) BODY8(INS) BODY8(INS) BODY8(INS) BODY8(INS) BODY8(INS) BODY8(INS) BODY8(INS) }   \
         float s = 0;                                                                                  \
         for (int k = 0; k < 8; k++) s += a[k].x + a[k].y;                                             \
         if (s == 12345.f) out[0] = s;                                                                 \
@@ -90,6 +90,10 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 KERNEL(k_fma32, float, I_FMA32, B_CONTRACT, C_UNIT)
 KERNEL(k_mul32, float, I_MUL32, B_NEARONE, C_UNIT)
 KERNEL(k_add32, float, I_ADD32, B_CONTRACT, C_SMALL)
+// the same multiply with a factor of 1.5: the accumulators overflow to +inf within a hundred iterations and stay there -- what
+// tools/valubench's loop did, and why its table showed plain multiplies / adds at half the cycles they take on finite data
+KERNEL(k_mul32_inf, float, I_MUL32, ((TYPE)1.5), C_UNIT)
+KERNEL(k_add32_inf, float, I_ADD32, B_CONTRACT, ((TYPE)3.0e38f))
 KERNEL_PK(k_pkfma, I_PKFMA, B_CONTRACT, C_UNIT)
 KERNEL_PK(k_pkmul, I_PKMUL, B_NEARONE, C_UNIT)
 KERNEL_PK(k_pkadd, I_PKADD, B_CONTRACT, C_SMALL)
@@ -153,6 +157,7 @@ static void launcher(void *out, int blocks) { hipLaunchKernelGGL(K, dim3(blocks)
 static const Entry kTable[] = {
     ENTRY("s_nop", float, k_nop),           ENTRY("v_mov_b32", float, k_mov32),     ENTRY("v_xor_b32", float, k_xor),
     ENTRY("v_mul_f32", float, k_mul32),     ENTRY("v_add_f32", float, k_add32),     ENTRY("v_fma_f32", float, k_fma32),
+    ENTRY("v_mul_f32_inf", float, k_mul32_inf), ENTRY("v_add_f32_inf", float, k_add32_inf),
     ENTRY("v_pk_mul_f32", double, k_pkmul), ENTRY("v_pk_add_f32", double, k_pkadd), ENTRY("v_pk_fma_f32", double, k_pkfma),
     ENTRY("v_sub_f32_sdwa", float, k_subsdwa), ENTRY("v_max3_f32", float, k_max3),  ENTRY("v_min_f32", float, k_min32),
     ENTRY("v_cmp_lt_f32", float, k_cmp32),  ENTRY("v_cndmask_b32", float, k_cndmask), ENTRY("v_rcp_f32", float, k_rcp32),
