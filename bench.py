@@ -697,12 +697,15 @@ def run_rank(args):
             # with exit code 4 without waiting for the device -- a hung collective must not read as a success
             log("[bench] rank %d: with_gather did not finish within %.0f s -- stuck in split=%s phase=%s step=%s"
                 % (rank, args.gather_timeout, progress["split"], progress["phase"], progress["step"]))
+            # headline: set once the row-tile split (north_star's, the line's `value`) has been timed AND its gathered bytes checked; a
+            # side measurement that hangs afterwards costs its own entry, not the headline (every rank holds the same value: it is a
+            # maximum over ranks), and then the ranks leave with 0
             if rank == 0:
                 g = dict(gather)
                 g["error"] = ("the with_gather phase did not finish within %.0f s and was abandoned (rank 0 in split=%s phase=%s step=%s)"
                               % (args.gather_timeout, progress["split"], progress["phase"], progress["step"]))
-                print(json.dumps(make_result(g, headline=None)), flush=True)
-            os._exit(4)
+                print(json.dumps(make_result(g, headline=headline)), flush=True)
+            os._exit(0 if headline is not None else 4)
         watchdog = threading.Timer(args.gather_timeout, gather_stuck)
         watchdog.daemon = True
         watchdog.start()
