@@ -523,6 +523,15 @@ def run_rank(args):
     bpp = synth.algorithmic_bytes_per_pixel(spec)
     bytes_per_launch = n_sets * H * W * bpp
 
+    # The output planes of the C4+xyUk entry (other_configs), one allocation per plane, BEFORE anything else of this process is on
+    # the device: what INTEGRATION.md advises a caller of slx_decode_batch_ex to do -- that launch has three speeds depending on the
+    # physical placement of its buffers, and planes allocated separately in a fresh process got the fast one in every run of
+    # tools/aux_layout.py / aux_vmm.py, planes allocated in a process that already holds gigabytes did not
+    early_aux = None
+    if world == 1 and not args.no_other_configs:
+        c4 = synth.make_spec("C4")
+        early_aux = {name: (torch.empty((16, c4["n_freq"] - 1, c4["height"], c4["width"]), dtype=torch.int32, device=device) if name == "k"
+                            else torch.empty((16, c4["height"], c4["width"]), dtype=torch.float64, device=device)) for name in ("z", "x", "y", "U", "k")}
     t0 = time.perf_counter()
     phase_full, gray_full = make_batch(torch, synth, full_spec, args.sets_per_gpu, device, seed=0x5EED + 4 + rank)
     if full_spec["mode"] in (synth.MODE_PHASE_ONLY, synth.MODE_GRAY_ONLY) and (world > 1 or not args.no_cpu_baseline):
@@ -883,10 +892,13 @@ def run_rank(args):
                     if oph.shape[1] == 0:
                         oph = None                                   # the Gray decoder has no phase planes
                     primary = {synth.MODE_PHASE_ONLY: "pix", synth.MODE_GRAY_ONLY: "gray"}.get(ospec["mode"], "z")   # what the primary output holds
-                    outs = {"z": torch.empty((sets, oH, oW), dtype=torch.float64, device=device)}
-                    for p in aux:
-                        outs[p] = (torch.empty((sets, ospec["n_freq"] - 1, oH, oW), dtype=torch.int32, device=device) if p == "k"
-                                   else torch.empty((sets, oH, oW), dtype=torch.float64, device=device))
+                    if label == "C4+xyUk" and early_aux is not None:
+                        outs = dict(early_aux)                       # allocated first thing, one allocation per plane (above)
+                    else:
+                        outs = {"z": torch.empty((sets, oH, oW), dtype=torch.float64, device=device)}
+                        for p in aux:
+                            outs[p] = (torch.empty((sets, ospec["n_freq"] - 1, oH, oW), dtype=torch.int32, device=device) if p == "k"
+                                       else torch.empty((sets, oH, oW), dtype=torch.float64, device=device))
                     aux_bpp = sum(4 * (ospec["n_freq"] - 1) if p == "k" else 8 for p in aux)
                     torch.cuda.synchronize()
                     with api.Context(ospec, device=dev_index) as octx:
