@@ -31,6 +31,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 PKG = "structured-light-calculation_amd"
 HBM_PEAK_GBPS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+XGMI_LINK_GBPS = 153.0          # one xGMI link between two MI355X of a node (7 per GPU, point to point): the figure SURVEY.md section 8(e) prices the gather with
 
 
 def log(*a):
@@ -655,7 +656,8 @@ def run_rank(args):
         if gathered:
             value = None if headline is None else world * args.sets_per_gpu * args.steps / headline
             ms_per_step = None if headline is None else headline / args.steps * 1e3
-            workload_tail = ", row-tiled over %d GPUs (%d rows of %d each), RCCL gather of the depth tiles to rank 0 included" % (world, full_h // world, full_h)
+            workload_tail = ", row-tiled over %d GPUs (%d rows of %d each), RCCL gather of the depth tiles to rank 0 included (%s shape)" % (
+                world, full_h // world, full_h, headline_shape[0] or "no")
         else:
             value, ms_per_step, workload_tail = kernel_only["value"], kernel_only["ms_per_step"], ""
         return {
@@ -665,13 +667,16 @@ def run_rank(args):
             "config": {"workload": "%s: %dx%d, %d-frequency x %d-step temporal unwrap%s + triangulation, %d frame-sets per GPU per step%s"
                                    % (args.config, W, full_h, spec["n_freq"], spec["n_steps"], " + %d-bit Gray mask" % spec["gray_bits"] if n_gray else "", args.sets_per_gpu, workload_tail),
                        "periods": spec["periods"],
-                       "sharding": (("by row tile (%d rows of %d per GPU), one grouped ncclSend/ncclRecv gather of the depth tiles to rank 0 per step. "
+                       "sharding": (("by row tile (%d rows of %d per GPU), one grouped ncclSend/ncclRecv gather of the depth tiles to rank 0 per chunk of a step, "
+                                     "timed in both gather shapes (with_gather.rows: one message per (peer, frame-set) in place; with_gather.rows_staged: one "
+                                     "per (peer, chunk) + a row-scatter kernel on the root); `value` is the faster one (config.gather_shape). "
                                      "`value` is that split END TO END and is bound by the root's ingest: (N-1)/N of every depth map "
                                      "(%.2f GB per step) arrives over rank 0's N-1 = %d xGMI links, so it is expected BELOW N x the N = 1 value "
                                      "and is not a regression of the decode; the decode alone scales as `kernel_only` (%.0f frames/s here)")
                                     % (full_h // world, full_h, world * args.sets_per_gpu * (full_h - full_h // world) * W * 8 / 1e9, world - 1,
                                        kernel_only["value"]) if gathered else
                                     ("by frame-set" if args.shard == "framesets" or world == 1 else "by row tile (%d rows of %d per GPU, %d frame-sets)" % (H, full_h, n_sets)) + ", no data-path collective"),
+                       "gather_shape": (headline_shape[0] if gathered else None),
                        "kernel_variant": args.variant, "settle_launches": settle, "tuning": tune or None},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
@@ -687,13 +692,17 @@ def run_rank(args):
             "collective_backend": (backend if world > 1 else None),
             "cpu_baseline": cpu_single, "cpu_baseline_all_cores": cpu_multi,
             "parity_vs_oracle": parity, "other_configs": other, "with_gather": gather,
+            # non-null only when the watchdog abandoned the collective phase: which measurement, phase and step hung (exit code 7 or 4)
+            "stuck": stuck_at[0],
         }
 
     # ------------------------------------------------------------------ N > 1: decode + gather, both ways of cutting the batch
     gather = None
     watchdog = None
     rccl_info = {"world": None, "rank": None}
-    headline = None                 # seconds for args.steps steps of decode + gather by rows (MAX over ranks)
+    headline = None                 # seconds for args.steps steps of decode + gather by rows (MAX over ranks), the faster gather shape
+    headline_shape = [None]         # ... and which shape that was
+    stuck_at = [None]               # set by the watchdog: where the collective phase hung
     gather_ok = True
     if world > 1 and not args.no_gather:
         import threading
@@ -707,14 +716,18 @@ def run_rank(args):
             log("[bench] rank %d: with_gather did not finish within %.0f s -- stuck in split=%s phase=%s step=%s"
                 % (rank, args.gather_timeout, progress["split"], progress["phase"], progress["step"]))
             # headline: set once the row-tile split (north_star's, the line's `value`) has been timed AND its gathered bytes checked; a
-            # side measurement that hangs afterwards costs its own entry, not the headline (every rank holds the same value: it is a
-            # maximum over ranks), and then the ranks leave with 0
+            # later measurement that hangs costs its own entry, not the headline (every rank holds the same value: it is a maximum over
+            # ranks) -- the line keeps `value`, names the place in its top-level `stuck` key, and the exit code says a hang happened
+            stuck_at[0] = {"split": progress["split"], "phase": progress["phase"], "step": progress["step"], "rank": rank,
+                           "timeout_s": args.gather_timeout, "headline_valid": headline is not None}
             if rank == 0:
                 g = dict(gather)
                 g["error"] = ("the with_gather phase did not finish within %.0f s and was abandoned (rank 0 in split=%s phase=%s step=%s)"
                               % (args.gather_timeout, progress["split"], progress["phase"], progress["step"]))
                 print(json.dumps(make_result(g, headline=headline)), flush=True)
-            os._exit(0 if headline is not None else 4)
+            # never 0: a hung collective is a fault to be traced (a dead rank, a stuck GPU, the fabric) even when the headline was
+            # already measured and checked -- 7 = "headline valid, a later measurement hung", 4 = "no gathered number at all"
+            os._exit(7 if headline is not None else 4)
         watchdog = threading.Timer(args.gather_timeout, gather_stuck)
         watchdog.daemon = True
         watchdog.start()
@@ -734,11 +747,19 @@ def run_rank(args):
             comm = None
             gather["error"] = "communicator: %s: %s" % (type(e).__name__, e)
         total = world * args.sets_per_gpu
-        # rows: north_star's split and the headline -- exactly args.steps timed steps after args.warmup; framesets: a short side measurement
+        # Three measurements through one communicator:
+        #   rows          north_star's split, the IN-PLACE gather shape: one message per (peer, frame-set) landing at its rows
+        #   rows_staged   the same split, the STAGED shape: one message per (peer, chunk) into a staging slot of the root + a row-scatter
+        #                 kernel that runs while the next chunk arrives (slx_comm_set_gather_shape; csrc/slx_comm.cpp, slx_gather.hip)
+        #   framesets     whole frame-sets per rank, one message per peer and chunk: a short side measurement
+        # Both row shapes run exactly args.steps timed steps after the warm-up; the line's `value` is the faster of the two (the same
+        # split, the same bytes in the same places: config.gather_shape says which), so that the ONE 8-GPU run the driver makes tells
+        # link-bound (both shapes alike, GB/s per link near the xGMI figure) from message-overhead-bound (staged faster).
         side_reps = max(3, min(20, args.steps // 15))
-        for split in ("rows", "framesets"):
+        row_times = {}
+        for key, split, shape in (("rows", "rows", "in_place"), ("rows_staged", "rows", "staged"), ("framesets", "framesets", "in_place")):
             n_warm, n_steps = (max(2, min(args.warmup, 10)), args.steps) if split == "rows" else (2, side_reps)
-            progress.update(split=split, phase="setup", step=None)
+            progress.update(split=key, phase="setup", step=None)
             res = {}
             gctx = None
             try:
@@ -758,9 +779,17 @@ def run_rank(args):
                 full = torch.empty((total, full_h, W), dtype=torch.float64, device=device) if rank == 0 else None
                 scratch = None if rank == 0 else torch.empty((gn, grows, W), dtype=torch.float64, device=device)
                 torch.cuda.synchronize()
+                # the schedule of one step as libslx plans it (no GPU involved): messages the root receives, bytes into the root
+                n_msgs_root, staging_bytes = 0, 0
+                most_sets = max(t[1] for t in table)
+                for first in range(0, most_sets, args.gather_chunk):
+                    m0, _, st0 = api.gather_plan_ex(table, 0, full_h, W, first, args.gather_chunk, local_plane_stride=full_h * W, root=0, shape=shape)
+                    n_msgs_root += sum(1 for m in m0 if m[1] != 1)
+                    staging_bytes = max(staging_bytes, st0 * 8)
                 if backend == "nccl":
                     if comm is None:
                         raise RuntimeError(gather.get("error", "no communicator"))
+                    comm.set_gather_shape(shape)
 
                     def decode_only():
                         gctx.decode_batch_ex(gn, gphase, ggray, z=(full[set0:, row0:] if rank == 0 else scratch),
@@ -768,6 +797,11 @@ def run_rank(args):
 
                     def decode_and_gather():
                         comm.decode_gather(table, full_h, args.gather_chunk, gphase, ggray, scratch, full, root=0, ctx=gctx)
+
+                    def gather_only():
+                        # the finished tiles again, no decode in front: what the links and RCCL deliver by themselves
+                        comm.gather_depth(table, full_h, W, (full[set0:, row0:] if rank == 0 else scratch), full, root=0,
+                                          local_plane_stride=(full_h * W if rank == 0 else 0))
 
                     def drain():
                         comm.synchronize()
@@ -778,10 +812,14 @@ def run_rank(args):
                     def decode_only():
                         gctx.decode_batch(gn, gphase, ggray, local)
 
+                    def gather_only():
+                        holder["full"] = shard.gather_shards(holder["local_cpu"], table, full_h, W, dst=0, shape=shape, chunk=args.gather_chunk)
+
                     def decode_and_gather():
                         decode_only()
                         torch.cuda.synchronize()
-                        holder["full"] = shard.gather_shards(local.cpu(), table, full_h, W, dst=0)
+                        holder["local_cpu"] = local.cpu()
+                        gather_only()
 
                     def drain():
                         pass
@@ -802,9 +840,19 @@ def run_rank(args):
                 drain()
                 torch.cuda.synchronize()
                 tg = time.perf_counter() - t0g
+                progress.update(phase="gather_only", step=None)
+                fence()
+                n_go = max(3, min(n_steps, 10))
+                t0o = time.perf_counter()
+                for i in range(n_go):
+                    progress.update(step=i)
+                    gather_only()
+                drain()
+                torch.cuda.synchronize()
+                to = (time.perf_counter() - t0o) / n_go
                 progress.update(phase="check", step=None)
                 fence()
-                tk_max, tg_max = max_over_ranks([tk, tg])
+                tk_max, tg_max, to_max = max_over_ranks([tk, tg, to])
                 # the gathered array against what every rank decoded: wrapping int64 sums of the bit patterns, per rank
                 mine = (full[set0:set0 + gn, row0:row0 + grows] if (rank == 0 and backend == "nccl") else
                         (scratch if backend == "nccl" else local))
@@ -819,28 +867,43 @@ def run_rank(args):
                         if ok and n and rows:
                             part = got_full[s0:s0 + n, r0:r0 + rows].contiguous().view(torch.int64).sum()
                             ok = ok and int(part) == int(sums[r])
-                res = {"kernel_only": {"value": total * n_steps / tk_max, "unit": "frames/s", "ms_per_step": tk_max / n_steps * 1e3},
+                into_root = int(((total - gn) * full_h if split == "framesets" else total * (full_h - grows)) * W * 8)
+                link_gbps = into_root / to_max / 1e9 / max(world - 1, 1)
+                res = {"split": split, "gather_shape": shape,
+                       "kernel_only": {"value": total * n_steps / tk_max, "unit": "frames/s", "ms_per_step": tk_max / n_steps * 1e3},
                        "end_to_end": {"value": total * n_steps / tg_max, "unit": "frames/s", "ms_per_step": tg_max / n_steps * 1e3},
+                       # what the gather adds to a step beyond the decode it overlaps with, and the gather by itself
+                       "gather_wait_ms_per_step": (tg_max - tk_max) / n_steps * 1e3,
+                       "gather_only": {"ms_per_step": to_max * 1e3, "steps": n_go, "gbps_into_root": into_root / to_max / 1e9,
+                                       "gbps_per_link": link_gbps, "links": world - 1, "xgmi_link_peak_gbps": XGMI_LINK_GBPS,
+                                       "frac_of_link_peak": link_gbps / XGMI_LINK_GBPS if backend == "nccl" else None,
+                                       "what": "slx_gather_depth of the finished tiles, no decode; bytes into the root / time / (N-1) links"
+                                               if backend == "nccl" else "gloo through host memory (one-GPU rehearsal): not a link measurement"},
                        "steps": n_steps, "warmup": n_warm,
-                       "bytes_into_root_per_step": int(((total - gn) * full_h if split == "framesets" else total * (full_h - grows)) * W * 8),
-                       "gathered_shape": [total, full_h, W], "messages_at_root_per_step": (world - 1) * (1 if split == "framesets" else total),
+                       "bytes_into_root_per_step": into_root,
+                       "gathered_shape": [total, full_h, W], "messages_at_root_per_step": n_msgs_root,
+                       "bytes_per_message": (into_root // n_msgs_root) if n_msgs_root else None,
+                       "root_staging_bytes": 2 * staging_bytes if staging_bytes else 0,
                        "gathered_equals_local_decodes": ok}
                 if split == "rows" and ok is not False:
-                    headline = tg_max              # (a gather that delivers other bytes than the ranks decoded is a failure, not a number)
+                    row_times[key] = (tg_max, shape)
+                    if headline is None or tg_max < headline:      # (a gather that delivers other bytes than the ranks decoded is a failure, not a number)
+                        headline, headline_shape[0] = tg_max, shape
             except Exception as e:      # the decode-only measurement above must still be reported
-                res = {"error": "%s: %s" % (type(e).__name__, e)}
+                res = {"split": split, "gather_shape": shape, "error": "%s: %s" % (type(e).__name__, e)}
                 gather_ok = False
             finally:
                 if gctx is not None:
                     if comm is not None:
                         try:
-                            comm.synchronize()          # nothing of this split may still be in flight when its buffers go
+                            comm.synchronize()          # nothing of this measurement may still be in flight when its buffers go
                         except Exception:
                             pass
                     gctx.close()
             if res.get("gathered_equals_local_decodes") is False:
                 gather_ok = False
-            gather[split] = res
+            gather[key] = res
+        gather["value_is"] = ("rows_staged" if headline_shape[0] == "staged" else "rows") if headline is not None else None
         if comm is not None:
             try:
                 comm.close()
@@ -979,23 +1042,28 @@ def selftest_rank(args):
     total, H, W = 2 * world, 13, 8
     want = torch.arange(total * H * W, dtype=torch.float64).reshape(total, H, W)
     res = {}
-    for name, table, n_steps in (("rows", shard.shards_by_rows(total, world, H), args.steps), ("framesets", shard.shards_by_frameset(total, world, H), 2)):
+    for name, table, n_steps, shape in (("rows", shard.shards_by_rows(total, world, H), args.steps, "in_place"),
+                                        ("rows_staged", shard.shards_by_rows(total, world, H), args.steps, "staged"),
+                                        ("framesets", shard.shards_by_frameset(total, world, H), 2, "in_place")):
         s0, n, r0, rows = table[rank]
         local = want[s0:s0 + n, r0:r0 + rows].contiguous()
         dist.barrier()
         t0 = time.perf_counter()
         for _ in range(n_steps):
-            full = shard.gather_shards(local, table, H, W, dst=0)
+            full = shard.gather_shards(local, table, H, W, dst=0, shape=shape, chunk=3)
         dist.barrier()
         tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        res[name] = {"end_to_end": {"value": total * n_steps / float(tt[0]), "unit": "frames/s", "ms_per_step": float(tt[0]) / n_steps * 1e3},
+        res[name] = {"gather_shape": shape, "end_to_end": {"value": total * n_steps / float(tt[0]), "unit": "frames/s", "ms_per_step": float(tt[0]) / n_steps * 1e3},
                      "steps": n_steps, "gathered_equals_local_decodes": bool(rank != 0 or torch.equal(full, want))}
     dist.barrier()
     if rank == 0:
-        # the key layout of the real N > 1 line: `value` IS the row-tile split end to end, exactly --steps steps
-        print(json.dumps({"metric": "launcher_selftest", "value": res["rows"]["end_to_end"]["value"], "unit": "frames/s", "n_gpus": world,
-                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": res["rows"]["end_to_end"]["ms_per_step"], "max_rank": float(t[0]),
+        # the key layout of the real N > 1 line: `value` IS the row-tile split end to end, exactly --steps steps, in the faster gather shape
+        best = max(("rows", "rows_staged"), key=lambda k: res[k]["end_to_end"]["value"])
+        res["value_is"] = best
+        print(json.dumps({"metric": "launcher_selftest", "value": res[best]["end_to_end"]["value"], "unit": "frames/s", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": res[best]["end_to_end"]["ms_per_step"], "max_rank": float(t[0]),
+                          "config": {"gather_shape": res[best]["gather_shape"]},
                           "rccl_world_size": None, "torch_world_size": dist.get_world_size(), "collective_backend": "gloo", "kernel_only": None, "with_gather": res}), flush=True)
     dist.destroy_process_group()
 

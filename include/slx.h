@@ -285,8 +285,11 @@ enum slx_tuning_key {
     SLX_TUNE_COUNT = 11
 };
 int slx_set_tuning(slx_ctx *ctx, int key, int value);
-/* Which kernel the context's last decode launch was and how its work was cut ("slx_stream_kernel: resident waves, 2-row items from
- * queues", "slx_strip_kernel: 16-row items, 8 rows per row group", "slx_fused_kernel" ...): for bench lines and profiles. */
+/* Which kernel the context's last decode launch was -- the instantiation, spelled as rocprofv3's kernel trace prints it -- and how
+ * its work was cut: "slx_stream_kernel<3>: resident waves, 2-row items from queues", "slx_strip_kernel<3, 3, 0, 4, false>: 16-row
+ * items, 8 rows per row group" (<mode, frequencies, Gray bits on the DMA ring, steps, optional planes>), "slx_decoder_strip_kernel<0>:
+ * 3-row items, 2 rows per row group", "slx_fused_kernel<3, 3, true, true>" (<mode, frequencies, 4 steps, optional planes>).  For bench
+ * lines, profiles, and tests that must know a launch did not silently take another kernel. */
 int slx_last_kernel(slx_ctx *ctx, char *buf, size_t buf_bytes);
 
 /* ---- frame ingest pipeline: the live loop around the path -------------------------------------
@@ -354,9 +357,31 @@ int slx_gather_depth(slx_comm *comm, const slx_shard *shards, int height, int wi
  * [first, first+count) counted within every shard, receives first, then sends, in posting order.  offset is in doubles into
  * `full` for a receive and into this rank's `local` for a send.  *n_out receives the number of messages (also when it exceeds
  * `capacity`).  For inspection and for checking the schedule of a world of N ranks on a machine without N GPUs. */
-typedef struct slx_msg { int peer, send; unsigned long long offset, count; } slx_msg;
+typedef struct slx_msg { int peer, send; unsigned long long offset, count; } slx_msg;   /* send: 0 receive into `full`, 1 send from `local`, 2 receive into the staging slot */
 int slx_gather_plan(const slx_shard *shards, int world, int rank, int height, int width, int first, int count,
                     size_t local_plane_stride, int root, slx_msg *out, int capacity, int *n_out);
+/* Two shapes of the same gather (the same bytes arrive in the same places):
+ *   SLX_GATHER_IN_PLACE  one message per (peer, frame-set) of a row split, landing at the tile's rows of that set: no staging, no
+ *                        second pass over the root's HBM; 7 x 256 = 1 792 messages of 2.3 MB per step for configuration 4 on 8 ranks.
+ *   SLX_GATHER_STAGED    (gathers to ONE root; with root = -1 the in-place shape is used) one contiguous message per (peer, chunk)
+ *                        into a staging slot of the root -- 224 messages of 18.4 MB for the same step in chunks of 8 -- and a
+ *                        row-scatter kernel that moves the tiles to their rows while the next chunk's messages arrive in the
+ *                        other slot.  Sending ranks must hold a dense tile stack (slx_decode_gather's scratch is).
+ * Whole-frame shards are one message per peer in either shape.  The shape is a property of the communicator; every rank must
+ * set the same one.  Default: SLX_GATHER_IN_PLACE. */
+enum slx_gather_shape { SLX_GATHER_IN_PLACE = 0, SLX_GATHER_STAGED = 1 };
+int slx_comm_set_gather_shape(slx_comm *comm, int shape);
+/* The plan of a group for either shape.  Receives with send == 2 land `offset` doubles into the staging slot (of
+ * *staging_doubles doubles); scatter_out lists how the slot then goes to the full array: n_runs runs of `run` doubles from
+ * slot + src + t * src_stride to full + dst + t * dst_stride.  Counts are returned also when they exceed the capacities. */
+typedef struct slx_scatter { unsigned long long src, dst, run, n_runs, src_stride, dst_stride; } slx_scatter;
+int slx_gather_plan_ex(const slx_shard *shards, int world, int rank, int height, int width, int first, int count,
+                       size_t local_plane_stride, int root, int shape, slx_msg *out, int capacity, int *n_out,
+                       slx_scatter *scatter_out, int scatter_capacity, int *n_scatter_out, unsigned long long *staging_doubles);
+/* Runs a scatter list of slx_gather_plan_ex on the context's device -- the root-side kernel of the staged shape by itself, for a
+ * host that moves the messages with its own transport (MPI, its own RCCL calls) and for tests on a box with one GPU: staging and
+ * full are device memory; asynchronous on `stream` (NULL: the context's stream). */
+int slx_scatter_rows(slx_ctx *ctx, const slx_scatter *scatter, int n, const double *staging, double *full, void *stream);
 /* Decode + gather of this rank's shard, pipelined: the shard's frame-sets are decoded `chunk_sets` at a time on `stream`
  * (NULL: the context's) and every finished chunk is gathered on the comm's stream while the next one decodes.  Inputs as
  * slx_decode_batch (this rank's shards[rank].n_sets frame-sets, tile height shards[rank].rows = the context's height).

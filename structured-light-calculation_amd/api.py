@@ -32,7 +32,7 @@ SYMBOLS = [
     "slx_get_depth", "slx_get_point_cloud", "slx_point_cloud_of_depth", "slx_track_begin", "slx_track_next", "slx_track_image_buffer", "slx_track_next_batch", "slx_track_stage_frames", "slx_track_frames_buffer", "slx_output_device_ptr", "slx_get_calibration", "slx_enable_timing",
     "slx_last_decode_ms", "slx_debug_stamps", "slx_set_variant", "slx_set_tuning", "slx_last_kernel", "slx_read_bmp_gray", "slx_read_pgm_gray", "slx_read_calibration_yaml", "slx_write_point_cloud_text", "slx_get_point_cloud_view", "slx_version",
     "slx_decode_batch_ex", "slx_comm_unique_id", "slx_comm_create", "slx_comm_adopt", "slx_comm_destroy", "slx_comm_info", "slx_comm_last_error",
-    "slx_comm_synchronize", "slx_gather_depth", "slx_decode_gather", "slx_gather_plan",
+    "slx_comm_synchronize", "slx_gather_depth", "slx_decode_gather", "slx_gather_plan", "slx_gather_plan_ex", "slx_comm_set_gather_shape", "slx_scatter_rows",
     "slx_pipe_create", "slx_pipe_destroy", "slx_pipe_layout", "slx_pipe_acquire", "slx_pipe_submit", "slx_pipe_collect", "slx_pipe_last_error",
 ]
 
@@ -62,7 +62,14 @@ class SlxMsg(C.Structure):
     _fields_ = [("peer", C.c_int), ("send", C.c_int), ("offset", C.c_ulonglong), ("count", C.c_ulonglong)]
 
 
+class SlxScatter(C.Structure):
+    _fields_ = [("src", C.c_ulonglong), ("dst", C.c_ulonglong), ("run", C.c_ulonglong), ("n_runs", C.c_ulonglong), ("src_stride", C.c_ulonglong),
+                ("dst_stride", C.c_ulonglong)]
+
+
 COMM_ID_BYTES = 128
+GATHER_IN_PLACE, GATHER_STAGED = 0, 1
+GATHER_SHAPES = {"in_place": GATHER_IN_PLACE, "staged": GATHER_STAGED}
 
 
 class SlxPipeConfig(C.Structure):
@@ -117,6 +124,10 @@ def lib():
         L.slx_decode_gather.argtypes = [vp, vp, C.POINTER(SlxShard), C.c_int, C.c_int, vp, sz, vp, sz, sz, vp, vp, C.c_int, vp]
         L.slx_gather_plan.argtypes = [C.POINTER(SlxShard), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, sz, C.c_int, C.POINTER(SlxMsg), C.c_int,
                                       C.POINTER(C.c_int)]
+        L.slx_gather_plan_ex.argtypes = [C.POINTER(SlxShard), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, sz, C.c_int, C.c_int, C.POINTER(SlxMsg), C.c_int,
+                                         C.POINTER(C.c_int), C.POINTER(SlxScatter), C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_ulonglong)]
+        L.slx_comm_set_gather_shape.argtypes = [vp, C.c_int]
+        L.slx_scatter_rows.argtypes = [vp, C.POINTER(SlxScatter), C.c_int, vp, vp, vp]
         L.slx_synchronize.argtypes = [vp]
         L.slx_get_stream.argtypes = [vp, C.POINTER(vp)]
         L.slx_get_output.argtypes = [vp, C.c_int, vp, sz, C.c_int]
@@ -457,6 +468,14 @@ class Context:
             self._stamps = tensor
             self._check(lib().slx_debug_stamps(self._h, tensor.data_ptr(), tensor.numel()))
 
+    def scatter_rows(self, scatters, staging, full, stream=None):
+        """slx_scatter_rows: the row scatter of a staged gather group ([(src, dst, run, n_runs, src_stride, dst_stride)] from
+        gather_plan_ex) from a staging buffer into the full array, both CUDA f64 tensors; asynchronous on the context's stream."""
+        arr = (SlxScatter * max(len(scatters), 1))()
+        for i, q in enumerate(scatters):
+            arr[i] = SlxScatter(*[int(v) for v in q])
+        self._check(lib().slx_scatter_rows(self._h, arr, len(scatters), staging.data_ptr(), full.data_ptr(), stream))
+
     def set_variant(self, v):
         self._check(lib().slx_set_variant(self._h, int(v)))
 
@@ -557,6 +576,25 @@ def gather_plan(shards, rank, height, width, first, count, local_plane_stride=0,
     return [(m.peer, m.send, m.offset, m.count) for m in buf[: n.value]]
 
 
+def gather_plan_ex(shards, rank, height, width, first, count, local_plane_stride=0, root=0, shape=GATHER_IN_PLACE):
+    """slx_gather_plan_ex: (messages, scatters, staging_doubles) of one group for either gather shape (no GPU needed).
+    messages: [(peer, send, offset, count)] with send 0 = receive into full, 1 = send from local, 2 = receive into the staging slot;
+    scatters: [(src, dst, run, n_runs, src_stride, dst_stride)] -- how the staging slot then goes to the full array."""
+    shape = GATHER_SHAPES.get(shape, shape)
+    t = shard_table(shards)
+    n, ns, st = C.c_int(0), C.c_int(0), C.c_ulonglong(0)
+    args = (t, len(shards), rank, height, width, first, count, local_plane_stride, root, shape)
+    rc = lib().slx_gather_plan_ex(*args, None, 0, C.byref(n), None, 0, C.byref(ns), C.byref(st))
+    if rc != OK:
+        raise SlxError(rc, "slx_gather_plan_ex")
+    buf, sbuf = (SlxMsg * max(n.value, 1))(), (SlxScatter * max(ns.value, 1))()
+    rc = lib().slx_gather_plan_ex(*args, buf, n.value, C.byref(n), sbuf, ns.value, C.byref(ns), C.byref(st))
+    if rc != OK:
+        raise SlxError(rc, "slx_gather_plan_ex")
+    return ([(m.peer, m.send, m.offset, m.count) for m in buf[: n.value]],
+            [(q.src, q.dst, q.run, q.n_runs, q.src_stride, q.dst_stride) for q in sbuf[: ns.value]], st.value)
+
+
 def shard_table(shards):
     """[(set0, n_sets, row0, rows), ...] per rank -> the C array slx_gather_depth takes."""
     arr = (SlxShard * len(shards))()
@@ -575,7 +613,11 @@ class Comm:
         if rc != OK:
             self._h = C.c_void_p()
             raise SlxError(rc, lib().slx_comm_last_error(None).decode())
-        self.world, self.rank = self.info()
+        try:
+            self.world, self.rank = self.info()
+        except Exception:
+            self.close()                                             # the communicator exists: do not leak it with the exception
+            raise
 
     def info(self):
         """(ranks, this rank) as RCCL reports them for the communicator the gather runs on (ncclCommCount / ncclCommUserRank)."""
@@ -602,6 +644,11 @@ class Comm:
 
     def synchronize(self):
         self._check(lib().slx_comm_synchronize(self._h))
+
+    def set_gather_shape(self, shape):
+        """"in_place" (one message per (peer, frame-set), landing in place) or "staged" (one message per (peer, chunk) into a staging
+        slot of the root + a row-scatter kernel): slx_comm_set_gather_shape.  Every rank must set the same shape."""
+        self._check(lib().slx_comm_set_gather_shape(self._h, GATHER_SHAPES.get(shape, shape)))
 
     def gather_depth(self, shards, height, width, local, full, root=0, local_plane_stride=0, stream=None):
         """shards: [(set0, n_sets, row0, rows)] per rank; local / full: CUDA float64 tensors (full may be None on ranks that
@@ -668,13 +715,18 @@ def read_calibration_yaml(path):
     return {k: list(b) for k, b in zip(("cam", "pro", "rot", "trans"), bufs)}
 
 
-def decode_frameset(spec, phase=None, gray=None, want=("z",), device=-1, variant=0):
-    """Convenience: one frame-set from host arrays, outputs as numpy arrays."""
+def decode_frameset(spec, phase=None, gray=None, want=("z",), device=-1, variant=0, tune=None, info=None):
+    """Convenience: one frame-set from host arrays, outputs as numpy arrays.  tune: slx_set_tuning overrides; info: a dict that
+    receives "kernel" = slx_last_kernel's text for the launch."""
     aux = [w for w in want if w != "z" or spec["mode"] < MODE_GRAY_PHASE]
     primary = {MODE_PHASE_ONLY: "pix", MODE_GRAY_ONLY: "gray"}.get(spec["mode"])
     aux = [w for w in aux if w != primary]
     with Context(spec, device=device, aux=aux) as ctx:
         ctx.set_variant(variant)
+        if tune:
+            ctx.set_tuning(**tune)
         ctx.set_frames(phase, gray)
         ctx.decode()
+        if info is not None:
+            info["kernel"] = ctx.last_kernel()
         return {w: ctx.get_output(w) for w in want}

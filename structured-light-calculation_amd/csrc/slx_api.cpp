@@ -1000,6 +1000,15 @@ int slx_track_stage_frames(slx_ctx *ctx, const uint8_t *images, size_t stride_by
         return fail(ctx, SLX_ERR_UNAVAILABLE, "dynamic frames need a depth mode created with SLX_OUT_U in aux_outputs");
     SLX_HIP(ctx, hipSetDevice(ctx->device));
     const unsigned i = ctx->track_slab & 1u;
+    if (n_frames > ctx->track_slab_frames) {
+        // the slabs are about to be replaced by larger ones: a pointer into a slab slx_track_frames_buffer handed out for fewer
+        // frames would dangle the moment they are freed (and the images behind it with them)
+        const size_t cap = (size_t)c.width * c.height * (size_t)ctx->track_slab_frames;
+        for (int k = 0; k < 2; k++)
+            if (ctx->h_track_slab[k] && images >= ctx->h_track_slab[k] && images < ctx->h_track_slab[k] + cap)
+                return fail(ctx, SLX_ERR_INVALID_ARG, "images points into the pinned slab slx_track_frames_buffer handed out for %d frames; ask it for %d first",
+                            ctx->track_slab_frames, n_frames);
+    }
     if (int rc = track_slab_ready(ctx, i, n_frames)) return rc;
     ctx->track_slab++;
     const size_t bytes = (size_t)c.width * c.height;
@@ -1308,9 +1317,19 @@ int slx_last_kernel(slx_ctx *ctx, char *buf, size_t buf_bytes)
     if (!ctx || !buf || buf_bytes == 0) return SLX_ERR_INVALID_ARG;
     const SlxStreamState &st = ctx->stream_state;
     static const char *const names[] = {"none", "slx_fused_kernel", "slx_strip_kernel", "slx_stream_kernel", "slx_decoder_strip_kernel"};
-    if (st.last_kind == 3) snprintf(buf, buf_bytes, "%s: resident waves, %d-row items from queues", names[3], st.last_rows);
-    else if (st.last_kind == 2 || st.last_kind == 4) snprintf(buf, buf_bytes, "%s: %d-row items, %d rows per row group", names[st.last_kind], st.last_rows, st.last_weave);
-    else snprintf(buf, buf_bytes, "%s", names[st.last_kind >= 0 && st.last_kind <= 4 ? st.last_kind : 0]);
+    // the instantiation, written the way rocprofv3's kernel trace demangles it
+    char inst[64];
+    const char *aux = st.last_aux ? "true" : "false";
+    switch (st.last_kind) {
+    case 1: snprintf(inst, sizeof inst, "%s<%d, %d, %s, %s>", names[1], st.last_mode, st.last_freq, (st.last_steps == 4 || st.last_mode == SLX_MODE_GRAY_ONLY) ? "true" : "false", st.last_mode >= SLX_MODE_GRAY_PHASE ? aux : "false"); break;
+    case 2: snprintf(inst, sizeof inst, "%s<%d, %d, %d, %d, %s>", names[2], st.last_mode, st.last_freq, st.last_gray_ring_bits, st.last_steps, aux); break;
+    case 3: snprintf(inst, sizeof inst, "%s<%d>", names[3], st.last_freq); break;
+    case 4: snprintf(inst, sizeof inst, "%s<%d>", names[4], st.last_mode); break;
+    default: snprintf(inst, sizeof inst, "%s", names[0]); break;
+    }
+    if (st.last_kind == 3) snprintf(buf, buf_bytes, "%s: resident waves, %d-row items from queues", inst, st.last_rows);
+    else if (st.last_kind == 2 || st.last_kind == 4) snprintf(buf, buf_bytes, "%s: %d-row items, %d rows per row group", inst, st.last_rows, st.last_weave);
+    else snprintf(buf, buf_bytes, "%s", inst);
     return SLX_OK;
 }
 

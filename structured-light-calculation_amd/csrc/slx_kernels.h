@@ -108,6 +108,13 @@ bool slx_track_fusable(int W, int H, int win);
 int slx_launch_track_fused(const SlxKParams &kp, const uint8_t *cam, size_t stride, float *stripW, float *stripB, const float *prevW, const float *prevB,
                            float *deltaP, double *U, double *z, double *x, double *y, double *deltaZ, void *stream);
 
+// Root-side row scatter of the staged depth-map gather (slx_gather.hip): segment k moves n_runs tiles of `run` doubles from
+// stage + src + t * src_stride to full + dst + t * dst_stride.  Up to SLX_SCATTER_MAX_SEGS segments (peers) per launch.
+#define SLX_SCATTER_MAX_SEGS 16
+struct SlxScatterSeg { unsigned long long src, dst, run, n_runs, src_stride, dst_stride; };
+struct SlxScatterSegs { int n; SlxScatterSeg seg[SLX_SCATTER_MAX_SEGS]; };
+int slx_launch_row_scatter(const SlxScatterSegs &segs, const double *stage, double *full, void *stream);
+
 // True when the strip kernel can run this configuration / these operands.
 bool slx_strip_eligible(const SlxKParams &kp, int mode, bool aux);
 
@@ -158,6 +165,8 @@ struct SlxStreamState {
     unsigned epoch = 0;
     // what the last launch was (slx_last_kernel): 0 none, 1 slx_fused_kernel, 2 slx_strip_kernel, 3 slx_stream_kernel, 4 slx_decoder_strip_kernel
     int last_kind = 0, last_rows = 0, last_weave = 0;
+    // ... and which instantiation: the template arguments as rocprofv3 prints them (mode, frequencies, Gray bits on the DMA ring, steps, optional planes)
+    int last_mode = 0, last_freq = 0, last_gray_ring_bits = 0, last_steps = 0, last_aux = 0;
 };
 int slx_launch_fused(const SlxKParams &kp, int mode, bool aux, int n_sets, int variant, void *stream, const SlxTuning *tune = nullptr,
                      SlxStreamState *stream_state = nullptr);

@@ -1904,6 +1904,11 @@ int slx_launch_fused(const SlxKParams &kp_in, int mode, bool aux, int n_sets, in
         st->last_kind = plan.stream ? 3 : !plan.strip ? 1 : (mode == SLX_MODE_PHASE_ONLY || mode == SLX_MODE_GRAY_ONLY) ? 4 : 2;
         st->last_rows = plan.stream ? (int)kp.sq_rows : plan.strip ? (int)kp.tier_rows[0] : 0;
         st->last_weave = plan.strip ? (int)kp.interleave : 0;
+        st->last_mode = mode;
+        st->last_freq = mode == SLX_MODE_GRAY_ONLY ? 0 : (mode == SLX_MODE_PHASE_ONLY || mode == SLX_MODE_GRAY_PHASE) ? 1 : kp.n_freq;
+        st->last_gray_ring_bits = plan.strip && !plan.stream ? plan.gray_ring_bits : 0;
+        st->last_steps = kp.n_steps;
+        st->last_aux = aux ? 1 : 0;
     }
     // operand shapes were validated by the caller (slx_api.cpp: check_launch_shapes), slx_strip_eligible and the plan
     hipLaunchKernelGGL(fn, dim3(plan.grid_x, plan.grid_y, 1), dim3(plan.block, 1, 1), plan.lds_bytes, (hipStream_t)stream, kp);

@@ -224,7 +224,10 @@ int slx_plan_launch(const SlxKParams &kp_in, int mode, bool aux, int n_sets, int
         const unsigned wpw = (tn.strip_waves >= 1 && tn.strip_waves <= 4) ? (unsigned)tn.strip_waves : 4u;
         const unsigned per_cu = std::min(32u, wpw * (160u * 1024u / (wpw * lds_w0)));
         const unsigned long long waves = (unsigned long long)cus * (tn.strip_waves ? per_cu : 16u);
-        const unsigned m = cpg <= 255u ? 255u / cpg : 0u;
+        // Queues: a wave polls queue (its number) % queues, so every queue that holds items needs a wave of its own residue -- at most
+        // as many queues as the launch has waves (a partitioned or small device: fewer than 255 resident waves), else a queue's row
+        // groups would never be decoded
+        const unsigned m = cpg <= 255u ? (unsigned)std::min<unsigned long long>(255u / cpg, waves / cpg) : 0u;
         const bool big = groups_total * cpg >= 8ull * waves;               // >= 8 items per resident wave
         if (m >= 1 && cpg * m <= SLX_STREAM_MAX_QUEUES && groups_total * gps < (1ull << 32) && groups_total < (1ull << 31) &&
             (tn.stream == 2 ? groups_total * cpg >= 1 : big)) {

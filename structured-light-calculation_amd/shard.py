@@ -73,7 +73,7 @@ def gather_depth(local, dst=0, group=None, all_ranks=False):
 # A shard = (set0, n_sets, row0, rows): the rows [row0, row0+rows) of the frame-sets [set0, set0+n_sets) of a batch whose
 # full result is [total_sets][height][width].  The same table drives the native RCCL gather (slx_gather_depth /
 # slx_decode_gather in include/slx.h, api.Comm) and the torch.distributed one below, which exists for CPU (gloo) tests and
-# one-GPU rehearsals: same messages -- one per (peer, frame-set), or one per peer for whole-frame shards -- same result.
+# one-GPU rehearsals: it posts the messages libslx's own planner lists (slx_gather_plan_ex), in either gather shape.
 
 def shards_by_frameset(total_sets, world, height):
     out = []
@@ -95,50 +95,57 @@ def total_sets(shards):
     return max((s0 + n for s0, n, _, _ in shards), default=0)
 
 
-def gather_shards(local, shards, height, width, dst=0, group=None):
+def gather_shards(local, shards, height, width, dst=0, group=None, shape="in_place", chunk=None):
     """local: this rank's shard, [n_sets, rows, width] (contiguous).  Returns the reassembled [total_sets, height, width]
     tensor on rank `dst` (None elsewhere), or on every rank when dst is None.  Row tiles land at their row offset of every
-    frame-set; ragged tile heights and ragged set counts are fine."""
+    frame-set; ragged tile heights and ragged set counts are fine.
+
+    The messages are the NATIVE gather's: every group is planned by libslx's slx_gather_plan_ex (csrc/slx_comm.cpp: plan_range,
+    the code the RCCL path posts from) and posted here through torch.distributed point to point, so a gloo run exercises the same
+    schedule the GPUs would see.  shape: "in_place" (one message per (peer, frame-set), landing in place) or "staged" (one message
+    per (peer, chunk) into a staging buffer, then the planner's row scatter); chunk: frame-sets per group (None: all in one)."""
+    from . import api
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     assert len(shards) == world
     set0, n, row0, rows = shards[rank]
     assert tuple(local.shape) == (n, rows, width), (tuple(local.shape), shards[rank], width)
     local = local.contiguous()
+    flat_local = local.reshape(-1)
     receives = dst is None or dst == rank
-    full = None
-    ops = []
+    root = -1 if dst is None else dst
+    full = flat_full = None
     if receives:
         full = torch.zeros((total_sets(shards), height, width), dtype=local.dtype, device=local.device)
-        full[set0:set0 + n, row0:row0 + rows] = local
-        for p, (ps0, pn, pr0, prows) in enumerate(shards):
-            if p == rank or pn == 0 or prows == 0:
-                continue
-            if prows == height:
-                ops.append(dist.P2POp(dist.irecv, full[ps0:ps0 + pn], p, group))                 # contiguous run of whole frames
+        full[set0:set0 + n, row0:row0 + rows] = local                     # this rank's own shard (gather_range's self copy)
+        flat_full = full.reshape(-1)
+    most = max((s[1] for s in shards), default=0)
+    step = most if not chunk else int(chunk)
+    for first in range(0, most, max(step, 1)):
+        msgs, scat, staging = api.gather_plan_ex(shards, rank, height, width, first, max(step, 1), 0, root, shape)
+        stage = torch.empty((staging,), dtype=local.dtype, device=local.device) if staging else None
+        ops = []
+        for peer, send, off, cnt in msgs:
+            if send == 1:
+                ops.append(dist.P2POp(dist.isend, flat_local[off:off + cnt], peer, group))
+            elif send == 2:
+                ops.append(dist.P2POp(dist.irecv, stage[off:off + cnt], peer, group))
             else:
-                for k in range(pn):
-                    ops.append(dist.P2POp(dist.irecv, full[ps0 + k, pr0:pr0 + prows], p, group))  # contiguous: rows of one set
-    if n and rows:
-        for d in range(world):
-            if d == rank or not (dst is None or dst == d):
-                continue
-            if rows == height:
-                ops.append(dist.P2POp(dist.isend, local, d, group))
-            else:
-                for k in range(n):
-                    ops.append(dist.P2POp(dist.isend, local[k], d, group))
-    if ops:
-        for w in dist.batch_isend_irecv(ops):
-            w.wait()
+                ops.append(dist.P2POp(dist.irecv, flat_full[off:off + cnt], peer, group))
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+        for src, dst_off, run, n_runs, src_stride, dst_stride in scat:    # what slx_row_scatter_kernel does on the root
+            for t in range(n_runs):
+                flat_full[dst_off + t * dst_stride: dst_off + t * dst_stride + run] = stage[src + t * src_stride: src + t * src_stride + run]
     return full
 
 
-def gather_rows(local, heights, dst=0, group=None):
+def gather_rows(local, heights, dst=0, group=None, shape="in_place", chunk=None):
     """Row-tile gather: local [n_sets, h_rank, W]; heights = tile height of every rank -> [n_sets, sum(heights), W]."""
     n_sets, _, width = local.shape
     shards, row0 = [], 0
     for h in heights:
         shards.append((0, n_sets, row0, h))
         row0 += h
-    return gather_shards(local, shards, row0, width, dst=dst, group=group)
+    return gather_shards(local, shards, row0, width, dst=dst, group=group, shape=shape, chunk=chunk)

@@ -293,7 +293,7 @@ static void check_plan(int w, int h, int n_sets, int mode, int F, int N, int G, 
 
 // The stream kernel's plan: every (row group, chunk column) of the launch belongs to exactly one queue position, the scalar
 // multiply-high that turns a group number into (frame-set, group) is exact for every group, the groups cover the tile.
-static void check_stream_plan(int w, int h, int n_sets, int F, int rows)
+static void check_stream_plan(int w, int h, int n_sets, int F, int rows, unsigned n_cus = 0)
 {
     SlxKParams kp;
     std::memset(&kp, 0, sizeof kp);
@@ -310,6 +310,7 @@ static void check_stream_plan(int w, int h, int n_sets, int F, int rows)
     kp.phase_set_stride = (size_t)(F * 4) * plane;
     kp.z = out_arena;
     kp.sq_counters = counters;
+    kp.n_cus = n_cus;
     SlxTuning tn;
     std::memset(&tn, 0, sizeof tn);
     tn.stream = 2;
@@ -325,6 +326,14 @@ static void check_stream_plan(int w, int h, int n_sets, int F, int rows)
     CHECK((unsigned long long)(q.sq_groups_per_set - 1) * q.sq_rows * q.interleave < (unsigned)h);          // the last group starts inside the tile
     CHECK(q.sq_groups_total == q.sq_groups_per_set * (unsigned)n_sets);
     CHECK(plan.block == 256 && plan.grid_x >= 1 && plan.grid_x <= 1024 && plan.lds_bytes <= 160u * 1024u);
+    {
+        // every queue that holds items is polled: a wave takes queue (wave number) % queues, so the launch needs a wave for every
+        // queue index below chunks_per_group * min(sq_m, row groups) (a device with few compute units has fewer waves than 255)
+        const unsigned long long launched = (unsigned long long)plan.grid_x * (plan.block / 64u);
+        const unsigned long long holding = (unsigned long long)q.chunks_per_group * std::min(q.sq_m, q.sq_groups_total);
+        CHECK(launched >= holding);
+        if (n_cus) CHECK(launched <= (unsigned long long)n_cus * 16ull + 3ull);
+    }
     // every group is some queue's k-th item exactly once, and the multiply-high division is exact
     unsigned long long seen = 0;
     for (unsigned j = 0; j < q.sq_m; j++) {
@@ -350,6 +359,15 @@ static void test_plans()
                 for (int rows : {0, 2, 3, 4, 16})
                     if ((unsigned long long)w * h * 12ull * (unsigned)n < (1ull << 40)) check_stream_plan(w, h, n, 3, rows);
     CHECK(g_stream_plans > 300);
+    {
+        // small and partitioned devices (the planner reads the device's compute-unit count): fewer resident waves than queues
+        const int before = g_stream_plans;
+        for (unsigned cus : {1u, 2u, 4u, 8u, 15u, 16u, 32u, 64u, 128u})
+            for (int w : {1920, 1280, 64, 516})
+                for (int n : {1, 9, 256})
+                    check_stream_plan(w, 1200, n, 3, 2, cus);
+        CHECK(g_stream_plans > before + 40);
+    }
     std::mt19937 rng(11);
     const int shapes[][2] = {{1920, 1200}, {1280, 1024}, {1280, 720}, {640, 480}, {4096, 3000}, {4, 1}, {8, 1200}, {500, 5}, {1920, 150}, {1920, 37}, {4096, 130}, {64, 20}, {252, 3000}, {4092, 17}};
     for (const auto &s : shapes)

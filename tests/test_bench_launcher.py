@@ -24,10 +24,14 @@ def test_parent_starts_two_ranks_and_relays_the_line():
     assert d["metric"] == "launcher_selftest" and d["n_gpus"] == 2 and d["torch_world_size"] == 2 and d["rccl_world_size"] is None   # gloo: no RCCL communicator exists
     assert d["max_rank"] == 1.0                                         # MAX over ranks of the rank number
     # the key layout of the N > 1 line: the headline IS the row-tile split end to end (gather included), --steps steps of it
-    rows = d["with_gather"]["rows"]
+    # ... in the faster of the two gather shapes, both timed for --steps steps and both checked against the local arrays
+    assert d["with_gather"]["value_is"] in ("rows", "rows_staged")
+    rows = d["with_gather"][d["with_gather"]["value_is"]]
+    assert d["config"]["gather_shape"] == rows["gather_shape"] and {d["with_gather"][k]["gather_shape"] for k in ("rows", "rows_staged")} == {"in_place", "staged"}
     assert d["value"] == rows["end_to_end"]["value"] > 0 and rows["steps"] == d["steps"] == 3
+    assert d["value"] == max(d["with_gather"][k]["end_to_end"]["value"] for k in ("rows", "rows_staged"))
     assert d["ms_per_step"] == rows["end_to_end"]["ms_per_step"] and "kernel_only" in d
-    assert all(d["with_gather"][k]["gathered_equals_local_decodes"] is True for k in ("rows", "framesets"))
+    assert all(d["with_gather"][k]["gathered_equals_local_decodes"] is True for k in ("rows", "rows_staged", "framesets"))
 
 
 def test_failing_rank_gives_nonzero_exit():

@@ -63,6 +63,17 @@ def strip_outputs(spec):
     return tuple(w for w in all_outputs(spec) if w not in ("pix", "gray"))
 
 
+def strip_kernel_name(spec, aux, gray_on_ring=True):
+    """The slx_strip_kernel instantiation a launch of this configuration is MEANT to run as, written as slx_last_kernel (and
+    rocprofv3) print it: <mode, frequencies, Gray bits riding the DMA ring, steps, optional planes>.  Six Gray bits ride the ring
+    (the reference's and configuration 3's count); a launch that fell back to ordinary Gray loads reports 0 there and fails the
+    assertion that uses this name -- round 3's silent REF regression was exactly that fall."""
+    mode = spec["mode"]
+    F = 1 if mode == 2 else spec["n_freq"]
+    gb = 6 if (gray_on_ring and mode in (2, 4) and spec.get("gray_bits") == 6) else 0
+    return "slx_strip_kernel<%d, %d, %d, %d, %s>" % (mode, F, gb, spec.get("n_steps", 4), "true" if aux else "false")
+
+
 def assert_same(got, want, names, tol=RMS_TOL_MM):
     for n in names:
         g, w = got[n], want[n]
@@ -180,6 +191,7 @@ def test_gray_and_phase_groups_far_apart_in_memory(api, oracle, synth, torch_cud
                 ctx.set_variant(2)
                 ctx.decode_batch(n_sets, ph, gr, z)
                 ctx.synchronize()
+                assert ctx.last_kernel().startswith(strip_kernel_name(spec, aux=False) + ":"), ctx.last_kernel()   # Gray planes on the ring, not <..., 0, 4, ...>
             for s in range(n_sets):
                 assert np.array_equal(z[s].cpu().numpy(), refs[s], equal_nan=True), (name, gray_first, s)
             del arena, lo, hi, ph, gr
@@ -217,6 +229,8 @@ def test_decoder_objects_on_the_strip_path(api, oracle, synth, torch_cuda, varia
                     ctx.set_tuning(strip_rows=rows)
                     ctx.decode_batch(n_sets, view if key == "pix" else None, view if key == "gray" else None, out, row_stride=pitch)
                     ctx.synchronize()
+                    meant = "slx_fused_kernel<%d, " % spec["mode"] if variant == 1 else "slx_decoder_strip_kernel<%d>:" % spec["mode"]
+                    assert ctx.last_kernel().startswith(meant), (ctx.last_kernel(), meant)
                 for s in range(n_sets):
                     assert np.array_equal(out[s].cpu().numpy(), refs[s]), (W, H, key, variant, rows, s)
     # what the strip variant refuses stays refused (and the automatic choice falls back to the generic kernel)
@@ -253,14 +267,21 @@ def test_baseline_configs_full_size(api, oracle, synth, name, scene):
     spec = synth.make_spec(name)
     ph, gr, _ = synth.render(spec, scene, seed=0x5EED + len(name), noise_sigma=2.0)
     want = all_outputs(spec)
-    got = api.decode_frameset(spec, ph, gr, want=want)
+    info = {}
+    got = api.decode_frameset(spec, ph, gr, want=want, info=info)
+    assert info["kernel"].startswith("slx_fused_kernel<%d, " % spec["mode"]), info   # the per-frequency pix planes / the Gray plane: the generic kernel's
     ref = oracle.pipeline(spec, ph, gr, want=want, threads=8)
     assert_same(got, ref, want)
     assert (got["z"] > 0).mean() > 0.9
-    # x, y, U, the fringe orders and the mask from the strip kernel (variant 2 refuses to fall back)
+    # x, y, U, the fringe orders and the mask from the strip kernel (variant 2 refuses to fall back), Gray planes on the DMA ring
     sw = strip_outputs(spec)
-    got = api.decode_frameset(spec, ph, gr, want=sw, variant=api.VARIANT_STRIP)
+    got = api.decode_frameset(spec, ph, gr, want=sw, variant=api.VARIANT_STRIP, info=info)
+    assert info["kernel"].startswith(strip_kernel_name(spec, aux=True) + ":"), info
     assert_same(got, ref, sw)
+    # the call the reference's host loop makes -- one frame-set, depth only, automatic plan: the same kernel family, no optional planes
+    got = api.decode_frameset(spec, ph, gr, want=("z",), info=info)
+    assert info["kernel"].startswith(strip_kernel_name(spec, aux=False) + ":"), info
+    assert_same(got, ref, ("z",))
 
 
 def test_baseline_config_c5(api, oracle, synth):
@@ -271,10 +292,14 @@ def test_baseline_config_c5(api, oracle, synth):
     ref = oracle.pipeline(spec, ph, None, want=("z", "k", "U"), threads=8)
     got = api.decode_frameset(spec, ph, None, want=("z", "k", "U"))
     assert_same(got, ref, ("z", "k", "U"), RMS_TOL_MM_C5)
-    for variant in (api.VARIANT_GENERIC, api.VARIANT_STRIP):
-        got = api.decode_frameset(spec, ph, None, want=("z",), variant=variant)
+    info = {}
+    for variant, kernel in ((api.VARIANT_GENERIC, "slx_fused_kernel<3, 4, false, false>"), (api.VARIANT_STRIP, "slx_strip_kernel<3, 4, 0, 8, false>:"),
+                            (api.VARIANT_AUTO, "slx_strip_kernel<3, 4, 0, 8, false>:")):
+        got = api.decode_frameset(spec, ph, None, want=("z",), variant=variant, info=info)
+        assert info["kernel"].startswith(kernel), (variant, info)
         assert_same(got, ref, ("z",), RMS_TOL_MM_C5)
-    got = api.decode_frameset(spec, ph, None, want=("z", "k", "U"), variant=api.VARIANT_STRIP)
+    got = api.decode_frameset(spec, ph, None, want=("z", "k", "U"), variant=api.VARIANT_STRIP, info=info)
+    assert info["kernel"].startswith("slx_strip_kernel<3, 4, 0, 8, true>:"), info
     assert_same(got, ref, ("z", "k", "U"), RMS_TOL_MM_C5)
 
 
@@ -388,7 +413,11 @@ def test_variants_full_size(api, oracle, synth, name, scene, variant):
     spec = synth.make_spec(name)
     ph, gr, _ = synth.render(spec, scene, seed=11, noise_sigma=3.0)
     ref = oracle.pipeline(spec, ph, gr, want=("z",), threads=8)
-    got = api.decode_frameset(spec, ph, gr, want=("z",), variant=variant)
+    info = {}
+    got = api.decode_frameset(spec, ph, gr, want=("z",), variant=variant, info=info)
+    n4 = "true" if spec.get("n_steps", 4) == 4 else "false"
+    meant = strip_kernel_name(spec, aux=False) + ":" if variant == 2 else "slx_fused_kernel<%d, %d, %s, false>" % (spec["mode"], 1 if spec["mode"] == 2 else spec["n_freq"], n4)
+    assert info["kernel"].startswith(meant), (info, meant)
     assert_same(got, ref, ("z",))
 
 
@@ -1116,6 +1145,15 @@ def test_dynamic_frames_in_batches(api, oracle, synth, torch_cuda, shape, window
         with pytest.raises(api.SlxError) as e:
             ctx.track_next_batch(np.zeros((0, h, w), dtype=np.uint8))
         assert e.value.code == api.ERR_INVALID_ARG
+        # a pointer into the slab handed out for 5 frames, passed back for 9: the slabs would be freed and regrown under it -- refused,
+        # nothing staged, and the tracker carries on from where it was
+        small = ctx.track_frames_buffer(5)
+        nine = np.ctypeslib.as_array((np.ctypeslib.ctypes.c_uint8 * (5 * h * w)).from_address(small.ctypes.data)).reshape(5, h, w)
+        with pytest.raises(api.SlxError) as e:
+            dev_out = np.ctypeslib.ctypes.c_void_p()
+            ctx._check(api.lib().slx_track_stage_frames(ctx._h, nine.ctypes.data, w, h * w, 9, np.ctypeslib.ctypes.byref(dev_out)))
+        assert e.value.code == api.ERR_INVALID_ARG and "handed out for 5 frames" in str(e.value)
+        check_last(ctx, 13)
 
 
 @pytest.mark.parametrize("shape", [(70, 200), (64, 64), (129, 65), (5, 700)])
@@ -1232,6 +1270,7 @@ def test_full_size_batch_properties(api, oracle, synth, torch_cuda):
     with api.Context(spec) as ctx:
         ctx.decode_batch(n_sets, batch, None, z)
         ctx.synchronize()
+        assert ctx.last_kernel() == "slx_stream_kernel<3>: resident waves, 2-row items from queues", ctx.last_kernel()   # the headline launch (bench.py)
         first = z.clone()
         r0, r1 = torch.from_numpy(ref0).cuda(), torch.from_numpy(ref1).cuda()
         for s in range(n_sets):
@@ -1242,6 +1281,62 @@ def test_full_size_batch_properties(api, oracle, synth, torch_cuda):
         ctx.decode_batch(n_sets, batch, None, z)
         ctx.synchronize()
         assert torch.equal(torch.nan_to_num(z, nan=-7.0), torch.nan_to_num(first, nan=-7.0))
+
+
+def test_c4_batch_on_the_strip_kernel_16_row_items_woven_8(api, oracle, synth, torch_cuda):
+    """The launch plan that serves the reference's real batch output -- x, y beside z for every frame (R/CCalculation.cpp:756-771,
+    :666-785) -- at BASELINE configuration 4's per-GPU size: 32 frame-sets of 1920 x 1200, 3 x 4-step, on slx_strip_kernel with
+    16-row items woven 8 rows to a row group (the planner's own choice for >= 26 such frame-sets once the stream kernel is out:
+    it is depth-only).  1200 rows are not a multiple of the 128-row groups: the tail tier covers 192 rows for the last 176, so the
+    last row group of every frame-set walks 16 rows past the tile (DMA clamped to the last row, stores dropped by the descriptor's
+    range check) -- the geometry round 4's tools/weave_check.py reported a mismatch on before its fills were ordered against the
+    decode stream.  Four legs: {automatic tuning, weave=8 + strip_rows=16 forced} x {depth only, with x, y, U, k
+    through slx_decode_batch_ex}; 4 distinct frame-sets (a rendered scene and three of unstructured bytes) spread over the 32; EVERY
+    frame-set of every leg against the oracle, bit for bit (contract: 1e-4 mm RMS, fringe orders exact); slx_last_kernel must
+    name the instantiation and the item geometry.  Outputs are pre-filled with -7: a row the launch skipped would show."""
+    torch = torch_cuda
+    spec = synth.make_spec("C4")
+    H, W, n_sets = spec["height"], spec["width"], 32
+    assert (W, H) == (1920, 1200)
+    scenes = [synth.render(spec, "sphere", seed=501, noise_sigma=2.0)[0]] + [synth.random_planes(spec, seed=502 + s)[0] for s in range(3)]
+    names = ("z", "x", "y", "U", "k")
+    refs = [oracle.pipeline(spec, ph, None, want=names, threads=8) for ph in scenes]
+    dev_ref = [{w: torch.from_numpy(np.ascontiguousarray(r[w])).cuda() for w in names} for r in refs]
+    which = [(5 * s + s // 7) % 4 for s in range(n_sets)]            # every scene several times, no period that divides a tier
+    assert set(which) == {0, 1, 2, 3} and which[0] != which[-1]
+    dev_scenes = [torch.from_numpy(ph).cuda() for ph in scenes]
+    batch = torch.empty((n_sets, 12, H, W), dtype=torch.uint8, device="cuda")
+    for s in range(n_sets):
+        batch[s] = dev_scenes[which[s]]
+    del dev_scenes
+
+    def same(a, b):
+        if a.dtype == torch.float64:
+            return torch.equal(a.view(torch.int64), b.view(torch.int64)) or torch.equal(torch.nan_to_num(a, nan=-7.5), torch.nan_to_num(b, nan=-7.5))
+        return torch.equal(a, b)
+
+    with api.Context(spec) as ctx:
+        for tune in (dict(stream=1), dict(stream=1, weave=8, strip_rows=16)):
+            ctx.set_tuning(weave=0, strip_rows=0, **{k: v for k, v in tune.items() if k == "stream"})
+            ctx.set_tuning(**tune)
+            for aux in (False, True):
+                outs = {"z": torch.full((n_sets, H, W), -7.0, dtype=torch.float64, device="cuda")}
+                if aux:
+                    for w in ("x", "y", "U"):
+                        outs[w] = torch.full((n_sets, H, W), -7.0, dtype=torch.float64, device="cuda")
+                    outs["k"] = torch.full((n_sets, 2, H, W), -7, dtype=torch.int32, device="cuda")
+                torch.cuda.synchronize()          # the fills run on torch's stream, the decode on the context's own: order them
+                if aux:
+                    ctx.decode_batch_ex(n_sets, batch, None, **outs)
+                else:
+                    ctx.decode_batch(n_sets, batch, None, outs["z"])
+                ctx.synchronize()
+                meant = "slx_strip_kernel<3, 3, 0, 4, %s>: 16-row items, 8 rows per row group" % ("true" if aux else "false")
+                assert ctx.last_kernel() == meant, (ctx.last_kernel(), tune, aux)
+                for s in range(n_sets):
+                    for w in outs:
+                        assert same(outs[w][s], dev_ref[which[s]][w]), "frame-set %d (scene %d): %s differs from the oracle (%s, aux=%s)" % (s, which[s], w, tune, aux)
+                del outs
 
 
 # ------------------------------------------------------------------ frame ingest pipeline (host frames, pinned slots)
@@ -1431,7 +1526,9 @@ def test_north_star_row_tiles_at_full_size_against_the_oracle(api, oracle, synth
     for rank in range(world):
         tile, lo, hi = shard.row_tile_spec(spec, world, rank)
         assert (tile["height"], tile["row_offset"], lo, hi) == (150, 150 * rank, 150 * rank, 150 * rank + 150)
-        parts.append(api.decode_frameset(tile, scenes[0][:, lo:hi], None, want=("z", "y")))
+        info = {}
+        parts.append(api.decode_frameset(tile, scenes[0][:, lo:hi], None, want=("z", "y"), info=info))
+        assert info["kernel"].startswith("slx_strip_kernel<3, 3, 0, 4, true>:"), info
     for w in ("z", "y"):
         assert np.array_equal(np.concatenate([p[w] for p in parts]), refs[0][w], equal_nan=True), w
     # (b) 4 frame-sets, each rank's tile of all of them in one launch, in place in the full-height maps
@@ -1444,6 +1541,7 @@ def test_north_star_row_tiles_at_full_size_against_the_oracle(api, oracle, synth
         with api.Context(tile) as ctx:
             ctx.decode_batch_ex(n_sets, ph, None, z=full["z"][0, lo:], y=full["y"][0, lo:], plane_stride=H * W)
             ctx.synchronize()
+            assert ctx.last_kernel().startswith("slx_strip_kernel<3, 3, 0, 4, true>:"), ctx.last_kernel()
     for s in range(n_sets):
         for w in ("z", "y"):
             assert np.array_equal(full[w][s].cpu().numpy(), refs[s][w], equal_nan=True), (s, w)
@@ -1566,13 +1664,19 @@ def test_bench_two_ranks_rehearsed_on_one_gpu():
     assert d["n_gpus"] == 2 and d["torch_world_size"] == 2 and d["rccl_world_size"] is None and d["value"] > 0 and d["roofline"]["frac"] > 0
     assert "root's ingest" in d["config"]["sharding"] and "kernel_only" in d["config"]["sharding"]
     # N > 1: the headline is north_star's split end to end (row tiles + the gather), exactly --steps steps; the decode alone sits beside it
-    assert d["value"] == d["with_gather"]["rows"]["end_to_end"]["value"] and d["with_gather"]["rows"]["steps"] == 20
+    # ... in the faster of the two gather shapes of that split (both timed for --steps steps, both checked against the local decodes)
+    best = d["with_gather"]["value_is"]
+    assert best in ("rows", "rows_staged") and d["config"]["gather_shape"] == d["with_gather"][best]["gather_shape"]
+    assert d["value"] == d["with_gather"][best]["end_to_end"]["value"] == max(d["with_gather"][k]["end_to_end"]["value"] for k in ("rows", "rows_staged"))
+    assert d["with_gather"]["rows"]["steps"] == d["with_gather"]["rows_staged"]["steps"] == 20 and d["stuck"] is None
     assert d["kernel_only"]["value"] > d["value"] and "row-tiled" in d["config"]["workload"]
-    for split in ("framesets", "rows"):
-        g = d["with_gather"][split]
+    for key, shape, msgs in (("framesets", "in_place", 1), ("rows", "in_place", 8), ("rows_staged", "staged", 1)):
+        g = d["with_gather"][key]
         assert "error" not in g, g
-        assert g["gathered_equals_local_decodes"] is True and g["gathered_shape"] == [8, 1200, 1920]
-        assert g["kernel_only"]["value"] > 0 and g["end_to_end"]["value"] > 0
+        assert g["gather_shape"] == shape and g["gathered_equals_local_decodes"] is True and g["gathered_shape"] == [8, 1200, 1920]
+        assert g["kernel_only"]["value"] > 0 and g["end_to_end"]["value"] > 0 and g["gather_only"]["ms_per_step"] > 0
+        assert g["messages_at_root_per_step"] == msgs, g                # 2 ranks, 8 frame-sets, one chunk: per (peer, set) / per (peer, chunk)
+    assert d["with_gather"]["rows_staged"]["root_staging_bytes"] == 2 * 8 * 600 * 1920 * 8 and d["with_gather"]["rows"]["root_staging_bytes"] == 0
 
 
 @pytest.mark.parametrize("bits", [1, 3, 6, 7, 8, 10, 12])

@@ -99,3 +99,72 @@ def test_planner_occupancy_matches_compiled_register_counts(kernels):
         assert claimed <= allowed, ((mode, F, GB, NS, AUX), v["vgpr_count"], claimed, allowed)
         # the decode kernels are planned for 4 waves per SIMD (their LDS ring allows no more), the decoder kernels (modes 0, 1) for 8
         assert claimed == min(8 if mode in (0, 1) else 4, allowed), ((mode, F, GB, NS, AUX), v["vgpr_count"], claimed, allowed)
+
+
+def _sgprs(operand_text):
+    """Indices of every scalar register an operand list names (s5, s[4:7])."""
+    regs = set()
+    for m in re.finditer(r"\bs\[(\d+):(\d+)\]", operand_text):
+        regs.update(range(int(m.group(1)), int(m.group(2)) + 1))
+    for m in re.finditer(r"\bs(\d+)\b", operand_text):
+        regs.add(int(m.group(1)))
+    return regs
+
+
+def test_stream_kernel_ticket_register_is_untouched_between_issue_and_wait(tmp_path):
+    """slx_stream_kernel takes its work tickets with a scalar atomic whose result lands in an SGPR when the NEXT `s_waitcnt lgkmcnt(0)`
+    retires -- issue and wait are two asm statements with the step's DMA wait, the depth stores and the LDS reads between them
+    (csrc/slx_kernels.hip: fetch_issue / fetch_wait).  Neither hipcc's register allocator nor its waitcnt insertion knows the register
+    is pending in between: a copy, spill or reuse of it there would read the placeholder (1) instead of the ticket, and rows would be
+    skipped or decoded twice with no error.  This pins the compiled code of every instantiation:
+      * all s_atomic_add of the kernel write ONE register R, each directly behind `s_mov_b32 R, 1`;
+      * nothing else ever writes R;
+      * every read of R sits in a basic block where an `s_waitcnt ... lgkmcnt(0)` comes between the block's start (or the block's
+        own s_atomic_add) and the read -- so no instruction can see R between an issue and its wait, on any path."""
+    if not os.path.exists(HIPCC):
+        pytest.skip("hipcc is not installed")
+    out = str(tmp_path / "slx_kernels.s")
+    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-I" + os.path.join(ROOT, "include"),
+                           "-I" + CSRC, "-S", "--cuda-device-only", os.path.join(CSRC, "slx_kernels.hip"), "-o", out], stderr=subprocess.DEVNULL)
+    lines = open(out).read().split("\n")
+    checked = 0
+    for F in (1, 2, 3, 4):
+        start = next(i for i, ln in enumerate(lines) if re.match(r"^_ZN\S*slx_stream_kernelILi%dEEEv10SlxKParams:" % F, ln))
+        end = next(i for i in range(start, len(lines)) if lines[i].startswith(".Lfunc_end"))
+        body = [ln.split(";")[0].rstrip() for ln in lines[start + 1:end]]
+        insts = [(i, ln.strip()) for i, ln in enumerate(body) if ln.startswith("\t") and not ln.strip().startswith(".")]
+        labels = {i for i, ln in enumerate(body) if re.match(r"^\.LBB\S*:", ln)}
+        atomics = [(i, t) for i, t in insts if t.startswith("s_atomic_add ")]
+        assert len(atomics) >= 2, (F, "expected the entry ticket and the loop's ticket")
+        dest = {re.match(r"s_atomic_add s(\d+),", t).group(1) for _, t in atomics}
+        assert len(dest) == 1, (F, "tickets land in different registers: a phi / copy of the pending register", dest)
+        R = int(dest.pop())
+        pos = {i: k for k, (i, _) in enumerate(insts)}
+        for i, t in atomics:
+            prev = insts[pos[i] - 1][1]
+            assert prev == "s_mov_b32 s%d, 1" % R, (F, prev, t)
+        for k, (i, t) in enumerate(insts):
+            op, _, rest = t.partition(" ")
+            operands = [o.strip() for o in rest.split(",")] if rest else []
+            if not any(R in _sgprs(o) for o in operands):
+                continue
+            if t == "s_mov_b32 s%d, 1" % R or t.startswith("s_atomic_add s%d," % R):
+                continue
+            # scalar / vector ALU: operand 0 is the destination (compares to vcc / scc name it explicitly as well)
+            assert R not in _sgprs(operands[0]) or op.startswith(("s_cmp", "v_cmp", "s_bitcmp")), (F, "something else writes the ticket register", t)
+            # a read: walk back inside the basic block; an lgkmcnt(0) wait must come before the block's start or an s_atomic_add does
+            waited = False
+            for kk in range(k - 1, -1, -1):
+                j, tj = insts[kk]
+                if any(lbl > j and lbl <= i for lbl in labels):
+                    break                                             # left the basic block
+                if tj.startswith("s_atomic_add"):
+                    break
+                if tj.startswith("s_waitcnt") and "lgkmcnt(0)" in tj:
+                    waited = True
+                    break
+                if tj.startswith(("s_cbranch", "s_branch")):
+                    break
+            assert waited, (F, "the ticket register is read with no lgkmcnt(0) wait before it in its block", t, i)
+            checked += 1
+    assert checked >= 8                                               # two reads (entry, loop) per instantiation at least

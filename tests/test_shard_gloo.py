@@ -67,6 +67,14 @@ def _worker(rank, world, port, n_sets, by, outdir):
                                             spec["width"], dst=last)
             if rank == last:
                 np.save(os.path.join(outdir, "rows_last.npy"), full_last.numpy())
+            # the STAGED shape of the same gather (one message per (peer, chunk) into a staging buffer + the planner's row scatter),
+            # in chunks of 2 frame-sets with a ragged last chunk, to rank 0 and to the last rank
+            for dst_rank, fname in ((0, "rows_staged.npy"), (last, "rows_staged_last.npy")):
+                staged = shard.gather_shards(torch.from_numpy(local), shard.shards_by_rows(n_sets, world, spec["height"]), spec["height"],
+                                             spec["width"], dst=dst_rank, shape="staged", chunk=2)
+                assert (staged is None) == (rank != dst_rank)
+                if rank == dst_rank:
+                    np.save(os.path.join(outdir, fname), staged.numpy())
     finally:
         dist.destroy_process_group()
 
@@ -83,4 +91,5 @@ def test_sharded_decode_and_gather(tmp_path, world, n_sets, by):
     assert got.shape == want.shape
     assert np.array_equal(got, want, equal_nan=True)
     if by == "rows":
-        assert np.array_equal(np.load(os.path.join(str(tmp_path), "rows_last.npy")), want, equal_nan=True)
+        for fname in ("rows_last.npy", "rows_staged.npy", "rows_staged_last.npy"):
+            assert np.array_equal(np.load(os.path.join(str(tmp_path), fname)), want, equal_nan=True), fname

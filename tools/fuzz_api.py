@@ -4,7 +4,7 @@ one at a time from host / strided host / device memory, decodes on the context's
 caller's buffers in between, every output plane read back, point clouds, the tracker begun and stepped in all its feeding modes,
 variants and tunings switched under way, calls made too early or with bad arguments -- with a model of what the context must hold
 after each call, built from the oracle.  A call the model says is valid must succeed and leave the oracle's bits; a call the
-model says is invalid must return an error code (and change nothing).  Usage: tools/fuzz_api.py [SECONDS] [SEED]."""
+model says is invalid must return an error code (and change nothing).  Usage: tools/fuzz_api.py [SECONDS] [SEED] [--cases N]."""
 import importlib, json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -15,9 +15,20 @@ import oracle as O                       # the checker
 synth = importlib.import_module("structured-light-calculation_amd.synth")
 api = importlib.import_module("structured-light-calculation_amd.api")
 
-budget = float(sys.argv[1]) if len(sys.argv) > 1 else 90.0
-seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else int(time.time())
-print("fuzz_api: %.0f s, seed %d" % (budget, seed0), flush=True)
+_argv = sys.argv[1:]
+CASES = None                             # --cases N: exactly N cases whatever the clock says (a run that two boxes repeat case for case)
+if "--cases" in _argv:
+    _k = _argv.index("--cases")
+    CASES = int(_argv[_k + 1])
+    del _argv[_k:_k + 2]
+budget = float(_argv[0]) if _argv else 90.0
+seed0 = int(_argv[1]) if len(_argv) > 1 else int(time.time())
+print("fuzz_api: %s, seed %d" % ("--cases %d" % CASES if CASES is not None else "%.0f s" % budget, seed0), flush=True)
+
+
+def more(done):
+    """Another case?  By count when --cases was given, else by the clock."""
+    return done < CASES if CASES is not None else time.time() < t_end
 
 
 class Mismatch(Exception):
@@ -264,7 +275,7 @@ def one_case(seed):
 
 t_end = time.time() + budget
 i = failures = 0
-while time.time() < t_end:
+while more(i):
     seed = seed0 * 100003 + i
     i += 1
     try:

@@ -2,7 +2,7 @@
 """Differential fuzz of the rows around the decode (GPU box): the single frame-set call with every output plane, the point cloud,
 and the dynamic-frame tracker fed in every way the C ABI offers (host images, strided host images, the pinned buffer, device
 images, batches, staged slabs), on random tile shapes, windows and image content, against the oracle.
-Usage: tools/fuzz_track.py [SECONDS] [SEED]; a JSON line per difference, exit code 1 if any."""
+Usage: tools/fuzz_track.py [SECONDS] [SEED] [--cases N]; a JSON line per difference, exit code 1 if any."""
 import importlib, json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -13,9 +13,20 @@ import oracle as O                       # the checker
 synth = importlib.import_module("structured-light-calculation_amd.synth")
 api = importlib.import_module("structured-light-calculation_amd.api")
 
-budget = float(sys.argv[1]) if len(sys.argv) > 1 else 90.0
-seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else int(time.time())
-print("fuzz_track: %.0f s, seed %d" % (budget, seed0), flush=True)
+_argv = sys.argv[1:]
+CASES = None                             # --cases N: exactly N cases whatever the clock says (a run that two boxes repeat case for case)
+if "--cases" in _argv:
+    _k = _argv.index("--cases")
+    CASES = int(_argv[_k + 1])
+    del _argv[_k:_k + 2]
+budget = float(_argv[0]) if _argv else 90.0
+seed0 = int(_argv[1]) if len(_argv) > 1 else int(time.time())
+print("fuzz_track: %s, seed %d" % ("--cases %d" % CASES if CASES is not None else "%.0f s" % budget, seed0), flush=True)
+
+
+def more(done):
+    """Another case?  By count when --cases was given, else by the clock."""
+    return done < CASES if CASES is not None else time.time() < t_end
 
 
 def images(rng, h, w, n):
@@ -128,7 +139,7 @@ def one_case(seed):
 
 t_end = time.time() + budget
 i = failures = refused = 0
-while time.time() < t_end:
+while more(i):
     seed = seed0 * 100003 + i
     i += 1
     try:
