@@ -282,11 +282,12 @@ enum slx_tuning_key {
     SLX_TUNE_WEAVE = 8,        /* rows woven into one row group (a lane's rows are that far apart), 1..64 */
     SLX_TUNE_STREAM = 9,       /* stream kernel (resident waves, short items from queues): 0 automatic, 1 never, 2 whenever possible */
     SLX_TUNE_STREAM_ROWS = 10, /* its rows per work item, 2..16                                          */
-    SLX_TUNE_COUNT = 11
+    SLX_TUNE_CLOUD_PASSES = 11,/* point cloud: 0 automatic, 1 the single fused launch (SLX_ERR_UNAVAILABLE where its plan refuses), 2 the count + write launches */
+    SLX_TUNE_COUNT = 12
 };
 int slx_set_tuning(slx_ctx *ctx, int key, int value);
 /* Which kernel the context's last decode launch was -- the instantiation, spelled as rocprofv3's kernel trace prints it -- and how
- * its work was cut: "slx_stream_kernel<3>: resident waves, 2-row items from queues", "slx_strip_kernel<3, 3, 0, 4, false>: 16-row
+ * its work was cut: "slx_stream_kernel<3, false>: resident waves, 2-row items from queues" (<frequencies, optional planes>), "slx_strip_kernel<3, 3, 0, 4, false>: 16-row
  * items, 8 rows per row group" (<mode, frequencies, Gray bits on the DMA ring, steps, optional planes>), "slx_decoder_strip_kernel<0>:
  * 3-row items, 2 rows per row group", "slx_fused_kernel<3, 3, true, true>" (<mode, frequencies, 4 steps, optional planes>).  For bench
  * lines, profiles, and tests that must know a launch did not silently take another kernel. */

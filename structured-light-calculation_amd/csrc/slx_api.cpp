@@ -58,6 +58,8 @@ struct slx_ctx {
     double *d_cloud = nullptr;
     double *h_cloud = nullptr;                                        // pinned, one triple per pixel: slx_get_point_cloud_view
     unsigned *h_cloud_total = nullptr;                                // pinned: the write kernel stores the point count here
+    unsigned long long *d_cloud_words = nullptr;                      // fused cloud: ticket counter + epoch-tagged counts (slx_cloud.hip)
+    unsigned cloud_epoch = 0;                                         // launches since the words were zeroed
     size_t cloud_capacity = 0;
     // dynamic-frame tracker: previous frame's strips, unblurred deltaP, staged camera image
     float *d_stripW_prev = nullptr, *d_stripB_prev = nullptr, *d_deltaP_raw = nullptr;
@@ -310,7 +312,7 @@ void slx_destroy(slx_ctx *ctx)
         if (o) (void)hipFree(o);
     if (ctx->d_lut) (void)hipFree(ctx->d_lut);
     if (ctx->stream_state.counters) (void)hipFree(ctx->stream_state.counters);
-    for (void *q : {(void *)ctx->d_cloud_counts, (void *)ctx->d_cloud_tiles, (void *)ctx->d_cloud, (void *)ctx->d_stripW_prev,
+    for (void *q : {(void *)ctx->d_cloud_counts, (void *)ctx->d_cloud_tiles, (void *)ctx->d_cloud, (void *)ctx->d_cloud_words, (void *)ctx->d_stripW_prev,
                     (void *)ctx->d_stripB_prev, (void *)ctx->d_deltaP_raw, (void *)ctx->d_track_img[0], (void *)ctx->d_track_img[1]})
         if (q) (void)hipFree(q);
     for (uint8_t *h : ctx->h_track_img)
@@ -701,14 +703,54 @@ int slx_point_cloud_of_depth(slx_ctx *ctx, const double *depth, double *xyz, siz
     SLX_HIP(ctx, hipSetDevice(ctx->device));
     if (int rc = order_after_done(ctx, ctx->stream)) return rc;   // the decode may have run on a caller stream: device-side wait only
     const int entries = slx_cloud_entries(c.width, c.height), n_tiles = slx_cloud_tiles(c.width, c.height);
-    if (!ctx->d_cloud_counts) SLX_HIP(ctx, hipMalloc((void **)&ctx->d_cloud_counts, (size_t)entries * sizeof(unsigned)));
     if (!ctx->d_cloud_tiles) SLX_HIP(ctx, hipMalloc((void **)&ctx->d_cloud_tiles, ((size_t)n_tiles + 1) * sizeof(unsigned)));   // + the total
     if (!ctx->h_cloud_total) SLX_HIP(ctx, hipHostMalloc((void **)&ctx->h_cloud_total, sizeof(unsigned), hipHostMallocDefault));
     unsigned *total_dev = ctx->d_cloud_tiles + n_tiles;
     const double *z = depth;
-    int e = slx_launch_cloud_count(ctx->kp, z, ctx->d_cloud_counts, ctx->d_cloud_tiles, ctx->stream);
-    if (e != 0) return hip_fail(ctx, (hipError_t)e, "point-cloud count");
-    // The write kernel can follow at once when its target cannot overflow (a device buffer for every pixel, or the
+    // One launch that reads the depth once (slx_cloud.hip) wherever its plan allows; else count + write (the depth read twice)
+    SlxCloudFused fq{};
+    const bool can_fuse = slx_cloud_fused_plan(c.width, c.height, ctx->kp.n_cus, &fq.groups, &fq.parts, &fq.rows_per_part);
+    if (ctx->tune.cloud_passes == 1 && !can_fuse) return fail(ctx, SLX_ERR_UNAVAILABLE, "the fused point-cloud launch has no plan for a %d x %d map on this device", c.width, c.height);
+    const bool fused = can_fuse && ctx->tune.cloud_passes != 2;
+    auto launch_cloud = [&](double *target) -> int {
+        if (!fused) {
+            if (!ctx->d_cloud_counts) SLX_HIP(ctx, hipMalloc((void **)&ctx->d_cloud_counts, (size_t)entries * sizeof(unsigned)));
+            int e2 = slx_launch_cloud_count(ctx->kp, z, ctx->d_cloud_counts, ctx->d_cloud_tiles, ctx->stream);
+            if (e2 != 0) return hip_fail(ctx, (hipError_t)e2, "point-cloud count");
+            e2 = slx_launch_cloud_write(ctx->kp, z, ctx->d_cloud_counts, ctx->d_cloud_tiles, target, total_dev, ctx->h_cloud_total, ctx->stream);   // target NULL: the total only
+            if (e2 != 0) return hip_fail(ctx, (hipError_t)e2, "point-cloud write");
+            return SLX_OK;
+        }
+        const size_t n_words = slx_cloud_fused_words(fq.groups, fq.parts);
+        if (!ctx->d_cloud_words || ctx->cloud_epoch >= (1u << 30)) {
+            // first use, or before the epoch tags could repeat: the ticket counter and every tagged word start from zero
+            if (!ctx->d_cloud_words) SLX_HIP(ctx, hipMalloc((void **)&ctx->d_cloud_words, n_words * sizeof(unsigned long long)));
+            SLX_HIP(ctx, hipMemsetAsync(ctx->d_cloud_words, 0, n_words * sizeof(unsigned long long), ctx->stream));
+            ctx->cloud_epoch = 0;
+        }
+        fq.z = z;
+        fq.xyz = target;
+        fq.words = ctx->d_cloud_words;
+        fq.total_dev = total_dev;
+        fq.total_host = ctx->h_cloud_total;
+        fq.W = c.width;
+        fq.H = c.height;
+        fq.epoch = ctx->cloud_epoch++;
+        fq.row_offset = ctx->kp.row_offset;
+        fq.fov_min = ctx->kp.fov_min;
+        fq.fov_max = ctx->kp.fov_max;
+        fq.cx = ctx->kp.cx;
+        fq.cy = ctx->kp.cy;
+        fq.fu = ctx->kp.fu;
+        fq.fv = ctx->kp.fv;
+        const int e2 = slx_launch_cloud_fused(fq, ctx->stream);
+        if (e2 != 0) {
+            ctx->cloud_epoch = 1u << 30;                            // whatever a failed launch left in the words is not trusted: zero them next time
+            return hip_fail(ctx, (hipError_t)e2, "point-cloud launch");
+        }
+        return SLX_OK;
+    };
+    // The points can be written at once when the target cannot overflow (a device buffer for every pixel, or the
     // context's own staging buffer, which is sized for every pixel): one pass over the GPU, one wait.
     const size_t all = (size_t)c.width * c.height;
     double *dst = nullptr;
@@ -724,16 +766,14 @@ int slx_point_cloud_of_depth(slx_ctx *ctx, const double *depth, double *xyz, siz
         }
         dst = ctx->d_cloud;
     }
-    e = slx_launch_cloud_write(ctx->kp, z, ctx->d_cloud_counts, ctx->d_cloud_tiles, dst, total_dev, ctx->h_cloud_total, ctx->stream);   // dst NULL: the total only
-    if (e != 0) return hip_fail(ctx, (hipError_t)e, "point-cloud write");
+    if (int rc = launch_cloud(dst)) return rc;                      // dst NULL: the total only
     SLX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     const unsigned total = *(volatile unsigned *)ctx->h_cloud_total;   // stored by the write kernel, visible once the stream has drained
     *n_points = total;
     if (total == 0) return SLX_OK;
     if (!xyz || capacity_points < total) return fail(ctx, SLX_ERR_INVALID_ARG, "the cloud has %u points, the buffer holds %zu", total, capacity_points);
     if (!dst) {                                                     // a device buffer smaller than the frame, now known to be large enough
-        e = slx_launch_cloud_write(ctx->kp, z, ctx->d_cloud_counts, ctx->d_cloud_tiles, xyz, total_dev, ctx->h_cloud_total, ctx->stream);
-        if (e != 0) return hip_fail(ctx, (hipError_t)e, "point-cloud write");
+        if (int rc = launch_cloud(xyz)) return rc;
     } else if (mem_kind == SLX_MEM_HOST) {
         SLX_HIP(ctx, hipMemcpyAsync(xyz, dst, (size_t)total * 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     } else {
@@ -1323,7 +1363,7 @@ int slx_last_kernel(slx_ctx *ctx, char *buf, size_t buf_bytes)
     switch (st.last_kind) {
     case 1: snprintf(inst, sizeof inst, "%s<%d, %d, %s, %s>", names[1], st.last_mode, st.last_freq, (st.last_steps == 4 || st.last_mode == SLX_MODE_GRAY_ONLY) ? "true" : "false", st.last_mode >= SLX_MODE_GRAY_PHASE ? aux : "false"); break;
     case 2: snprintf(inst, sizeof inst, "%s<%d, %d, %d, %d, %s>", names[2], st.last_mode, st.last_freq, st.last_gray_ring_bits, st.last_steps, aux); break;
-    case 3: snprintf(inst, sizeof inst, "%s<%d>", names[3], st.last_freq); break;
+    case 3: snprintf(inst, sizeof inst, "%s<%d, %s>", names[3], st.last_freq, aux); break;
     case 4: snprintf(inst, sizeof inst, "%s<%d>", names[4], st.last_mode); break;
     default: snprintf(inst, sizeof inst, "%s", names[0]); break;
     }
@@ -1356,7 +1396,7 @@ int slx_set_tuning(slx_ctx *ctx, int key, int value)
     SlxTuning &t = ctx->tune;
     const Range r[SLX_TUNE_COUNT] = {{&t.strip_rows, 0, 32}, {&t.tail_pct, -1, 99}, {&t.tail_rows, 0, 32}, {&t.gray_plain, 0, 1},
                                      {&t.strip_waves, 0, 4}, {&t.lds_pad_kib, 0, 128}, {&t.plain_order, 0, 1}, {&t.tiers, 0, SLX_MAX_TIERS},
-                                     {&t.weave, 0, 64}, {&t.stream, 0, 2}, {&t.stream_rows, 0, 16}};
+                                     {&t.weave, 0, 64}, {&t.stream, 0, 2}, {&t.stream_rows, 0, 16}, {&t.cloud_passes, 0, 2}};
     if (key < 0 || key >= SLX_TUNE_COUNT) return fail(ctx, SLX_ERR_INVALID_ARG, "unknown tuning key %d", key);
     if (value < r[key].lo || value > r[key].hi) return fail(ctx, SLX_ERR_INVALID_ARG, "tuning key %d takes values in [%d,%d] (got %d)", key, r[key].lo, r[key].hi, value);
     *r[key].field = value;

@@ -95,6 +95,30 @@ int slx_launch_cloud_count(const SlxKParams &kp, const double *z, unsigned *coun
 int slx_launch_cloud_write(const SlxKParams &kp, const double *z, const unsigned *counts, const unsigned *tiles, double *xyz, unsigned *total_dev,
                            unsigned *total_host, void *stream);   // total_host: pinned host word or NULL
 
+// The same in ONE launch that reads the depth once (slx_cloud.hip): a workgroup owns 16 columns x rows_per_part rows (part p of column
+// group g), counts while the rows come in, learns its offsets by a decoupled look-back over epoch-tagged words, writes its runs.
+// words: device, slx_cloud_fused_words(groups, parts) x 8 bytes, zeroed once (and whenever epoch restarts at 0): the ticket counters
+// (one per 16 words), then one total and 16 column counts per part.  epoch: launches since the words were zeroed.
+#define SLX_CLOUD_THREADS 512        /* threads of a workgroup: 8 waves, a wave per column in the write phase */
+#define SLX_CLOUD_COUNTERS 64        /* ticket counters (classes of workgroup indices), 128 bytes apart */
+struct SlxCloudFused {
+    const double *z;
+    double *xyz;                               // null: only the number of points
+    unsigned long long *words;
+    unsigned *total_dev, *total_host;          // the number of points (device word, pinned host word or null)
+    int W, H, groups, parts, rows_per_part;
+    unsigned epoch;
+    int row_offset;
+    double fov_min, fov_max, cx, cy, fu, fv;
+};
+// Plan of the fused cloud for a W x H map on a device of n_cus compute units (0: 256): false when the shape or the device is
+// outside what the kernel's look-back may assume (more parts per column group than workgroups the device keeps resident, more than
+// 16 parts) -- the two-launch path serves those.  Host arithmetic only (slx_plan.cpp).
+bool slx_cloud_fused_plan(int W, int H, unsigned n_cus, int *groups, int *parts, int *rows_per_part);
+size_t slx_cloud_fused_lds_bytes(int rows_per_part);          // dynamic LDS of a workgroup
+size_t slx_cloud_fused_words(int groups, int parts);
+int slx_launch_cloud_fused(const SlxCloudFused &q, void *stream);
+
 // Dynamic-frame tracker (slx_track.hip).  Device pointers; 0 or a hipError_t.
 // prevW / prevB / raw non-null: also raw = the deltaP selection between the previous frame's strips and the new ones
 // (fused into the strip kernel for the 21-pixel window, a second launch otherwise).
@@ -132,6 +156,7 @@ struct SlxTuning {
     int weave;           // rows woven into one row group, rounded down to a multiple of the smallest legal count, 1..64
     int stream;          // stream kernel: 0 automatic, 1 never, 2 whenever it can run
     int stream_rows;     // its rows per item, 2..16
+    int cloud_passes;    // point cloud: 0 automatic (one launch where its plan allows), 1 the fused launch or an error, 2 the two-launch path
 };
 
 // Waves per SIMD the VGPR count of a strip-kernel instantiation allows (host-side table, checked against the compiled kernels
@@ -159,6 +184,9 @@ int slx_plan_launch(const SlxKParams &kp, int mode, bool aux, int n_sets, int va
 // Returns 0, or a hipError_t value.  `variant` selects a kernel variant, `tune` (may be null) the item geometry.
 // Host-side record of a context's queue counters (slx_stream_kernel): the geometry they were last zeroed for and the launches since.
 #define SLX_STREAM_MAX_QUEUES 256
+// 1: the planner takes the stream kernel by itself for launches with the optional planes (x, y, U, k); 0: only when asked (slx_set_tuning
+// stream = 2).  Decided by the same-box A/B of round 5.
+#define SLX_STREAM_AUX_DEFAULT 0
 struct SlxStreamState {
     unsigned *counters = nullptr;               // device, SLX_STREAM_MAX_QUEUES * 32 words
     unsigned long long key = 0;                 // geometry the counters count for (0: none yet)

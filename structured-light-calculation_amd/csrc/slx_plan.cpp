@@ -21,6 +21,33 @@ int slx_cloud_entries(int width, int height) { return width * ((height + kCloudT
 
 int slx_cloud_tiles(int width, int height) { return ((width + kCloudTile - 1) / kCloudTile) * ((height + kCloudTile - 1) / kCloudTile); }
 
+// ---- fused point cloud (slx_cloud.hip) ----
+// A part is 16 columns x R rows; R = 256 (the workgroup's 512 lanes x 4 loads of 16 bytes, all in flight), less for a
+// shorter map (rounded up to the 32 rows a pass of the lanes covers), more only when 16 parts of 256 rows do not reach the bottom.
+size_t slx_cloud_fused_lds_bytes(int rows_per_part) { return (size_t)rows_per_part * 16u * sizeof(double) + (SLX_CLOUD_THREADS / 64u) * 192u * sizeof(double); }
+
+size_t slx_cloud_fused_words(int groups, int parts) { return (size_t)SLX_CLOUD_COUNTERS * 16u + (size_t)groups * (size_t)parts * 17u; }
+
+bool slx_cloud_fused_plan(int W, int H, unsigned n_cus, int *groups, int *parts, int *rows_per_part)
+{
+    if (W < 1 || H < 1 || (unsigned long long)W * (unsigned)H >= (1ull << 31)) return false;   // 32-bit point counts and offsets
+    int R = H >= 256 ? 256 : (H + 63) / 64 * 64;
+    if ((H + R - 1) / R > 16) R = ((H + 15) / 16 + 63) / 64 * 64;
+    const int P = (H + R - 1) / R;
+    const size_t lds = slx_cloud_fused_lds_bytes(R) + 2048u;        // + the kernel's static words
+    if (P > 16 || lds > 64u * 1024u) return false;                  // (64 KiB: the dynamic LDS a launch gets without asking for more)
+    // the look-back waits for the sibling parts of a column group, whose tickets are adjacent: they must be able to be resident together
+    const unsigned long long cus = n_cus ? n_cus : 256u;
+    const unsigned long long resident = cus * std::min<unsigned long long>(2048u / SLX_CLOUD_THREADS, 160u * 1024u / lds);
+    if (resident < (unsigned long long)P) return false;
+    const long long G = ((long long)W + 15) / 16;
+    if (G * P >= (1ll << 24)) return false;
+    *groups = (int)G;
+    *parts = P;
+    *rows_per_part = R;
+    return true;
+}
+
 bool slx_fast_arith_ok(const SlxKParams &kp)
 {
     for (int f = 0; f < kp.n_freq; f++)
@@ -211,7 +238,7 @@ int slx_plan_launch(const SlxKParams &kp_in, int mode, bool aux, int n_sets, int
     }
     // Stream kernel (slx_kernels.hip: slx_stream_kernel): the Gray-free 4-step depth-only class, launches that fill the chip many times over
     plan->stream = 0;
-    if (!decoder && mode == SLX_MODE_MULTIFREQ && kp.n_steps == 4 && !aux && kp.sq_counters && tn.stream != 1 && tn.weave <= 1) {
+    if (!decoder && mode == SLX_MODE_MULTIFREQ && kp.n_steps == 4 && kp.sq_counters && tn.stream != 1 && tn.weave <= 1 && (!aux || SLX_STREAM_AUX_DEFAULT || tn.stream == 2)) {
         const unsigned il = 64u / g;                                     // no weave: the queues hand the rows out in order anyway
         const unsigned cpg = il * QR / 64u;
         const unsigned R = (tn.stream_rows >= 2 && tn.stream_rows <= 16) ? (unsigned)tn.stream_rows : 2u;   // measured: 2 rows 270, 4: 274, 8: 284, 16: 302 us (C4 x 32)
@@ -220,15 +247,19 @@ int slx_plan_launch(const SlxKParams &kp_in, int mode, bool aux, int n_sets, int
         const unsigned cus = kp.n_cus ? kp.n_cus : 256u;
         // resident waves per CU: 16 (4 per SIMD) in 4-wave workgroups; experiments: strip_waves = w makes w-wave workgroups and as many
         // of them as the CU's 160 KiB of LDS hold (1-wave workgroups: 20 waves per CU = 5 per SIMD)
-        const unsigned lds_w0 = 2u * (unsigned)kp.n_freq * 4u * 256u + 2048u;
+        const unsigned lds_w0 = 2u * (unsigned)kp.n_freq * 4u * 256u + 2048u + (aux ? 2048u : 0u);   // + the optional planes' staging area
         const unsigned wpw = (tn.strip_waves >= 1 && tn.strip_waves <= 4) ? (unsigned)tn.strip_waves : 4u;
         const unsigned per_cu = std::min(32u, wpw * (160u * 1024u / (wpw * lds_w0)));
-        const unsigned long long waves = (unsigned long long)cus * (tn.strip_waves ? per_cu : 16u);
+        // (with the optional planes the 4-frequency instantiation needs more than 128 VGPRs: 3 waves per SIMD, tests/test_kernel_resources.py)
+        const unsigned long long waves = (unsigned long long)cus * (tn.strip_waves ? per_cu : (aux && kp.n_freq >= 4) ? 12u : 16u);
         // Queues: a wave polls queue (its number) % queues, so every queue that holds items needs a wave of its own residue -- at most
         // as many queues as the launch has waves (a partitioned or small device: fewer than 255 resident waves), else a queue's row
         // groups would never be decoded
         const unsigned m = cpg <= 255u ? (unsigned)std::min<unsigned long long>(255u / cpg, waves / cpg) : 0u;
-        const bool big = groups_total * cpg >= 8ull * waves;               // >= 8 items per resident wave
+        // >= 5 items per resident wave.  Same-box sweep of round 5 (tools/stream_sweep.sh, C4 x 4 ... 31 frame-sets, stream against strip
+        // kernel): 4 sets -3 % (the minima equal), 6 sets -6 %, 8 -10 %, 10 -14 %, 12 -10 %, 16 -7 %, 20 ... 24 -6 %, 28 ... 31 -3 %: the
+        // queues pay from about 5 items per wave on (round 4's threshold was 8)
+        const bool big = groups_total * cpg >= 5ull * waves;
         if (m >= 1 && cpg * m <= SLX_STREAM_MAX_QUEUES && groups_total * gps < (1ull << 32) && groups_total < (1ull << 31) &&
             (tn.stream == 2 ? groups_total * cpg >= 1 : big)) {
             kp.interleave = il;
@@ -240,7 +271,7 @@ int slx_plan_launch(const SlxKParams &kp_in, int mode, bool aux, int n_sets, int
             kp.sq_groups_total = (unsigned)groups_total;
             kp.sq_magic = (unsigned)((1ull << 32) / gps) + 1u;
             kp.n_tiers = 0;
-            const unsigned lds_w = 2u * (unsigned)kp.n_freq * 4u * 256u + 2048u;
+            const unsigned lds_w = lds_w0;
             const unsigned long long items = groups_total * cpg;
             const unsigned long long want_waves = std::min<unsigned long long>(waves, items);
             plan->strip = 1;

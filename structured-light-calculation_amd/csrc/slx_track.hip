@@ -211,7 +211,7 @@ constexpr int kFusedRows = 8;
 template <int HW>
 __global__ __launch_bounds__(kTile) void slx_track_fused_kernel(const uint8_t *cam, size_t stride, float *stripW, float *stripB, const float *prevW,
                                                                 const float *prevB, float *deltaP, double *U, double *z, double *x, double *y,
-                                                                double *deltaZ, const SlxKParams p)
+                                                                double *deltaZ, const SlxKParams p, unsigned tiles_x)
 {
     static_assert(2 * HW <= 31, "the neighbour rank must fit 5 bits");
     constexpr int OUT = kTile - 2 * HW - 2;                          // output columns per workgroup
@@ -220,8 +220,20 @@ __global__ __launch_bounds__(kTile) void slx_track_fused_kernel(const uint8_t *c
     __shared__ float rawt[RR][kTile];
     const int W = p.width, H = p.height;
     const int tx = threadIdx.x;
-    const int c = (int)blockIdx.x * OUT + tx - (HW + 1);             // image column of this lane
-    const int r0 = (int)blockIdx.y * kFusedRows;
+    // XCD-aware tile order (round 5).  The dispatcher deals workgroups round-robin over the 8 XCDs, each with its own L2; a band shares 22
+    // of its 30 image rows and 2 of its 10 rows of the previous frame's strips with the bands above and below it, and in plain order
+    // those neighbours (9 workgroups apart at 1920 columns) sit on other XCDs: the shared rows came from HBM once per band (74.9 MB read
+    // per frame for 57.6 algorithmic, profiles/r05_track_pmc_summary.json).  Here XCD x takes a contiguous run of tiles in row-major
+    // order, so that a tile's vertical neighbours run on its own XCD at about the same time and the shared rows are L2 hits.
+    // Placement only affects speed; any order gives the same result.
+    unsigned tile = blockIdx.x;
+    {
+        const unsigned nb = gridDim.x, q = nb >> 3, r = nb & 7u, x = tile & 7u, within = tile >> 3;
+        tile = x * q + (x < r ? x : r) + within;
+    }
+    const int tile_x = (int)(tile % tiles_x), tile_y = (int)(tile / tiles_x);
+    const int c = tile_x * OUT + tx - (HW + 1);                      // image column of this lane
+    const int r0 = tile_y * kFusedRows;
     const int r1 = r0 + kFusedRows < H ? r0 + kFusedRows : H;
     const int ra = r0 - 1;                                           // image row of tile row 0
     const bool col_in = c >= 0 && c < W;
@@ -393,8 +405,9 @@ int slx_launch_track_fused(const SlxKParams &kp, const uint8_t *cam, size_t stri
                            float *deltaP, double *U, double *z, double *x, double *y, double *deltaZ, void *stream)
 {
     constexpr int out_cols = kTile - 2 * 10 - 2;
-    const dim3 grid((unsigned)((kp.width + out_cols - 1) / out_cols), (unsigned)((kp.height + kFusedRows - 1) / kFusedRows));
-    hipLaunchKernelGGL(slx_track_fused_kernel<10>, grid, dim3(kTile), 0, (hipStream_t)stream, cam, stride, stripW, stripB, prevW, prevB, deltaP, U, z, x, y,
-                       deltaZ, kp);
+    const unsigned tiles_x = (unsigned)((kp.width + out_cols - 1) / out_cols), tiles_y = (unsigned)((kp.height + kFusedRows - 1) / kFusedRows);
+    if ((unsigned long long)tiles_x * tiles_y >= (1ull << 31)) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(slx_track_fused_kernel<10>, dim3(tiles_x * tiles_y), dim3(kTile), 0, (hipStream_t)stream, cam, stride, stripW, stripB, prevW, prevB,
+                       deltaP, U, z, x, y, deltaZ, kp, tiles_x);
     return (int)hipGetLastError();
 }

@@ -428,6 +428,78 @@ static void test_gather_plans()
             }
     int n = 0;
     CHECK(slx_gather_plan(nullptr, 2, 0, 4, 4, 0, 1, 0, 0, nullptr, 0, &n) == SLX_ERR_INVALID_ARG);
+    // the staged shape (slx_gather_plan_ex) in chunks: sends meet receives, staged receives stay inside the slot the plan asks for,
+    // the scatter list reads every staged double once and writes inside the full array
+    for (int world = 2; world <= 8; world++)
+        for (int root : {0, world - 1})
+            for (int chunk : {1, 3, 100}) {
+                const int H = 41, W = 10, total = 7;
+                std::vector<slx_shard> sh((size_t)world);
+                for (int r = 0; r < world; r++) { const int lo = H * r / world, hi = H * (r + 1) / world; sh[(size_t)r] = {0, total, lo, hi - lo}; }
+                for (int first = 0; first < total; first += chunk) {
+                    std::vector<std::vector<slx_msg>> plans((size_t)world);
+                    std::vector<slx_scatter> scat;
+                    unsigned long long staging = 0;
+                    for (int r = 0; r < world; r++) {
+                        int nm = 0, ns = 0;
+                        unsigned long long st = 0;
+                        const size_t ls = r == root ? (size_t)H * W : 0;            // the root holds its tile in place, the others a dense stack
+                        CHECK(slx_gather_plan_ex(sh.data(), world, r, H, W, first, chunk, ls, root, SLX_GATHER_STAGED, nullptr, 0, &nm, nullptr, 0, &ns, &st) == SLX_OK);
+                        plans[(size_t)r].resize((size_t)nm);
+                        std::vector<slx_scatter> sc((size_t)ns);
+                        CHECK(slx_gather_plan_ex(sh.data(), world, r, H, W, first, chunk, ls, root, SLX_GATHER_STAGED, plans[(size_t)r].data(), nm, &nm, sc.data(), ns, &ns, &st) == SLX_OK);
+                        if (r == root) { scat = sc; staging = st; }
+                        else CHECK(ns == 0 && st == 0);
+                    }
+                    std::vector<int> hits((size_t)staging, 0);
+                    for (int a = 0; a < world; a++) {
+                        std::vector<unsigned long long> sends, recvs;
+                        for (const slx_msg &m : plans[(size_t)a]) if (m.send == 1 && m.peer == root) sends.push_back(m.count);
+                        for (const slx_msg &m : plans[(size_t)root]) if (m.send != 1 && m.peer == a) { recvs.push_back(m.count); CHECK(m.send == 2 && m.offset + m.count <= staging); }
+                        if (a != root) CHECK(sends == recvs && sends.size() <= 1);
+                    }
+                    for (const slx_scatter &q : scat)
+                        for (unsigned long long t = 0; t < q.n_runs; t++) {
+                            CHECK(q.src + t * q.src_stride + q.run <= staging && q.dst + t * q.dst_stride + q.run <= (unsigned long long)total * H * W);
+                            for (unsigned long long i = 0; i < q.run && q.src + t * q.src_stride + i < staging; i++) hits[(size_t)(q.src + t * q.src_stride + i)]++;
+                        }
+                    for (int h : hits) CHECK(h == 1);
+                }
+            }
+    CHECK(slx_gather_plan_ex(nullptr, 2, 0, 4, 4, 0, 1, 0, 0, SLX_GATHER_STAGED, nullptr, 0, &n, nullptr, 0, nullptr, nullptr) == SLX_ERR_INVALID_ARG);
+    {
+        slx_shard two[2] = {{0, 2, 0, 2}, {0, 2, 2, 2}};
+        CHECK(slx_gather_plan_ex(two, 2, 0, 4, 4, 0, 1, 0, 0, 5, nullptr, 0, &n, nullptr, 0, nullptr, nullptr) == SLX_ERR_INVALID_ARG);   // unknown shape
+        CHECK(slx_gather_plan_ex(two, 2, 1, 4, 4, 0, 2, 16, 0, SLX_GATHER_STAGED, nullptr, 0, &n, nullptr, 0, nullptr, nullptr) == SLX_ERR_INVALID_ARG);   // sender not dense
+        CHECK(slx_scatter_rows(nullptr, nullptr, 0, nullptr, nullptr, nullptr) == SLX_ERR_INVALID_ARG);
+    }
+}
+
+// The fused point cloud's plan (slx_cloud_fused_plan): the parts tile the map, the sizes stay inside what the kernel's arrays and a
+// launch's LDS allow, a device too small to keep a column group's parts resident is refused.
+static void test_cloud_plans()
+{
+    int planned = 0;
+    for (int W : {1, 15, 16, 17, 250, 1280, 1920, 4096, 100000})
+        for (int H : {1, 31, 32, 33, 255, 256, 257, 480, 1024, 1200, 3000, 4096, 4097, 7000, 9000, 20000})
+            for (unsigned cus : {0u, 1u, 2u, 8u, 256u}) {
+                int G = -1, P = -1, R = -1;
+                if (!slx_cloud_fused_plan(W, H, cus, &G, &P, &R)) {
+                    CHECK(H > 4096 || cus == 1u || cus == 2u || (unsigned long long)W * H >= (1ull << 31) || W > 16 * (1 << 20));   // the refused ones are the expected ones
+                    continue;
+                }
+                planned++;
+                CHECK(G == (W + 15) / 16 && P >= 1 && P <= 16 && R >= 1 && R % 64 == 0);
+                CHECK((long long)P * R >= H && (long long)(P - 1) * R < H);                       // the last part starts inside the map
+                CHECK(slx_cloud_fused_lds_bytes(R) + 2048u <= 64u * 1024u);
+                CHECK(slx_cloud_fused_words(G, P) == (size_t)SLX_CLOUD_COUNTERS * 16u + (size_t)G * P * 17u);
+                const unsigned long long resident = (cus ? cus : 256u) * std::min<unsigned long long>(2048u / SLX_CLOUD_THREADS, 160u * 1024u / (slx_cloud_fused_lds_bytes(R) + 2048u));
+                CHECK(resident >= (unsigned long long)P);
+            }
+    CHECK(planned > 200);
+    int G, P, R;
+    CHECK(slx_cloud_fused_plan(1920, 1200, 256, &G, &P, &R) && G == 120 && P == 5 && R == 256);
+    CHECK(!slx_cloud_fused_plan(0, 10, 256, &G, &P, &R) && !slx_cloud_fused_plan(1920, 1200, 1, &G, &P, &R));   // one CU keeps 3 such workgroups: 5 parts do not fit
 }
 
 int main(int argc, char **argv)
@@ -440,6 +512,7 @@ int main(int argc, char **argv)
     test_validate_and_create();
     test_plans();
     test_gather_plans();
+    test_cloud_plans();
     if (g_fail) { std::fprintf(stderr, "host_sanitize: %d check(s) failed\n", g_fail); return 1; }
     CHECK(g_strip_plans > 5000 && g_generic_plans > 1000);
     if (g_fail) return 1;

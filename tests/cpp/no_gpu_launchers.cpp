@@ -18,3 +18,4 @@ bool slx_track_fusable(int, int, int) { return false; }
 int slx_launch_track_fused(const SlxKParams &, const uint8_t *, size_t, float *, float *, const float *, const float *, float *, double *, double *, double *,
                            double *, double *, void *) { return kNoDevice; }
 int slx_launch_row_scatter(const SlxScatterSegs &, const double *, double *, void *) { return kNoDevice; }
+int slx_launch_cloud_fused(const SlxCloudFused &, void *) { return kNoDevice; }

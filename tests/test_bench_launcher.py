@@ -50,16 +50,18 @@ def test_more_ranks_than_gpus_is_refused_without_the_rehearsal_flag():
 
 
 def test_traffic_probe_parses_the_counter_files(tmp_path, monkeypatch):
-    """bench.py measures roofline.traffic by running itself under `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE`.  Here a
-    stand-in profiler (a shell script that writes the counter file rocprofv3 would) checks the arithmetic around it: the mean over
-    the decode kernel's dispatches only, FETCH_SIZE x 1024 x 2 (gfx950 tallies 128-byte reads at 64 bytes), WRITE_SIZE x 1024,
-    and the fallback when the profiler fails."""
+    """bench.py measures roofline.traffic by running itself under `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE`: ONE child run per
+    counter launches every workload (the headline and the other_configs entries) a fixed number of times.  Here a stand-in profiler
+    (a shell script that writes the counter files rocprofv3 would) checks the arithmetic around it: the decode kernels' dispatches
+    only, from every counter file, cut into the workloads by dispatch order; FETCH_SIZE x 1024 x 2 (gfx950 tallies 128-byte reads at
+    64 bytes), WRITE_SIZE x 1024; and the fallbacks when the profiler fails or the dispatch count is not the launched one."""
     import argparse
     import stat
     import importlib.util
     spec = importlib.util.spec_from_file_location("slx_bench_under_test", os.path.join(ROOT, "bench.py"))
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
+    n1, n2 = bench.PROBE_LAUNCHES, bench.ROTATE
     fake = tmp_path / "rocprofv3"
     fake.write_text("""#!/bin/bash
 # stand-in for rocprofv3: --pmc <COUNTER> ... -d <dir> -- <program>
@@ -71,34 +73,49 @@ V=432000; [ $C = WRITE_SIZE ] && V=576000
 # one file per process, as the profiler writes them: the first holds no decode dispatch at all
 { echo '"Dispatch_Id","Kernel_Name","Counter_Name","Counter_Value"'
   echo "7,\\"a_kernel_of_the_runtime\\",\\"$C\\",123"; } > $D/box/0_counter_collection.csv
+# workload 1: N1 dispatches of the stream kernel (ids 100...), alternating V and V + 2000, in two files; a foreign kernel in between
 { echo '"Dispatch_Id","Kernel_Name","Counter_Name","Counter_Value"'
-  echo "1,\\"void (anonymous namespace)::slx_strip_kernel<3, 3, 0, 4, false>(SlxKParams)\\",\\"$C\\",$V"
-  echo "3,\\"some_other_kernel\\",\\"$C\\",999999999"; } > $D/box/1_counter_collection.csv
+  for i in $(seq 0 2 $((N1 - 1))); do echo "$((100 + i)),\\"void (anonymous namespace)::slx_stream_kernel<3>(SlxKParams)\\",\\"$C\\",$V"; done
+  echo "103,\\"some_other_kernel\\",\\"$C\\",999999999"; } > $D/box/1_counter_collection.csv
 { echo '"Dispatch_Id","Kernel_Name","Counter_Name","Counter_Value"'
-  echo "2,\\"void (anonymous namespace)::slx_strip_kernel<3, 3, 0, 4, false>(SlxKParams)\\",\\"$C\\",$((V + 2000))"; } > $D/box/2_counter_collection.csv
-""")
+  for i in $(seq 1 2 $((N1 - 1))); do echo "$((100 + i)),\\"void (anonymous namespace)::slx_stream_kernel<3>(SlxKParams)\\",\\"$C\\",$((V + 2000))"; done
+  # workload 2: N2 dispatches of a strip kernel (ids 500...), a tenth of the bytes
+  for i in $(seq 0 $((N2 - 1 - DROP))); do echo "$((500 + i)),\\"void (anonymous namespace)::slx_strip_kernel<3, 3, 0, 4, false>(SlxKParams)\\",\\"$C\\",$((V / 10))"; done
+} > $D/box/2_counter_collection.csv
+""".replace("\\\\", "\\"))
     fake.chmod(fake.stat().st_mode | stat.S_IEXEC)
     monkeypatch.setenv("PATH", str(tmp_path) + os.pathsep + os.environ["PATH"])
+    monkeypatch.setenv("N1", str(n1))
+    monkeypatch.setenv("N2", str(n2))
+    monkeypatch.setenv("DROP", "0")
     for k in list(os.environ):
         if k.startswith(("ROCPROF", "ROCP_")):
             monkeypatch.delenv(k)
     argv_log = tmp_path / "argv.log"
     monkeypatch.setenv("FAKE_ARGV_LOG", str(argv_log))
     args = argparse.Namespace(config="C4", sets_per_gpu=32, variant=0, tune=["strip_rows=8", "gray_plain=1"])
-    total, source = bench.traffic_probe(args)
+    workloads = [("headline", "C4", 32, (), 1), ("C4x1", "C4", 1, (), bench.ROTATE)]
+    got = bench.traffic_probe(args, workloads)
+    total, source = got["headline"]
     assert total == (433000.0 * 1024 * 2) + (577000.0 * 1024), source         # dispatches from every counter file, the decode kernel's only
-    assert "measured in this run" in source and "2 / 2 dispatches" in source
-    # the child runs the launch plan the timed region runs: every --tune item is forwarded, and so are the workload's keys
-    for ln in argv_log.read_text().splitlines():
-        assert "--tune strip_rows=8 --tune gray_plain=1" in ln and "--config C4 --sets-per-gpu 32" in ln, ln
-    # another configuration of other_configs (C3: BASELINE config 3, "rocprof HBM-bandwidth capture")
-    argv_log.write_text("")
-    total3, _ = bench.traffic_probe(args, "C3", 16)
-    assert total3 == total and all("--config C3 --sets-per-gpu 16" in ln for ln in argv_log.read_text().splitlines())
+    assert "measured in this run" in source and "%d / %d dispatches" % (n1, n1) in source
+    total1, source1 = got["C4x1"]
+    assert total1 == (43200.0 * 1024 * 2) + (57600.0 * 1024) and "%d / %d dispatches" % (n2, n2) in source1
+    # the child runs the launch plan the timed region runs: every --tune item is forwarded, and so is the list of workloads
+    lines = argv_log.read_text().splitlines()
+    assert len(lines) == 2                                              # one child run per counter, whatever the number of workloads
+    for ln in lines:
+        assert "--tune strip_rows=8 --tune gray_plain=1" in ln and "--probe-list headline:C4:32::1;C4x1:C4:1::%d" % bench.ROTATE in ln, ln
+    assert bench.parse_probe_list("a:C4:16:xyUk:1;b:REF:1::12") == [("a", "C4", 16, ("x", "y", "U", "k"), 1), ("b", "REF", 1, (), 12)]
+    # a pass whose decode dispatches are not the launched number is not cut into workloads by guesswork
+    monkeypatch.setenv("DROP", "1")
+    got = bench.traffic_probe(args, workloads)
+    assert all(v[0] is None for v in got.values()) and "decode dispatches" in got["headline"][1]
+    monkeypatch.setenv("DROP", "0")
     monkeypatch.setenv("FAKE_FAIL", "1")
-    total, source = bench.traffic_probe(args)
+    total, source = bench.traffic_probe(args, workloads)["headline"]
     assert total is None and "failed" in source
     monkeypatch.delenv("FAKE_FAIL")
     monkeypatch.setenv("ROCPROFILER_FAKE", "1")
-    total, source = bench.traffic_probe(args)
+    total, source = bench.traffic_probe(args, workloads)["C4x1"]
     assert total is None and "already runs under a profiler" in source

@@ -164,6 +164,52 @@ def test_stream_kernel_geometries_and_repeated_launches(api, oracle, synth, torc
         assert np.array_equal(z[0].cpu().numpy(), refs[0], equal_nan=True)
 
 
+@pytest.mark.parametrize("name,shape,n_sets", [("C4", (516, 71), 9), ("C2", (320, 33), 20), ("C1", (192, 150), 6), ("C5x4", (260, 64), 5), ("C4", (1920, 150), 4)])
+def test_stream_kernel_with_optional_planes(api, oracle, synth, torch_cuda, name, shape, n_sets):
+    """slx_stream_kernel<F, true>: x, y, U, the fringe orders and the mask beside z from the resident-wave kernel (stream = 2 asks for it:
+    the planner does not take it by itself for launches with optional planes), every rows-per-item choice, a subset of the planes
+    (the others go to an empty descriptor), a plane stride, repeated launches; every plane of every frame-set against the oracle."""
+    torch = torch_cuda
+    spec = small_spec(synth, "C5" if name == "C5x4" else name, *shape)
+    spec["n_steps"] = 4
+    H, W, F = spec["height"], spec["width"], spec["n_freq"]
+    sets = [synth.random_planes(spec, seed=7100 + s)[0] for s in range(n_sets)]
+    names = ("z", "x", "y", "U", "mask") + (("k",) if F > 1 else ())
+    refs = [oracle.pipeline(spec, p, None, want=names) for p in sets]
+    ph = torch.from_numpy(np.stack(sets)).cuda()
+    per = H * W + 8                                                   # a plane stride (a multiple of 4 elements: 16-byte stores in the 4-byte planes too)
+    with api.Context(spec) as ctx:
+        ctx.set_variant(2)
+        for rows, want in ((2, names), (3, ("z", "y", "k") if F > 1 else ("z", "y")), (16, names), (0, ("z", "x", "mask")), (5, names)):
+            ctx.set_tuning(stream=2, stream_rows=rows)
+            for rep in range(2):
+                outs = {}
+                for w in want:
+                    planes = F - 1 if w == "k" else 1
+                    dt = {"k": torch.int32, "mask": torch.uint8}.get(w, torch.float64)
+                    outs[w] = torch.full((n_sets * planes * per + 16,), 7 if w == "mask" else -7, dtype=dt, device="cuda")
+                torch.cuda.synchronize()
+                ctx.decode_batch_ex(n_sets, ph, None, plane_stride=per, **outs)
+                ctx.synchronize()
+                assert ctx.last_kernel().startswith("slx_stream_kernel<%d, true>:" % F), ctx.last_kernel()
+                for s_ in range(n_sets):
+                    for w in want:
+                        planes = F - 1 if w == "k" else 1
+                        got = outs[w].cpu().numpy()
+                        for q in range(planes):
+                            g = got[(s_ * planes + q) * per:(s_ * planes + q) * per + H * W].reshape(H, W)
+                            r = refs[s_][w][q] if w == "k" else refs[s_][w]
+                            assert np.array_equal(g, r, equal_nan=True), (rows, rep, s_, w, q)
+                # nothing outside the planes was touched: the strides' padding and the tail keep their fill
+                for w in want:
+                    planes = F - 1 if w == "k" else 1
+                    got = outs[w].cpu().numpy()
+                    fill = 7 if w == "mask" else -7
+                    for i in range(n_sets * planes):
+                        assert (got[i * per + H * W:(i + 1) * per] == fill).all(), (rows, w, i)
+                    assert (got[n_sets * planes * per:] == fill).all()
+
+
 def test_gray_and_phase_groups_far_apart_in_memory(api, oracle, synth, torch_cuda):
     """The two plane groups of a batch are separate allocations and may sit anywhere: here more than 2 GiB apart, in either order
     (the Gray planes ride the DMA ring through a descriptor of their own; round 3's single descriptor made such a launch fall back
@@ -922,13 +968,18 @@ def test_gray_lut_replacement(api, oracle, synth):
 
 # ------------------------------------------------------------------ point cloud (CCalculation::Result)
 @pytest.mark.parametrize("name,shape", [("C1x4", (120, 200)), ("C4", (1200, 1920)), ("C3", (33, 130)), ("C2", (1, 4))])
-def test_point_cloud(api, oracle, synth, name, shape):
+@pytest.mark.parametrize("passes", [0, 2])
+def test_point_cloud(api, oracle, synth, name, shape, passes):
+    """CCalculation::Result's data (R/CCalculation.cpp:323-357, :756-771) against the oracle, byte for byte: passes = 0 the
+    library's choice -- the single fused launch that reads the depth once (slx_cloud.hip) on every shape here -- and 2 the count +
+    write launches of rounds 1-4."""
     h, w = shape
     spec = small_spec(synth, name, w, h) if (h, w) != (1200, 1920) else synth.make_spec(name)
     ph, gr, _ = synth.render(spec, "sphere", seed=9, noise_sigma=2.0)
     z = oracle.pipeline(spec, ph, gr, want=("z",), threads=8)["z"]
     ref = oracle.point_cloud(spec, z)
     with api.Context(spec) as ctx:
+        ctx.set_tuning(cloud_passes=passes)
         ctx.set_frames(ph, gr)
         ctx.decode()
         got = ctx.get_point_cloud()
@@ -944,6 +995,48 @@ def test_point_cloud(api, oracle, synth, name, shape):
         ctx.set_frames(ph, gr)
         ctx.decode()
         assert ctx.get_point_cloud().shape == (0, 3) and ctx.get_point_cloud_view().shape == (0, 3)
+
+
+@pytest.mark.parametrize("shape", [(1, 1), (3, 17), (33, 16), (255, 31), (256, 48), (257, 33), (700, 130), (1200, 1920), (3000, 250), (4500, 40), (5000, 20)])
+def test_fused_point_cloud_geometries(api, oracle, synth, torch_cuda, shape):
+    """slx_cloud_fused_kernel's work split -- column groups of 16 (ragged last group), parts of 256 rows (ragged last part, one part
+    shorter than a pass of the lanes, more rows per part on maps taller than 16 x 256) -- on depth planes of unstructured content
+    (a third of the depths outside the FOV, NaNs and infinities among them) through slx_point_cloud_of_depth: cloud_passes = 1
+    (the fused launch or an error) must equal the two-launch path and the oracle's order byte for byte; launch after launch on
+    one context (the ticket counter and the epoch tags carry over), into host memory, into a device buffer, count only."""
+    torch = torch_cuda
+    h, w = shape
+    spec = small_spec(synth, "C4", w, h)
+    spec["fov_min"], spec["fov_max"] = 100.0, 900.0
+    rng = np.random.default_rng(h * 131 + w)
+    planes = []
+    for k in range(3):
+        zz = rng.uniform(50.0, 1200.0, size=(h, w))
+        zz[rng.random((h, w)) < 0.02] = np.nan
+        zz[rng.random((h, w)) < 0.02] = np.inf
+        zz[rng.random((h, w)) < 0.05] = 0.0
+        if k == 2:
+            zz[:, : w // 2] = 2000.0                                  # whole columns without a point
+        planes.append(zz)
+    z = torch.from_numpy(np.stack(planes)).cuda()
+    dev = torch.full((h * w, 3), -7.0, dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    with api.Context(spec) as ctx:
+        for k in (0, 1, 2, 0):
+            ref = oracle.point_cloud(spec, planes[k])
+            ctx.set_tuning(cloud_passes=1)
+            got = ctx.point_cloud_of_depth(z[k])
+            assert got.shape == ref.shape and np.array_equal(got, ref, equal_nan=True), (k, "fused, host")
+            n = ctx.point_cloud_of_depth(z[k], out=dev)
+            assert n == len(ref) and np.array_equal(dev[:n].cpu().numpy(), ref, equal_nan=True), (k, "fused, device")
+            ctx.set_tuning(cloud_passes=2)
+            assert np.array_equal(ctx.point_cloud_of_depth(z[k]), ref, equal_nan=True), (k, "two launches")
+        # a device buffer smaller than the frame: the count comes first, then the points (two fused launches)
+        ctx.set_tuning(cloud_passes=1)
+        ref = oracle.point_cloud(spec, planes[1])
+        if 0 < len(ref) < h * w:
+            tight = torch.full((len(ref), 3), -7.0, dtype=torch.float64, device="cuda")
+            assert ctx.point_cloud_of_depth(z[1], out=tight) == len(ref) and np.array_equal(tight.cpu().numpy(), ref, equal_nan=True)
 
 
 # ------------------------------------------------------------------ dynamic frames (CCalculation::CalculateOther)
@@ -1270,7 +1363,7 @@ def test_full_size_batch_properties(api, oracle, synth, torch_cuda):
     with api.Context(spec) as ctx:
         ctx.decode_batch(n_sets, batch, None, z)
         ctx.synchronize()
-        assert ctx.last_kernel() == "slx_stream_kernel<3>: resident waves, 2-row items from queues", ctx.last_kernel()   # the headline launch (bench.py)
+        assert ctx.last_kernel() == "slx_stream_kernel<3, false>: resident waves, 2-row items from queues", ctx.last_kernel()   # the headline launch (bench.py)
         first = z.clone()
         r0, r1 = torch.from_numpy(ref0).cuda(), torch.from_numpy(ref1).cuda()
         for s in range(n_sets):
@@ -1545,6 +1638,55 @@ def test_north_star_row_tiles_at_full_size_against_the_oracle(api, oracle, synth
     for s in range(n_sets):
         for w in ("z", "y"):
             assert np.array_equal(full[w][s].cpu().numpy(), refs[s][w], equal_nan=True), (s, w)
+
+
+@pytest.mark.parametrize("name,shape,world,n_sets,chunk", [("C4", (128, 37), 3, 5, 2), ("C2", (64, 41), 8, 4, 3), ("C4", (1920, 1200), 8, 8, 8)])
+def test_staged_gather_row_scatter_on_one_gpu(api, oracle, synth, shard, torch_cuda, name, shape, world, n_sets, chunk):
+    """The STAGED gather shape with every rank played on this one GPU: each "rank" decodes its row tile of all frame-sets into a dense
+    tile stack (what slx_decode_gather's scratch is), the root decodes in place; per chunk the messages libslx plans
+    (slx_gather_plan_ex, every rank's plan matched pairwise as RCCL would) are carried by device-to-device copies into the root's
+    staging slot, and slx_scatter_rows -- the kernel the RCCL path launches on the root -- moves the tiles to their rows.  The
+    assembled [set][H][W] must be the oracle's, bit for bit; the last case is BASELINE configuration 4's real geometry (8 ranks,
+    150-row tiles of 1920 x 1200, chunks of 8: 7 messages of 18.4 MB into a 129 MB slot).  RCCL itself needs N GPUs; this pins
+    everything around it."""
+    torch = torch_cuda
+    spec = small_spec(synth, name, *shape)
+    H, W = spec["height"], spec["width"]
+    sets = [synth.random_planes(spec, seed=880 + s)[0] for s in range(n_sets)]
+    want = np.stack([oracle.pipeline(spec, p, None, want=("z",), threads=8)["z"] for p in sets])
+    table = shard.shards_by_rows(n_sets, world, H)
+    full = torch.full((n_sets, H, W), -7.0, dtype=torch.float64, device="cuda")
+    flat_full = full.view(-1)
+    local = {}
+    for rank in range(world):
+        tile, lo, hi = shard.row_tile_spec(spec, world, rank)
+        ph = torch.from_numpy(np.stack([p[:, lo:hi] for p in sets])).cuda()
+        torch.cuda.synchronize()
+        with api.Context(tile) as ctx:
+            if rank == 0:
+                ctx.decode_batch_ex(n_sets, ph, None, z=full[0, lo:], plane_stride=H * W)       # the root: in place
+            else:
+                local[rank] = torch.empty((n_sets, hi - lo, W), dtype=torch.float64, device="cuda")
+                ctx.decode_batch(n_sets, ph, None, local[rank])
+            ctx.synchronize()
+    n_msgs = 0
+    with api.Context(spec) as ctx:
+        for first in range(0, n_sets, chunk):
+            root_msgs, scat, staging = api.gather_plan_ex(table, 0, H, W, first, chunk, local_plane_stride=H * W, root=0, shape="staged")
+            assert all(kind == 2 for _, kind, _, _ in root_msgs) and len(scat) == len(root_msgs) == sum(1 for t in table[1:] if t[3])
+            stage = torch.full((staging,), -3.0, dtype=torch.float64, device="cuda")
+            for peer, _, roff, rcnt in root_msgs:
+                sends, no_scatter, no_staging = api.gather_plan_ex(table, peer, H, W, first, chunk, root=0, shape="staged")
+                assert len(sends) == 1 and not no_scatter and no_staging == 0
+                to, kind, soff, scnt = sends[0]
+                assert (to, kind, scnt) == (0, 1, rcnt)
+                stage[roff:roff + rcnt] = local[peer].view(-1)[soff:soff + scnt]
+                n_msgs += 1
+            torch.cuda.synchronize()
+            ctx.scatter_rows(scat, stage, flat_full)
+            ctx.synchronize()
+    assert n_msgs == (world - 1 - sum(1 for t in table[1:] if not t[3])) * ((n_sets + chunk - 1) // chunk)
+    assert np.array_equal(full.cpu().numpy(), want, equal_nan=True)
 
 
 @pytest.mark.parametrize("split", ["framesets", "rows"])

@@ -52,12 +52,12 @@ def kernels(tmp_path_factory):
     assert (0, 1, 0, 4, 0) in found and (1, 0, 0, 4, 0) in found
     # the stream kernel (resident waves, queues): mode 3, 4 steps, keyed with GB = 9 to keep it apart from the strip instantiations
     for blk in re.split(r"\n  - \.agpr_count:", meta):
-        m = re.search(r"\.name:\s+\S*slx_stream_kernelILi(\d)E", blk)
+        m = re.search(r"\.name:\s+\S*slx_stream_kernelILi(\d)ELb(\d)E", blk)
         if m:
-            found[(3, int(m.group(1)), 9, 4, 0)] = {f: int(re.search(r"\.%s:\s+(\d+)" % f, blk).group(1))
-                                                     for f in ("vgpr_count", "vgpr_spill_count", "sgpr_spill_count", "private_segment_fixed_size",
-                                                               "group_segment_fixed_size")}
-    assert all((3, F, 9, 4, 0) in found for F in (1, 2, 3, 4))
+            found[(3, int(m.group(1)), 9, 4, int(m.group(2)))] = {f: int(re.search(r"\.%s:\s+(\d+)" % f, blk).group(1))
+                                                                  for f in ("vgpr_count", "vgpr_spill_count", "sgpr_spill_count", "private_segment_fixed_size",
+                                                                            "group_segment_fixed_size")}
+    assert all((3, F, 9, 4, aux) in found for F in (1, 2, 3, 4) for aux in (0, 1))
     return found
 
 
@@ -92,7 +92,10 @@ def test_planner_occupancy_matches_compiled_register_counts(kernels):
         if mode == MODE_GRAY_PHASE and F != 1:
             continue                                   # instantiated by the template switch, never launched
         if GB == 9:
-            continue                                   # the stream kernel: planned for 4 waves per SIMD, checked by the <= 128 test above
+            # the stream kernel: planned for 4 waves per SIMD (checked by the <= 128 test above), with the optional planes 3 from 4 frequencies on
+            alloc = (v["vgpr_count"] + 7) // 8 * 8
+            assert 512 // alloc >= (3 if (AUX and F >= 4) else 4), ((mode, F, GB, NS, AUX), v["vgpr_count"])
+            continue
         alloc = (v["vgpr_count"] + 7) // 8 * 8
         allowed = min(8, 512 // alloc)
         claimed = lib.slx_strip_waves_per_simd(mode, F, GB, NS, AUX)
@@ -114,57 +117,113 @@ def _sgprs(operand_text):
 def test_stream_kernel_ticket_register_is_untouched_between_issue_and_wait(tmp_path):
     """slx_stream_kernel takes its work tickets with a scalar atomic whose result lands in an SGPR when the NEXT `s_waitcnt lgkmcnt(0)`
     retires -- issue and wait are two asm statements with the step's DMA wait, the depth stores and the LDS reads between them
-    (csrc/slx_kernels.hip: fetch_issue / fetch_wait).  Neither hipcc's register allocator nor its waitcnt insertion knows the register
-    is pending in between: a copy, spill or reuse of it there would read the placeholder (1) instead of the ticket, and rows would be
-    skipped or decoded twice with no error.  This pins the compiled code of every instantiation:
-      * all s_atomic_add of the kernel write ONE register R, each directly behind `s_mov_b32 R, 1`;
-      * nothing else ever writes R;
-      * every read of R sits in a basic block where an `s_waitcnt ... lgkmcnt(0)` comes between the block's start (or the block's
-        own s_atomic_add) and the read -- so no instruction can see R between an issue and its wait, on any path."""
+    (csrc/slx_kernels.hip: fetch_issue / fetch_wait).  The register allocator knows the variable is live across that window, so it
+    gives the register to nothing else there; what it does NOT know is that the value is still in flight: a copy or a spill of it
+    inside the window (a phi of the `if (ri == 0)` arms, scalar-register pressure) would read the placeholder (1) instead of the
+    ticket, and rows would be skipped or decoded twice with no error.  This pins the compiled code of every instantiation:
+      * every s_atomic_add writes a register R directly behind `s_mov_b32 R, 1` (two ticket variables: the entry ticket, the loop's);
+      * no instruction READS R at a point an in-flight ticket can reach: "in flight" is set by the issue, cleared by an
+        `s_waitcnt ... lgkmcnt(0)` or another definition of R, and propagated over the control-flow graph to a fixed point (the
+        optional-plane instantiations are short of scalar registers and reuse R for other values outside the window: those uses
+        are clear of it by construction of the walk)."""
     if not os.path.exists(HIPCC):
         pytest.skip("hipcc is not installed")
     out = str(tmp_path / "slx_kernels.s")
     subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-I" + os.path.join(ROOT, "include"),
                            "-I" + CSRC, "-S", "--cuda-device-only", os.path.join(CSRC, "slx_kernels.hip"), "-o", out], stderr=subprocess.DEVNULL)
     lines = open(out).read().split("\n")
-    checked = 0
-    for F in (1, 2, 3, 4):
-        start = next(i for i, ln in enumerate(lines) if re.match(r"^_ZN\S*slx_stream_kernelILi%dEEEv10SlxKParams:" % F, ln))
+    ticket_reads = 0
+    for F, aux in ((f, a) for f in (1, 2, 3, 4) for a in (0, 1)):
+        who = (F, aux)
+        start = next(i for i, ln in enumerate(lines) if re.match(r"^_ZN\S*slx_stream_kernelILi%dELb%dEEEv10SlxKParams:" % (F, aux), ln))
         end = next(i for i in range(start, len(lines)) if lines[i].startswith(".Lfunc_end"))
         body = [ln.split(";")[0].rstrip() for ln in lines[start + 1:end]]
-        insts = [(i, ln.strip()) for i, ln in enumerate(body) if ln.startswith("\t") and not ln.strip().startswith(".")]
-        labels = {i for i, ln in enumerate(body) if re.match(r"^\.LBB\S*:", ln)}
-        atomics = [(i, t) for i, t in insts if t.startswith("s_atomic_add ")]
-        assert len(atomics) >= 2, (F, "expected the entry ticket and the loop's ticket")
-        dest = {re.match(r"s_atomic_add s(\d+),", t).group(1) for _, t in atomics}
-        assert len(dest) == 1, (F, "tickets land in different registers: a phi / copy of the pending register", dest)
-        R = int(dest.pop())
-        pos = {i: k for k, (i, _) in enumerate(insts)}
-        for i, t in atomics:
-            prev = insts[pos[i] - 1][1]
-            assert prev == "s_mov_b32 s%d, 1" % R, (F, prev, t)
-        for k, (i, t) in enumerate(insts):
-            op, _, rest = t.partition(" ")
-            operands = [o.strip() for o in rest.split(",")] if rest else []
-            if not any(R in _sgprs(o) for o in operands):
+        # basic blocks: a label starts one, a branch / s_endpgm ends one
+        blocks, label_of = [[]], {}
+        for ln in body:
+            m = re.match(r"^(\.LBB\S*):", ln)
+            if m:
+                if blocks[-1]:
+                    blocks.append([])
+                label_of[m.group(1)] = len(blocks) - 1
                 continue
-            if t == "s_mov_b32 s%d, 1" % R or t.startswith("s_atomic_add s%d," % R):
+            if not ln.startswith("\t") or ln.strip().startswith("."):
                 continue
-            # scalar / vector ALU: operand 0 is the destination (compares to vcc / scc name it explicitly as well)
-            assert R not in _sgprs(operands[0]) or op.startswith(("s_cmp", "v_cmp", "s_bitcmp")), (F, "something else writes the ticket register", t)
-            # a read: walk back inside the basic block; an lgkmcnt(0) wait must come before the block's start or an s_atomic_add does
-            waited = False
-            for kk in range(k - 1, -1, -1):
-                j, tj = insts[kk]
-                if any(lbl > j and lbl <= i for lbl in labels):
-                    break                                             # left the basic block
-                if tj.startswith("s_atomic_add"):
-                    break
-                if tj.startswith("s_waitcnt") and "lgkmcnt(0)" in tj:
-                    waited = True
-                    break
-                if tj.startswith(("s_cbranch", "s_branch")):
-                    break
-            assert waited, (F, "the ticket register is read with no lgkmcnt(0) wait before it in its block", t, i)
-            checked += 1
-    assert checked >= 8                                               # two reads (entry, loop) per instantiation at least
+            t = ln.strip()
+            blocks[-1].append(t)
+            if t.startswith(("s_cbranch", "s_branch", "s_endpgm")):
+                blocks.append([])
+        succ = []
+        for b, insts in enumerate(blocks):
+            last = insts[-1] if insts else ""
+            nxt = [b + 1] if b + 1 < len(blocks) else []
+            if last.startswith("s_endpgm"):
+                succ.append([])
+            elif last.startswith("s_branch"):
+                succ.append([label_of[last.split()[1]]])
+            elif last.startswith("s_cbranch"):
+                succ.append(nxt + [label_of[last.split()[1]]])
+            else:
+                assert not last.startswith(("s_setpc", "s_swappc")), (who, last)
+                succ.append(nxt)
+        atomics = [t for insts in blocks for t in insts if t.startswith("s_atomic_add ")]
+        assert len(atomics) >= 2, (who, "expected the entry ticket and the loop's ticket")
+        dest = sorted({int(re.match(r"s_atomic_add s(\d+),", t).group(1)) for t in atomics})
+        assert len(dest) <= 2, (who, "more ticket registers than ticket variables (the entry ticket, the loop's): a copy of a pending register", dest)
+        for R in dest:
+            mov = "s_mov_b32 s%d, 1" % R
+
+            def operands(t):
+                op, _, rest = t.partition(" ")
+                return op, [o.strip() for o in rest.split(",")] if rest else []
+
+            def writes_R(t):
+                op, ops = operands(t)
+                if not ops or op.startswith(("s_cmp", "s_bitcmp", "s_waitcnt", "s_cbranch", "s_branch", "buffer_store", "global_store", "ds_write", "s_setprio", "s_nop")):
+                    return False
+                return R in _sgprs(ops[0])                               # ALU / scalar loads / the atomic: operand 0 is the destination
+
+            def reads_R(t):
+                op, ops = operands(t)
+                if t.startswith("s_atomic_add s%d," % R):
+                    return False                                          # its data operand is the placeholder the s_mov just wrote: the issue itself
+                srcs = ops if op.startswith(("s_cmp", "s_bitcmp", "buffer_store", "global_store", "ds_write")) else ops[1:]
+                return any(R in _sgprs(o) for o in srcs)
+            # "a ticket may be in flight in R": set by the issue, cleared by an lgkmcnt(0) wait (the ticket has landed: R then holds an
+            # ordinary value) or by another definition of R; propagated along fall-through and branch edges to a fixed point.  The walk
+            # is path-insensitive (it also follows arm combinations the `ri == 0` tests exclude), which can only add windows, never hide one.
+            def step(t, state):
+                if t.startswith("s_atomic_add s%d," % R) or t == mov:
+                    return True
+                if (t.startswith("s_waitcnt") and "lgkmcnt(0)" in t) or writes_R(t):
+                    return False
+                return state
+            pend_in = [False] * len(blocks)
+            changed = True
+            while changed:
+                changed = False
+                for b, insts in enumerate(blocks):
+                    state = pend_in[b]
+                    for t in insts:
+                        state = step(t, state)
+                    for nb in succ[b]:
+                        if state and not pend_in[nb]:
+                            pend_in[nb] = True
+                            changed = True
+            for b, insts in enumerate(blocks):
+                state = pend_in[b]
+                for k, t in enumerate(insts):
+                    if t.startswith("s_atomic_add s%d," % R):
+                        assert k > 0 and insts[k - 1] == mov, (who, "the placeholder is not written directly before the atomic", insts[max(0, k - 2):k + 1])
+                    if reads_R(t):
+                        assert not state, (who, "s%d is read where a ticket may still be in flight" % R, t, insts[max(0, k - 6):k + 1])
+                        consumed = False                             # the consuming read: directly behind the wait, in its block
+                        for tj in reversed(insts[:k]):
+                            if tj.startswith("s_waitcnt") and "lgkmcnt(0)" in tj:
+                                consumed = True
+                                break
+                            if writes_R(tj) or tj.startswith("s_atomic_add"):
+                                break
+                        ticket_reads += 1 if consumed else 0
+                    state = step(t, state)
+    assert ticket_reads >= 16                                         # the entry ticket's and the loop ticket's consumption, all 8 instantiations

@@ -79,6 +79,7 @@ def one_case(seed):
     n_frames = int(rng.integers(2, 7))
     imgs = images(rng, h, w, n_frames)
     with api.Context(spec, aux=("U", "x", "y")) as ctx:
+        ctx.set_tuning(cloud_passes=int(rng.choice([0, 0, 2])))      # the fused single launch (the library's choice) or count + write
         ctx.set_frames(ph, gr)
         ctx.decode()
         check("cloud0", ctx.get_point_cloud(), O.point_cloud(spec, ref["z"]))
