@@ -287,7 +287,7 @@ enum slx_tuning_key {
 };
 int slx_set_tuning(slx_ctx *ctx, int key, int value);
 /* Which kernel the context's last decode launch was -- the instantiation, spelled as rocprofv3's kernel trace prints it -- and how
- * its work was cut: "slx_stream_kernel<3, false>: resident waves, 2-row items from queues" (<frequencies, optional planes>), "slx_strip_kernel<3, 3, 0, 4, false>: 16-row
+ * its work was cut: "slx_stream_kernel<3>: resident waves, 2-row items from queues", "slx_strip_kernel<3, 3, 0, 4, false>: 16-row
  * items, 8 rows per row group" (<mode, frequencies, Gray bits on the DMA ring, steps, optional planes>), "slx_decoder_strip_kernel<0>:
  * 3-row items, 2 rows per row group", "slx_fused_kernel<3, 3, true, true>" (<mode, frequencies, 4 steps, optional planes>).  For bench
  * lines, profiles, and tests that must know a launch did not silently take another kernel. */

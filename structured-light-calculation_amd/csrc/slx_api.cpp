@@ -1363,7 +1363,7 @@ int slx_last_kernel(slx_ctx *ctx, char *buf, size_t buf_bytes)
     switch (st.last_kind) {
     case 1: snprintf(inst, sizeof inst, "%s<%d, %d, %s, %s>", names[1], st.last_mode, st.last_freq, (st.last_steps == 4 || st.last_mode == SLX_MODE_GRAY_ONLY) ? "true" : "false", st.last_mode >= SLX_MODE_GRAY_PHASE ? aux : "false"); break;
     case 2: snprintf(inst, sizeof inst, "%s<%d, %d, %d, %d, %s>", names[2], st.last_mode, st.last_freq, st.last_gray_ring_bits, st.last_steps, aux); break;
-    case 3: snprintf(inst, sizeof inst, "%s<%d, %s>", names[3], st.last_freq, aux); break;
+    case 3: snprintf(inst, sizeof inst, "%s<%d>", names[3], st.last_freq); break;
     case 4: snprintf(inst, sizeof inst, "%s<%d>", names[4], st.last_mode); break;
     default: snprintf(inst, sizeof inst, "%s", names[0]); break;
     }

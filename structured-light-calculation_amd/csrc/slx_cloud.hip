@@ -13,8 +13,9 @@
 //   2. the part publishes its 16 column counts and their sum (epoch-tagged 64-bit words, relaxed atomic stores) and collects what it needs
 //      to know where its points go: the sums of every part of the column groups before it, and the column counts of its sibling
 //      parts -- a decoupled look-back over a few hundred words, no scan kernel, no second launch;
-//   3. a wave takes a column of the tile, 64 rows at a time: lane = row, the kept lanes' rank (ballot + popcount below the lane)
-//      places the point in the column's run, the run is packed in LDS and leaves as contiguous doubles, 512 bytes per store.
+//   3. a wave takes a column of the tile, 64 rows at a time: lane = row; x and y are computed into registers WHILE the look-back of
+//      step 2 waits for the other parts (3a), then the kept lanes' rank (ballot + popcount below the lane) places the point in the
+//      column's run, the run is packed in LDS and leaves as contiguous doubles, 512 bytes per store (3b).
 // Order of the parts: tickets number the workgroups in the order they START (64 counters, one per class of workgroup indices: see the
 // kernel), ticket -> (group, part) group-major.  A workgroup then only ever waits for workgroups with a lower ticket -- which have
 // started, and publish before they wait for anything -- or for its own group's parts, whose tickets are adjacent: with at least P
@@ -80,7 +81,8 @@ constexpr unsigned kThreads = SLX_CLOUD_THREADS, kWaves = kThreads / 64u;
 
 // FAST: x and y by slx_div_item_const (fu, fv checked on the host to sit inside its range) -- the same quotient bits.
 // WIDE: 16-byte loads (the width is even, the map 16-byte aligned).
-template <bool FAST, bool WIDE>
+// CH: 64-row chunks of a part at most (4 for the usual 256-row parts: x, y of a wave's 2 columns x CH chunks live in registers).
+template <bool FAST, bool WIDE, unsigned CH>
 __global__ __launch_bounds__(kThreads) void slx_cloud_fused_kernel(const SlxCloudFused q)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];    // [R][16] tile, swizzled | [kWaves][192] runs
@@ -162,6 +164,29 @@ __global__ __launch_bounds__(kThreads) void slx_cloud_fused_kernel(const SlxClou
         for (int c = 0; c < 16; c++) t += col_cnt[c];
         publish(totals + slot, tag, t);
     }
+    // ---- 3a. while the other parts publish: x and y of this wave's columns, into registers.  Nothing here needs the offsets; the
+    // look-back below then mostly finds its words already tagged (the parts of a launch run in step, so without this a workgroup
+    // idles for the skew of the launch -- ~6 us of a 21 us kernel in the first version)
+    constexpr unsigned kCols = 16u / kWaves, kChunks = CH;          // columns a wave owns, 64-row chunks of a part at most
+    const double ru = FAST ? slx_refined_rcp_f64(q.fu) : 0.0, rv = FAST ? slx_refined_rcp_f64(q.fv) : 0.0;
+    double xo[kCols][kChunks], yo[kCols][kChunks];
+    if (q.xyz) {
+#pragma unroll
+        for (unsigned ci = 0; ci < kCols; ci++) {
+            const unsigned c = wave + ci * kWaves;
+            const double uc = (double)(int)(u0 + c) - q.cx;         // R/CCalculation.cpp:762
+#pragma unroll
+            for (unsigned ch = 0; ch < kChunks; ch++) {
+                const unsigned rr = ch * 64u + lane;
+                const unsigned rc = rr < rows ? rr : (rows ? rows - 1u : 0u);
+                const double zc = tile[rc * 16u + (c ^ (rc & 15u))];
+                const double vc = (double)((int)(v0 + rr) + q.row_offset) - q.cy;               // :763
+                xo[ci][ch] = FAST ? slx_div_item_const(zc * uc, q.fu, ru) : zc * uc / q.fu;     // :766
+                yo[ci][ch] = FAST ? slx_div_item_const(zc * vc, q.fv, rv) : zc * vc / q.fv;     // :767
+            }
+        }
+    }
+
     unsigned before = 0;
     {
         // this thread's words: the column count (part, column) = tid of this group's parts, and every kThreads-th total of the parts
@@ -222,24 +247,24 @@ __global__ __launch_bounds__(kThreads) void slx_cloud_fused_kernel(const SlxClou
     return;
 #endif
 
-    // ---- 3. columns out: a wave per column, 64 rows at a time
-    const double ru = FAST ? slx_refined_rcp_f64(q.fu) : 0.0, rv = FAST ? slx_refined_rcp_f64(q.fv) : 0.0;
-    for (unsigned c = wave; c < 16u; c += kWaves) {
-        const unsigned u = u0 + c;
-        if (u >= W) break;                                          // uniform over the wave
-        const double uc = (double)(int)u - q.cx;                    // R/CCalculation.cpp:762
+    // ---- 3b. columns out: a wave per column, 64 rows at a time -- rank the kept depths, pack the records, store the run
+#pragma unroll
+    for (unsigned ci = 0; ci < kCols; ci++) {
+        const unsigned c = wave + ci * kWaves;
+        if (u0 + c >= W) break;                                     // uniform over the wave
         double *dst = q.xyz + (size_t)col_off[c] * 3u;
-        for (unsigned r = 0; r < rows; r += 64u) {
-            const unsigned rr = r + lane;
+#pragma unroll
+        for (unsigned ch = 0; ch < kChunks; ch++) {
+            if (ch * 64u >= rows) break;                            // uniform over the workgroup
+            const unsigned rr = ch * 64u + lane;
             const unsigned rc = rr < rows ? rr : rows - 1u;
             const double zc = tile[rc * 16u + (c ^ (rc & 15u))];
             const bool keep = rr < rows && cloud_keep(zc, q.fov_min, q.fov_max);
             const unsigned long long m = __builtin_amdgcn_ballot_w64(keep);
             if (keep) {
                 const unsigned rank = (unsigned)__builtin_popcountll(m & ((1ull << lane) - 1ull));
-                const double vc = (double)((int)(v0 + rr) + q.row_offset) - q.cy;               // :763
-                run[3u * rank + 0u] = FAST ? slx_div_item_const(zc * uc, q.fu, ru) : zc * uc / q.fu;   // :766
-                run[3u * rank + 1u] = FAST ? slx_div_item_const(zc * vc, q.fv, rv) : zc * vc / q.fv;   // :767
+                run[3u * rank + 0u] = xo[ci][ch];
+                run[3u * rank + 1u] = yo[ci][ch];
                 run[3u * rank + 2u] = zc;
             }
             // the chunk's records leave as one contiguous run of doubles (a wave's LDS accesses execute in order: the reads below
@@ -265,8 +290,13 @@ int slx_launch_cloud_fused(const SlxCloudFused &q, void *stream)
     auto in_range = [](double d) { return __builtin_fabs(d) > 0x1p-90 && __builtin_fabs(d) < 0x1p90; };
     const bool fast = in_range(q.fu) && in_range(q.fv);
     const bool wide = (q.W % 2) == 0 && (reinterpret_cast<uintptr_t>(q.z) % 16) == 0;
-    auto fn = fast ? (wide ? slx_cloud_fused_kernel<true, true> : slx_cloud_fused_kernel<true, false>)
-                   : (wide ? slx_cloud_fused_kernel<false, true> : slx_cloud_fused_kernel<false, false>);
+    if (q.rows_per_part > SLX_CLOUD_MAX_ROWS) return (int)hipErrorInvalidValue;
+    typedef void (*cloud_fn)(const SlxCloudFused);
+    constexpr unsigned kTall = SLX_CLOUD_MAX_ROWS / 64u;
+    static const cloud_fn table[2][2][2] = {
+        {{slx_cloud_fused_kernel<false, false, 4>, slx_cloud_fused_kernel<false, false, kTall>}, {slx_cloud_fused_kernel<false, true, 4>, slx_cloud_fused_kernel<false, true, kTall>}},
+        {{slx_cloud_fused_kernel<true, false, 4>, slx_cloud_fused_kernel<true, false, kTall>}, {slx_cloud_fused_kernel<true, true, 4>, slx_cloud_fused_kernel<true, true, kTall>}}};
+    const cloud_fn fn = table[fast ? 1 : 0][wide ? 1 : 0][q.rows_per_part > 256 ? 1 : 0];
     const size_t lds = slx_cloud_fused_lds_bytes(q.rows_per_part);
     hipLaunchKernelGGL(fn, dim3((unsigned)(q.groups * q.parts)), dim3(SLX_CLOUD_THREADS), lds, (hipStream_t)stream, q);
     return (int)hipGetLastError();

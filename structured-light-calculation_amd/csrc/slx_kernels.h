@@ -101,6 +101,7 @@ int slx_launch_cloud_write(const SlxKParams &kp, const double *z, const unsigned
 // (one per 16 words), then one total and 16 column counts per part.  epoch: launches since the words were zeroed.
 #define SLX_CLOUD_THREADS 512        /* threads of a workgroup: 8 waves, a wave per column in the write phase */
 #define SLX_CLOUD_COUNTERS 64        /* ticket counters (classes of workgroup indices), 128 bytes apart */
+#define SLX_CLOUD_MAX_ROWS 448       /* rows of a part at most (the kernel keeps x, y of its columns in registers: 2 columns x 7 chunks of 64 rows per wave) */
 struct SlxCloudFused {
     const double *z;
     double *xyz;                               // null: only the number of points
@@ -184,9 +185,6 @@ int slx_plan_launch(const SlxKParams &kp, int mode, bool aux, int n_sets, int va
 // Returns 0, or a hipError_t value.  `variant` selects a kernel variant, `tune` (may be null) the item geometry.
 // Host-side record of a context's queue counters (slx_stream_kernel): the geometry they were last zeroed for and the launches since.
 #define SLX_STREAM_MAX_QUEUES 256
-// 1: the planner takes the stream kernel by itself for launches with the optional planes (x, y, U, k); 0: only when asked (slx_set_tuning
-// stream = 2).  Decided by the same-box A/B of round 5.
-#define SLX_STREAM_AUX_DEFAULT 0
 struct SlxStreamState {
     unsigned *counters = nullptr;               // device, SLX_STREAM_MAX_QUEUES * 32 words
     unsigned long long key = 0;                 // geometry the counters count for (0: none yet)

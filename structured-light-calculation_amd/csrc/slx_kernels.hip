@@ -1269,17 +1269,12 @@ __global__ __launch_bounds__(256) void slx_strip_kernel(const SlxKParams p)
 // Counters: one 32-bit word per queue, 128 bytes apart (p.sq_counters); a launch adds exactly K_q + W_q to counter q (K_q items,
 // one failing ticket per wave), so launch number e of a geometry starts at e (K_q + W_q) and nothing is reset between launches
 // (the host zeroes them when the geometry changes, slx_launch_fused).
-// AUX: also the optional planes the reference computes beside z for every frame -- x, y (R/CCalculation.cpp:756-771), the projector
-// column U, the fringe orders k, the (all-valid) mask -- exactly as slx_strip_kernel<..., AUX> emits them: NA store instructions per
-// row whatever was asked for (a plane that was not is stored against an empty descriptor), so that the counted waits stay exact.
-template <int F, bool AUX>
+template <int F>
 __global__ __launch_bounds__(256) void slx_stream_kernel(const SlxKParams p)
 {
     constexpr int NPH = F * 4;                     // planes of a row = one ring chunk
     constexpr unsigned ROW_DW = NPH * 64;
     constexpr int NZ = 2;
-    constexpr int NK = F > 1 ? F - 1 : 0;          // planes of fringe orders
-    constexpr int NA = AUX ? 6 + NK + 1 : 0;       // store instructions of the optional planes per row: x, y, U (2 each), k, mask
     typedef double vec2 __attribute__((ext_vector_type(2)));
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     typedef __attribute__((address_space(3))) void lds_void;
@@ -1287,9 +1282,8 @@ __global__ __launch_bounds__(256) void slx_stream_kernel(const SlxKParams p)
     const unsigned t = threadIdx.x;
     const unsigned lane = t & 63u;
     const unsigned wave_in_wg = __builtin_amdgcn_readfirstlane(t >> 6);
-    uint32_t *ring = lds_raw + wave_in_wg * (2u * ROW_DW + 512u + (AUX ? 512u : 0u));
+    uint32_t *ring = lds_raw + wave_in_wg * (2u * ROW_DW + 512u);
     vec2 *stage = reinterpret_cast<vec2 *>(ring + 2u * ROW_DW);
-    vec2 *stage2 = stage + 128;                    // AUX only
 
     // ---- this wave's queue
     const unsigned waves_per_wg = blockDim.x >> 6;
@@ -1399,31 +1393,6 @@ __global__ __launch_bounds__(256) void slx_stream_kernel(const SlxKParams p)
     // the staged row waiting for its (one step late) stores
     __amdgpu_buffer_rsrc_t prsrc = zrsrc;
     unsigned pend_off[2] = {0xFFFFFFF0u, 0xFFFFFFF0u};
-    // the optional planes of the compute side's frame-set: a descriptor per plane (an empty one for a plane that was not asked for),
-    // the lane's own quad in the 4-byte and 1-byte planes, the reciprocals of the two divisors of a7's second pass
-    __amdgpu_buffer_rsrc_t xrsrc = zrsrc, yrsrc = zrsrc, Ursrc = zrsrc, mrsrc = zrsrc, krsrc[NK > 0 ? NK : 1];
-    unsigned own_px = 0;
-    double rfu = 0.0, rfv = 0.0;
-    auto aux_planes_of = [&](unsigned set) {
-        auto plane = [&](const void *base, size_t planes_per_set, size_t qq, unsigned elem) {
-            const char *b = base ? static_cast<const char *>(base) + ((size_t)set * planes_per_set + qq) * p.out_set_stride * elem : nullptr;
-            return __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(uniform_ptr(b ? b : reinterpret_cast<const char *>(p.z))), 0, b ? H * W * elem : 0u, 0x00020000);
-        };
-        xrsrc = plane(p.x, 1, 0, 8);
-        yrsrc = plane(p.y, 1, 0, 8);
-        Ursrc = plane(p.U, 1, 0, 8);
-        mrsrc = plane(p.mask, 1, 0, 1);
-#pragma unroll
-        for (int f = 0; f < NK; f++) krsrc[f] = plane(p.k, NK, f, 4);
-    };
-    unsigned aux_set = A.set;
-    if constexpr (AUX) {
-        aux_planes_of(A.set);
-        own_px = (A.row_base + sub) * W + cq * SLX_QUAD;
-        rfu = slx_refined_rcp_f64(p.fu);
-        rfv = slx_refined_rcp_f64(p.fv);
-    }
-
     issue_chunk(0);                                                // rows 0 and 1 of the first item (R >= 2)
     issue_chunk(1);
     unsigned ahead = 2;                                            // chunks requested and not yet waited for
@@ -1438,16 +1407,11 @@ __global__ __launch_bounds__(256) void slx_stream_kernel(const SlxKParams p)
         // issue and its wait and nothing else (a variable carried around the loop is live everywhere, and the allocator then saves and
         // restores its register around whatever needs scalar registers -- harmless after the wait, fatal inside the window;
         // tests/test_kernel_resources.py pins the compiled code)
-        // The optional-plane instantiations are short of scalar registers (hipcc spilled the pending register into a vector lane right
-        // behind the atomic: the placeholder, not the ticket): they take the ticket in ONE asm statement at the place of the wait and pay its
-        // latency once per item.
         unsigned next_raw;
-        if (!AUX && ri == 0) fetch_issue(next_raw);
+        if (ri == 0) fetch_issue(next_raw);
         // counted wait for chunk s (vmcnt retires in issue order): L(s) | Z(s-2) L(s+1) | wait -- as in slx_strip_kernel
-        //   with the optional planes:  L(s) A(s-2) | Z(s-2) L(s+1) A(s-1) | wait
         if (ahead < 2u) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else if (s >= 2u) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPH + NZ + 2 * NA) : "memory");
-        else if (s == 1u) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPH + NA) : "memory");
+        else if (s >= 2u) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPH + NZ) : "memory");
         else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPH) : "memory");
         ahead--;
         if (s > 0) {                                               // last row's stores, one step late
@@ -1476,8 +1440,7 @@ __global__ __launch_bounds__(256) void slx_stream_kernel(const SlxKParams p)
         }
         // the slot is free once it has been read -- and the ticket requested above has arrived with the same wait
         if (ri == 0) {
-            if constexpr (AUX) asm volatile("s_mov_b32 %0, 1\n\ts_atomic_add %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=&s"(next_raw) : "s"(ctr) : "memory");
-            else fetch_wait(next_raw);
+            fetch_wait(next_raw);
             B = decode(next_raw);
         } else {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1489,17 +1452,8 @@ __global__ __launch_bounds__(256) void slx_stream_kernel(const SlxKParams p)
             ahead++;
         }
         __builtin_amdgcn_s_setprio(0);
-        double z[SLX_QUAD], Uo[SLX_QUAD];
-        int kf[NK > 0 ? NK : 1][SLX_QUAD];
-        if constexpr (AUX) {                                        // the optional planes' stores below run for every lane, rows past the tile included
-#pragma unroll
-            for (int jx = 0; jx < SLX_QUAD; jx++) z[jx] = 0.0, Uo[jx] = 0.0;
-#pragma unroll
-            for (int f = 0; f < NK; f++)
-#pragma unroll
-                for (int jx = 0; jx < SLX_QUAD; jx++) kf[f][jx] = 0;
-        }
         if (row < H) {
+            double z[SLX_QUAD];
             const double vc = (double)((int)row + p.row_offset) - p.cy;
             const double vf = vc * p.fu;
             const double tvC = vf * p.P01, tvD = vf * p.P21;
@@ -1513,10 +1467,8 @@ __global__ __launch_bounds__(256) void slx_stream_kernel(const SlxKParams p)
                 for (int f = 1; f < F; f++) {
                     int kk;
                     Uf = unwrap_stage<true>(Uf, (double)pix[f][jx], p.period[f], p.inv_period[f], hb[f], kk);
-                    if constexpr (AUX && NK > 0) kf[f - 1][jx] = kk;
                 }
 #endif
-                if constexpr (AUX) Uo[jx] = Uf;
                 const double cC = (aC[jx] + tvC) + p.K1;
                 const double cD = (aD[jx] + tvD) + p.K2;
 #if SLX_EXP & 4
@@ -1528,38 +1480,6 @@ __global__ __launch_bounds__(256) void slx_stream_kernel(const SlxKParams p)
             stage[2 * lane + 0] = vec2{z[0], z[1]};
             stage[2 * lane + 1] = vec2{z[2], z[3]};
 
-        }
-        if constexpr (AUX) {
-            // a7, second pass (R/CCalculation.cpp:756-771): x = (z uc)/fu, y = (z vc)/fv from the final depth; then the planes leave in
-            // this order, NA store instructions in all, whatever was asked for (as in slx_strip_kernel)
-            double xo[SLX_QUAD], yo[SLX_QUAD];
-            const double vc = (double)((int)row + p.row_offset) - p.cy;
-#pragma unroll
-            for (int jx = 0; jx < SLX_QUAD; jx++) {
-                const double uc = (double)(int)(cq * SLX_QUAD + jx) - p.cx;
-                xo[jx] = slx_div_item_const(z[jx] * uc, p.fu, rfu);
-                yo[jx] = slx_div_item_const(z[jx] * vc, p.fv, rfv);
-            }
-            auto emit_f64 = [&](const double (&v)[SLX_QUAD], __amdgpu_buffer_rsrc_t r) {
-                stage2[2 * lane + 0] = vec2{v[0], v[1]};
-                stage2[2 * lane + 1] = vec2{v[2], v[3]};
-                __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                for (int k = 0; k < 2; k++) {
-                    const u32x4 t4 = *reinterpret_cast<const u32x4 *>(stage2 + k * 64 + lane);
-                    __builtin_amdgcn_raw_buffer_store_b128(t4, r, out_boff[k], 0, 2 /* nt */);   // out_boff: this row's slots (z follows next step)
-                }
-                __builtin_amdgcn_wave_barrier();
-            };
-            emit_f64(xo, xrsrc);
-            emit_f64(yo, yrsrc);
-            emit_f64(Uo, Ursrc);
-#pragma unroll
-            for (int f = 0; f < NK; f++) {
-                const u32x4 k4 = {(unsigned)kf[f][0], (unsigned)kf[f][1], (unsigned)kf[f][2], (unsigned)kf[f][3]};
-                __builtin_amdgcn_raw_buffer_store_b128(k4, krsrc[f], own_px * 4u, 0, 2);
-            }
-            __builtin_amdgcn_raw_buffer_store_b32(0x01010101u, mrsrc, own_px, 0, 2);           // every pixel valid outside the Gray-mask mode
         }
         // this row's stores go out at the top of the next step
         prsrc = zrsrc;
@@ -1573,11 +1493,6 @@ __global__ __launch_bounds__(256) void slx_stream_kernel(const SlxKParams p)
             A = B;
             ri = 0;
             row = A.row_base + sub;
-            if constexpr (AUX) {
-                if (A.set != uniform_u32(aux_set)) aux_planes_of(A.set);   // a queue stays in a frame-set for hundreds of items
-                aux_set = A.set;
-                own_px = (A.row_base + sub) * W + cq * SLX_QUAD;
-            }
             zrsrc = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(p.z + (size_t)A.set * p.out_set_stride), 0, H * W * 8u, 0x00020000);
             out_boff[0] = out_lane[0] + A.row_base * W * 8u;
             out_boff[1] = out_lane[1] + A.row_base * W * 8u;
@@ -1585,7 +1500,6 @@ __global__ __launch_bounds__(256) void slx_stream_kernel(const SlxKParams p)
             row += il;
             out_boff[0] += out_step;
             out_boff[1] += out_step;
-            if constexpr (AUX) own_px += il * W;
         }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1973,10 +1887,10 @@ int slx_launch_fused(const SlxKParams &kp_in, int mode, bool aux, int n_sets, in
         }
         kp.sq_epoch = st->epoch++;
         switch (kp.n_freq) {
-        case 1: fn = aux ? slx_stream_kernel<1, true> : slx_stream_kernel<1, false>; break;
-        case 2: fn = aux ? slx_stream_kernel<2, true> : slx_stream_kernel<2, false>; break;
-        case 3: fn = aux ? slx_stream_kernel<3, true> : slx_stream_kernel<3, false>; break;
-        default: fn = aux ? slx_stream_kernel<4, true> : slx_stream_kernel<4, false>; break;
+        case 1: fn = slx_stream_kernel<1>; break;
+        case 2: fn = slx_stream_kernel<2>; break;
+        case 3: fn = slx_stream_kernel<3>; break;
+        default: fn = slx_stream_kernel<4>; break;
         }
     } else if (!plan.strip) {
         fn = pick(mode, kp.n_freq, kp.n_steps == 4, aux);

@@ -31,14 +31,20 @@ size_t slx_cloud_fused_words(int groups, int parts) { return (size_t)SLX_CLOUD_C
 bool slx_cloud_fused_plan(int W, int H, unsigned n_cus, int *groups, int *parts, int *rows_per_part)
 {
     if (W < 1 || H < 1 || (unsigned long long)W * (unsigned)H >= (1ull << 31)) return false;   // 32-bit point counts and offsets
-    int R = H >= 256 ? 256 : (H + 63) / 64 * 64;
+#ifndef SLX_CLOUD_PART_ROWS
+#define SLX_CLOUD_PART_ROWS 256      /* experiments: -DSLX_CLOUD_PART_ROWS=128 | 192 (tools/cloud_bench.py --lib) */
+#endif
+    int R = H >= SLX_CLOUD_PART_ROWS ? SLX_CLOUD_PART_ROWS : (H + 63) / 64 * 64;
     if ((H + R - 1) / R > 16) R = ((H + 15) / 16 + 63) / 64 * 64;
     const int P = (H + R - 1) / R;
     const size_t lds = slx_cloud_fused_lds_bytes(R) + 2048u;        // + the kernel's static words
-    if (P > 16 || lds > 64u * 1024u) return false;                  // (64 KiB: the dynamic LDS a launch gets without asking for more)
+    if (P > 16 || R > SLX_CLOUD_MAX_ROWS || lds > 64u * 1024u) return false;   // (64 KiB: the dynamic LDS a launch gets without asking for more)
     // the look-back waits for the sibling parts of a column group, whose tickets are adjacent: they must be able to be resident together
     const unsigned long long cus = n_cus ? n_cus : 256u;
-    const unsigned long long resident = cus * std::min<unsigned long long>(2048u / SLX_CLOUD_THREADS, 160u * 1024u / lds);
+    // workgroups of 8 waves a CU keeps: by LDS, and by registers (74 VGPRs with 4 chunks per part: 6 waves per SIMD = 3 workgroups; 98 with
+    // 7 chunks: 5 waves per SIMD = 2 workgroups)
+    const unsigned long long by_regs = R > 256 ? 2u : 3u;
+    const unsigned long long resident = cus * std::min<unsigned long long>(by_regs, 160u * 1024u / lds);
     if (resident < (unsigned long long)P) return false;
     const long long G = ((long long)W + 15) / 16;
     if (G * P >= (1ll << 24)) return false;
@@ -236,9 +242,11 @@ int slx_plan_launch(const SlxKParams &kp_in, int mode, bool aux, int n_sets, int
         kp.gray_step = (unsigned)(kp.gray[1] - kp.gray[0]);
         if (kp.gray_step < 256u) kp.dma_imm = 0;
     }
-    // Stream kernel (slx_kernels.hip: slx_stream_kernel): the Gray-free 4-step depth-only class, launches that fill the chip many times over
+    // Stream kernel (slx_kernels.hip: slx_stream_kernel): the Gray-free 4-step depth-only class, launches that fill the chip many times over.
+    // (An instantiation with the optional planes x, y, U, k was built and measured in round 5 -- C4 x 8 / 16 / 32 frame-sets: +1.5 / -1.6 /
+    // -0.6 % against the strip kernel on the same box -- and is not in the tree: profiles/experiments/r05_stream_kernel_optional_planes.patch.)
     plan->stream = 0;
-    if (!decoder && mode == SLX_MODE_MULTIFREQ && kp.n_steps == 4 && kp.sq_counters && tn.stream != 1 && tn.weave <= 1 && (!aux || SLX_STREAM_AUX_DEFAULT || tn.stream == 2)) {
+    if (!decoder && mode == SLX_MODE_MULTIFREQ && kp.n_steps == 4 && !aux && kp.sq_counters && tn.stream != 1 && tn.weave <= 1) {
         const unsigned il = 64u / g;                                     // no weave: the queues hand the rows out in order anyway
         const unsigned cpg = il * QR / 64u;
         const unsigned R = (tn.stream_rows >= 2 && tn.stream_rows <= 16) ? (unsigned)tn.stream_rows : 2u;   // measured: 2 rows 270, 4: 274, 8: 284, 16: 302 us (C4 x 32)
@@ -247,11 +255,10 @@ int slx_plan_launch(const SlxKParams &kp_in, int mode, bool aux, int n_sets, int
         const unsigned cus = kp.n_cus ? kp.n_cus : 256u;
         // resident waves per CU: 16 (4 per SIMD) in 4-wave workgroups; experiments: strip_waves = w makes w-wave workgroups and as many
         // of them as the CU's 160 KiB of LDS hold (1-wave workgroups: 20 waves per CU = 5 per SIMD)
-        const unsigned lds_w0 = 2u * (unsigned)kp.n_freq * 4u * 256u + 2048u + (aux ? 2048u : 0u);   // + the optional planes' staging area
+        const unsigned lds_w0 = 2u * (unsigned)kp.n_freq * 4u * 256u + 2048u;
         const unsigned wpw = (tn.strip_waves >= 1 && tn.strip_waves <= 4) ? (unsigned)tn.strip_waves : 4u;
         const unsigned per_cu = std::min(32u, wpw * (160u * 1024u / (wpw * lds_w0)));
-        // (with the optional planes the 4-frequency instantiation needs more than 128 VGPRs: 3 waves per SIMD, tests/test_kernel_resources.py)
-        const unsigned long long waves = (unsigned long long)cus * (tn.strip_waves ? per_cu : (aux && kp.n_freq >= 4) ? 12u : 16u);
+        const unsigned long long waves = (unsigned long long)cus * (tn.strip_waves ? per_cu : 16u);
         // Queues: a wave polls queue (its number) % queues, so every queue that holds items needs a wave of its own residue -- at most
         // as many queues as the launch has waves (a partitioned or small device: fewer than 255 resident waves), else a queue's row
         // groups would never be decoded

@@ -485,7 +485,7 @@ static void test_cloud_plans()
             for (unsigned cus : {0u, 1u, 2u, 8u, 256u}) {
                 int G = -1, P = -1, R = -1;
                 if (!slx_cloud_fused_plan(W, H, cus, &G, &P, &R)) {
-                    CHECK(H > 4096 || cus == 1u || cus == 2u || (unsigned long long)W * H >= (1ull << 31) || W > 16 * (1 << 20));   // the refused ones are the expected ones
+                    CHECK(H > 4096 || cus == 1u || cus == 2u || cus == 8u || (unsigned long long)W * H >= (1ull << 31) || W > 16 * (1 << 20));   // the refused ones are the expected ones
                     continue;
                 }
                 planned++;
@@ -493,7 +493,8 @@ static void test_cloud_plans()
                 CHECK((long long)P * R >= H && (long long)(P - 1) * R < H);                       // the last part starts inside the map
                 CHECK(slx_cloud_fused_lds_bytes(R) + 2048u <= 64u * 1024u);
                 CHECK(slx_cloud_fused_words(G, P) == (size_t)SLX_CLOUD_COUNTERS * 16u + (size_t)G * P * 17u);
-                const unsigned long long resident = (cus ? cus : 256u) * std::min<unsigned long long>(2048u / SLX_CLOUD_THREADS, 160u * 1024u / (slx_cloud_fused_lds_bytes(R) + 2048u));
+                const unsigned long long resident = (cus ? cus : 256u) * std::min<unsigned long long>(R > 256 ? 2u : 3u, 160u * 1024u / (slx_cloud_fused_lds_bytes(R) + 2048u));
+                CHECK(R <= SLX_CLOUD_MAX_ROWS);
                 CHECK(resident >= (unsigned long long)P);
             }
     CHECK(planned > 200);

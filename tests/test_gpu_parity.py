@@ -164,52 +164,6 @@ def test_stream_kernel_geometries_and_repeated_launches(api, oracle, synth, torc
         assert np.array_equal(z[0].cpu().numpy(), refs[0], equal_nan=True)
 
 
-@pytest.mark.parametrize("name,shape,n_sets", [("C4", (516, 71), 9), ("C2", (320, 33), 20), ("C1", (192, 150), 6), ("C5x4", (260, 64), 5), ("C4", (1920, 150), 4)])
-def test_stream_kernel_with_optional_planes(api, oracle, synth, torch_cuda, name, shape, n_sets):
-    """slx_stream_kernel<F, true>: x, y, U, the fringe orders and the mask beside z from the resident-wave kernel (stream = 2 asks for it:
-    the planner does not take it by itself for launches with optional planes), every rows-per-item choice, a subset of the planes
-    (the others go to an empty descriptor), a plane stride, repeated launches; every plane of every frame-set against the oracle."""
-    torch = torch_cuda
-    spec = small_spec(synth, "C5" if name == "C5x4" else name, *shape)
-    spec["n_steps"] = 4
-    H, W, F = spec["height"], spec["width"], spec["n_freq"]
-    sets = [synth.random_planes(spec, seed=7100 + s)[0] for s in range(n_sets)]
-    names = ("z", "x", "y", "U", "mask") + (("k",) if F > 1 else ())
-    refs = [oracle.pipeline(spec, p, None, want=names) for p in sets]
-    ph = torch.from_numpy(np.stack(sets)).cuda()
-    per = H * W + 8                                                   # a plane stride (a multiple of 4 elements: 16-byte stores in the 4-byte planes too)
-    with api.Context(spec) as ctx:
-        ctx.set_variant(2)
-        for rows, want in ((2, names), (3, ("z", "y", "k") if F > 1 else ("z", "y")), (16, names), (0, ("z", "x", "mask")), (5, names)):
-            ctx.set_tuning(stream=2, stream_rows=rows)
-            for rep in range(2):
-                outs = {}
-                for w in want:
-                    planes = F - 1 if w == "k" else 1
-                    dt = {"k": torch.int32, "mask": torch.uint8}.get(w, torch.float64)
-                    outs[w] = torch.full((n_sets * planes * per + 16,), 7 if w == "mask" else -7, dtype=dt, device="cuda")
-                torch.cuda.synchronize()
-                ctx.decode_batch_ex(n_sets, ph, None, plane_stride=per, **outs)
-                ctx.synchronize()
-                assert ctx.last_kernel().startswith("slx_stream_kernel<%d, true>:" % F), ctx.last_kernel()
-                for s_ in range(n_sets):
-                    for w in want:
-                        planes = F - 1 if w == "k" else 1
-                        got = outs[w].cpu().numpy()
-                        for q in range(planes):
-                            g = got[(s_ * planes + q) * per:(s_ * planes + q) * per + H * W].reshape(H, W)
-                            r = refs[s_][w][q] if w == "k" else refs[s_][w]
-                            assert np.array_equal(g, r, equal_nan=True), (rows, rep, s_, w, q)
-                # nothing outside the planes was touched: the strides' padding and the tail keep their fill
-                for w in want:
-                    planes = F - 1 if w == "k" else 1
-                    got = outs[w].cpu().numpy()
-                    fill = 7 if w == "mask" else -7
-                    for i in range(n_sets * planes):
-                        assert (got[i * per + H * W:(i + 1) * per] == fill).all(), (rows, w, i)
-                    assert (got[n_sets * planes * per:] == fill).all()
-
-
 def test_gray_and_phase_groups_far_apart_in_memory(api, oracle, synth, torch_cuda):
     """The two plane groups of a batch are separate allocations and may sit anywhere: here more than 2 GiB apart, in either order
     (the Gray planes ride the DMA ring through a descriptor of their own; round 3's single descriptor made such a launch fall back
@@ -1363,7 +1317,7 @@ def test_full_size_batch_properties(api, oracle, synth, torch_cuda):
     with api.Context(spec) as ctx:
         ctx.decode_batch(n_sets, batch, None, z)
         ctx.synchronize()
-        assert ctx.last_kernel() == "slx_stream_kernel<3, false>: resident waves, 2-row items from queues", ctx.last_kernel()   # the headline launch (bench.py)
+        assert ctx.last_kernel() == "slx_stream_kernel<3>: resident waves, 2-row items from queues", ctx.last_kernel()   # the headline launch (bench.py)
         first = z.clone()
         r0, r1 = torch.from_numpy(ref0).cuda(), torch.from_numpy(ref1).cuda()
         for s in range(n_sets):

@@ -5,7 +5,8 @@ import collections, csv, glob, json, os, re, sys
 tag, config, sets, prefix = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
 out = "profiles"
 os.makedirs(out, exist_ok=True)
-stats = sorted(glob.glob("gpurun_out/prof_%s/trace/*/*kernel_stats.csv" % tag), key=os.path.getmtime)[-1]
+# the bench runs tools/membench as a child process, which the profiler traces into files of its own: take the decode's
+stats = [f for f in sorted(glob.glob("gpurun_out/prof_%s/trace/*/*kernel_stats.csv" % tag), key=os.path.getmtime) if "slx_" in open(f).read()][-1]
 rows = list(csv.reader(open(stats)))
 csv.writer(open(os.path.join(out, prefix + "_kernel_stats.csv"), "w")).writerows([rows[0]] + [r for r in rows[1:] if "slx_" in r[0]])
 trace = stats.replace("kernel_stats", "kernel_trace")
