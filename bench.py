@@ -896,6 +896,8 @@ def run_rank(args):
                 torch.cuda.synchronize()
                 tg = time.perf_counter() - t0g
                 progress.update(phase="gather_only", step=None)
+                gather_only()                      # untimed: the staged shape's slots grow to a whole step's tiles on the first call
+                drain()
                 fence()
                 n_go = max(3, min(n_steps, 10))
                 t0o = time.perf_counter()

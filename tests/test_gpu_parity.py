@@ -951,13 +951,16 @@ def test_point_cloud(api, oracle, synth, name, shape, passes):
         assert ctx.get_point_cloud().shape == (0, 3) and ctx.get_point_cloud_view().shape == (0, 3)
 
 
-@pytest.mark.parametrize("shape", [(1, 1), (3, 17), (33, 16), (255, 31), (256, 48), (257, 33), (700, 130), (1200, 1920), (3000, 250), (4500, 40), (5000, 20)])
+@pytest.mark.parametrize("shape", [(1, 1), (3, 17), (33, 16), (255, 31), (256, 48), (257, 33), (700, 130), (1200, 1920), (3000, 250), (4500, 40), (5000, 20),
+                                   (3000, 4096)])
 def test_fused_point_cloud_geometries(api, oracle, synth, torch_cuda, shape):
     """slx_cloud_fused_kernel's work split -- column groups of 16 (ragged last group), parts of 256 rows (ragged last part, one part
     shorter than a pass of the lanes, more rows per part on maps taller than 16 x 256) -- on depth planes of unstructured content
     (a third of the depths outside the FOV, NaNs and infinities among them) through slx_point_cloud_of_depth: cloud_passes = 1
     (the fused launch or an error) must equal the two-launch path and the oracle's order byte for byte; launch after launch on
-    one context (the ticket counter and the epoch tags carry over), into host memory, into a device buffer, count only."""
+    one context (the ticket counters and the epoch tags carry over), into host memory, into a device buffer, count only.  The last
+    shape (config 5's 4096 x 3000) is 3 072 workgroups for the 768 the chip keeps resident: the look-back's waits must also
+    resolve when the parts run in several rounds."""
     torch = torch_cuda
     h, w = shape
     spec = small_spec(synth, "C4", w, h)
