@@ -872,6 +872,64 @@ def test_contexts_on_concurrent_host_threads(api, oracle, synth, torch_cuda):
     assert not any(t.is_alive() for t in threads)
 
 
+def test_fused_point_cloud_beside_a_chip_filling_decode(api, oracle, synth, torch_cuda):
+    """The fused point-cloud kernel's look-back spins on words other workgroups publish; its liveness argument (slx_cloud.hip) must
+    hold when the chip is full of somebody else's waves.  Thread A keeps a second context decoding configuration 4's 32-frame-set
+    batch back to back (a launch that fills every CU many times over, the stream kernel's resident waves); thread B takes 150
+    clouds of two 1920 x 1200 depth maps through the fused launch meanwhile.  Every cloud must be the oracle's; both threads finish."""
+    import threading
+    torch = torch_cuda
+    spec = synth.make_spec("C4")
+    H, W = spec["height"], spec["width"]
+    rng = np.random.default_rng(4242)
+    planes = [rng.uniform(50.0, 1200.0, size=(H, W)) for _ in range(2)]
+    planes[1][:, ::7] = 5000.0
+    refs = [oracle.point_cloud(spec, zz) for zz in planes]
+    z = torch.from_numpy(np.stack(planes)).cuda()
+    batch = torch.randint(0, 256, (32, 12, H, W), dtype=torch.uint8, device="cuda")
+    zb = torch.empty((32, H, W), dtype=torch.float64, device="cuda")
+    dev = torch.empty((H * W, 3), dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    stop, errors, done = threading.Event(), [], {"decodes": 0, "clouds": 0}
+
+    def decoder():
+        try:
+            with api.Context(spec) as ctx:
+                while not stop.is_set():
+                    for _ in range(20):
+                        ctx.decode_batch(32, batch, None, zb)
+                    ctx.synchronize()
+                    done["decodes"] += 20
+        except BaseException as e:
+            errors.append("decoder: %r" % (e,))
+
+    def clouds():
+        try:
+            with api.Context(spec) as ctx:
+                ctx.set_tuning(cloud_passes=1)
+                for rep in range(150):
+                    k = rep & 1
+                    n = ctx.point_cloud_of_depth(z[k], out=dev)
+                    assert n == len(refs[k]), (rep, n, len(refs[k]))
+                    if rep % 10 == 0:
+                        assert np.array_equal(dev[:n].cpu().numpy(), refs[k]), rep
+                    done["clouds"] += 1
+        except BaseException as e:
+            errors.append("clouds: %r" % (e,))
+        finally:
+            stop.set()
+
+    ta, tb = threading.Thread(target=decoder), threading.Thread(target=clouds)
+    ta.start()
+    tb.start()
+    tb.join(240)
+    stop.set()
+    ta.join(60)
+    assert not errors, errors
+    assert not ta.is_alive() and not tb.is_alive()
+    assert done["clouds"] == 150 and done["decodes"] >= 20, done
+
+
 def test_error_paths_on_device(api, synth):
     spec = small_spec(synth, "C1x4", 32, 8)
     ph, gr = synth.random_planes(spec, seed=1)
