@@ -38,6 +38,27 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+_RESULT_FD = None
+
+
+def keep_stdout_for_the_result():
+    """Rank 0 prints ONE JSON line on stdout and nothing else.  Libraries do not know that: RCCL prints a version banner on stdout when
+    NCCL_DEBUG is set (found by the one-rank RCCL rehearsal of round 5: four banner lines in front of the JSON line under a launcher
+    that passes stdout through).  So the process keeps a private duplicate of stdout for the result line and points file descriptor 1
+    at stderr for everybody else."""
+    global _RESULT_FD
+    if _RESULT_FD is None:
+        sys.stdout.flush()
+        _RESULT_FD = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
+
+
+def emit(line):
+    out = _RESULT_FD or sys.stdout
+    out.write(line + "\n")
+    out.flush()
+
+
 def ensure_built():
     """`make` of the HIP library and the oracle under a file lock (a no-op when up to date): one rank builds, the others
     wait.  Runs before any GPU call of this process."""
@@ -401,6 +422,10 @@ def parse_args(argv=None):
     ap.add_argument("--gather-chunk", type=int, default=8, help="frame-sets per pipelined decode+gather chunk")
     ap.add_argument("--gather-timeout", type=float, default=240.0,
                     help="N > 1: seconds the whole with_gather phase may take before the line is printed without it (a stuck collective must not cost the decode-only result)")
+    ap.add_argument("--gather-world-of-one", action="store_true",
+                    help="N = 1 rehearsal of the N > 1 code path ON RCCL: a one-rank process group and communicator, every with_gather measurement "
+                         "(both gather shapes, the gather alone, the checksums) run through the same code the 8-GPU run executes; the line's value "
+                         "stays the decode's (there is nobody to gather from)")
     ap.add_argument("--backend", default=None, help="nccl (= RCCL, default on GPUs) or gloo (one-GPU rehearsal of the multi-rank path)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="allow --gpus N on a box with fewer GPUs: the ranks share GPU 0 and talk over gloo (RCCL refuses two ranks on one device)")
@@ -501,6 +526,7 @@ def launch_ranks(args, argv):
 
 # -------------------------------------------------------------------------------------------------------- one rank
 def run_rank(args):
+    keep_stdout_for_the_result()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -534,7 +560,10 @@ def run_rank(args):
     dev_index = 0 if shared_gpu else local_rank % n_dev
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
-    if world > 1:
+    solo_gather = world == 1 and args.gather_world_of_one and not args.no_gather
+    if solo_gather:
+        os.environ.setdefault("MASTER_PORT", str(free_port()))
+    if world > 1 or solo_gather:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("NCCL_DEBUG", "WARN")      # RCCL is silent by default: a failing collective should say why in the log
         if backend == "nccl":
@@ -743,7 +772,7 @@ def run_rank(args):
             "achieved_hbm_gbps_per_gpu": achieved, "kernel_only": kernel_only, "power": power,
             # rccl_world_size: ncclCommCount of the communicator the gather ran on (slx_comm_info asks RCCL), null when no RCCL
             # communicator existed (N = 1, --no-gather, the one-GPU gloo rehearsal); torch's own count sits beside it
-            "rccl_world_size": rccl_info["world"], "rccl_rank_of_rank0": rccl_info["rank"], "torch_world_size": (dist.get_world_size() if world > 1 else 1),
+            "rccl_world_size": rccl_info["world"], "rccl_rank_of_rank0": rccl_info["rank"], "torch_world_size": (dist.get_world_size() if (world > 1 or solo_gather) else 1),
             "collective_backend": (backend if world > 1 else None),
             "cpu_baseline": cpu_single, "cpu_baseline_all_cores": cpu_multi,
             "parity_vs_oracle": parity, "other_configs": other, "with_gather": gather,
@@ -759,7 +788,7 @@ def run_rank(args):
     headline_shape = [None]         # ... and which shape that was
     stuck_at = [None]               # set by the watchdog: where the collective phase hung
     gather_ok = True
-    if world > 1 and not args.no_gather:
+    if (world > 1 or solo_gather) and not args.no_gather:
         import threading
         gather = {}
         progress = {"split": None, "phase": "setup", "step": None}
@@ -779,7 +808,7 @@ def run_rank(args):
                 g = dict(gather)
                 g["error"] = ("the with_gather phase did not finish within %.0f s and was abandoned (rank 0 in split=%s phase=%s step=%s)"
                               % (args.gather_timeout, progress["split"], progress["phase"], progress["step"]))
-                print(json.dumps(make_result(g, headline=headline)), flush=True)
+                emit(json.dumps(make_result(g, headline=headline)))
             # never 0: a hung collective is a fault to be traced (a dead rank, a stuck GPU, the fabric) even when the headline was
             # already measured and checked -- 7 = "headline valid, a later measurement hung", 4 = "no gathered number at all"
             os._exit(7 if headline is not None else 4)
@@ -1066,9 +1095,9 @@ def run_rank(args):
                 except Exception as e:
                     other[label] = {"error": "%s: %s" % (type(e).__name__, e)}
         result = make_result(gather, cpu_single, cpu_multi, parity, other, headline=headline)
-        print(json.dumps(result), flush=True)
+        emit(json.dumps(result))
     ctx.close()
-    if world > 1:
+    if world > 1 or solo_gather:
         import threading
         # the result is out: a peer that never reaches the barrier must not hang the job -- but leaving this way is not a success
         bye = threading.Timer(60.0, lambda: (log("[bench] rank %d: a peer never reached the closing barrier" % rank), os._exit(5)))
@@ -1077,7 +1106,7 @@ def run_rank(args):
         dist.barrier()
         dist.destroy_process_group()
         bye.cancel()
-    if world > 1 and not args.no_gather and not (gather_ok and headline is not None):
+    if (world > 1 or solo_gather) and not args.no_gather and not (gather_ok and headline is not None):
         # the line is out with value null: the gather failed or delivered other bytes than the ranks decoded
         log("[bench] rank %d: a gathered measurement failed or delivered other bytes than the ranks decoded (see with_gather in the line)" % rank)
         sys.exit(6)

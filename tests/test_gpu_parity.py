@@ -1836,6 +1836,32 @@ def test_bench_two_ranks_rehearsed_on_one_gpu():
     assert d["with_gather"]["rows_staged"]["root_staging_bytes"] == 2 * 8 * 600 * 1920 * 8 and d["with_gather"]["rows"]["root_staging_bytes"] == 0
 
 
+def test_bench_gather_code_path_on_rccl_with_one_rank():
+    """`bench.py --gather-world-of-one`: the N > 1 code path of the bench ON RCCL with the one rank this box has -- the process group,
+    the communicator from a unique id, slx_comm_set_gather_shape, slx_decode_gather in chunks, the gather alone, the checksums, for
+    both gather shapes and the frame-set split -- so that the first 8-GPU run does not execute a line of Python or C that never ran.
+    (With one rank nothing travels: the messages themselves are covered by the plan replays and the one-GPU staged test.)"""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gather-world-of-one", "--steps", "20", "--warmup", "5", "--sets-per-gpu", "8",
+                        "--no-cpu-baseline", "--no-other-configs", "--no-traffic-probe", "--no-power-probe"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["rccl_world_size"] == 1 and d["rccl_rank_of_rank0"] == 0 and d["stuck"] is None
+    assert d["value"] == d["kernel_only"]["value"] > 0                 # nobody to gather from: the line's value stays the decode's
+    for key, shape in (("rows", "in_place"), ("rows_staged", "staged"), ("framesets", "in_place")):
+        g = d["with_gather"][key]
+        assert "error" not in g, g
+        assert g["gather_shape"] == shape and g["gathered_equals_local_decodes"] is True and g["gathered_shape"] == [8, 1200, 1920]
+        assert g["messages_at_root_per_step"] == 0 and g["bytes_into_root_per_step"] == 0
+        assert g["end_to_end"]["value"] > 0 and g["kernel_only"]["value"] > 0 and g["gather_only"]["ms_per_step"] >= 0
+
+
 @pytest.mark.parametrize("bits", [1, 3, 6, 7, 8, 10, 12])
 @pytest.mark.parametrize("std_lut", [True, False])
 def test_strip_kernel_gray_widths(api, oracle, synth, bits, std_lut):
