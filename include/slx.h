@@ -408,6 +408,11 @@ int slx_write_point_cloud_text(const char *path, const double *xyz, size_t n_poi
 /* CamMat, ProMat, R, T of the cv::FileStorage YAML Init reads (R/CCalculation.cpp:124-132; format of R/Result.yml). */
 int slx_read_calibration_yaml(const char *path, double cam[9], double pro[9], double rot[9], double trans[3]);
 
+/* The compiled-in configuration of the reference (R/StaticParameters.cpp) as the C++ mirror classes default to it, in this order:
+ * PROJECTOR_RESLINE, PROJECTOR_RESROW, CAMERA_RESLINE, CAMERA_RESROW, GRAY_V_NUMDIGIT, PHASE_NUMDIGIT, FOV_MIN_DISTANCE,
+ * FOV_MAX_DISTANCE, RECO_WINDOW_SIZE, DYNAFRAME_MAXNUM.  *n receives the count (10); SLX_ERR_INVALID_ARG when capacity is smaller. */
+int slx_reference_defaults(int *values, int capacity, int *n);
+
 int slx_version(void);
 
 #ifdef __cplusplus

@@ -32,7 +32,7 @@ SYMBOLS = [
     "slx_get_depth", "slx_get_point_cloud", "slx_point_cloud_of_depth", "slx_track_begin", "slx_track_next", "slx_track_image_buffer", "slx_track_next_batch", "slx_track_stage_frames", "slx_track_frames_buffer", "slx_output_device_ptr", "slx_get_calibration", "slx_enable_timing",
     "slx_last_decode_ms", "slx_debug_stamps", "slx_set_variant", "slx_set_tuning", "slx_last_kernel", "slx_read_bmp_gray", "slx_read_pgm_gray", "slx_read_calibration_yaml", "slx_write_point_cloud_text", "slx_get_point_cloud_view", "slx_version",
     "slx_decode_batch_ex", "slx_comm_unique_id", "slx_comm_create", "slx_comm_adopt", "slx_comm_destroy", "slx_comm_info", "slx_comm_last_error",
-    "slx_comm_synchronize", "slx_gather_depth", "slx_decode_gather", "slx_gather_plan", "slx_gather_plan_ex", "slx_comm_set_gather_shape", "slx_scatter_rows",
+    "slx_comm_synchronize", "slx_gather_depth", "slx_decode_gather", "slx_gather_plan", "slx_gather_plan_ex", "slx_comm_set_gather_shape", "slx_scatter_rows", "slx_reference_defaults",
     "slx_pipe_create", "slx_pipe_destroy", "slx_pipe_layout", "slx_pipe_acquire", "slx_pipe_submit", "slx_pipe_collect", "slx_pipe_last_error",
 ]
 
@@ -128,6 +128,7 @@ def lib():
                                          C.POINTER(C.c_int), C.POINTER(SlxScatter), C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_ulonglong)]
         L.slx_comm_set_gather_shape.argtypes = [vp, C.c_int]
         L.slx_scatter_rows.argtypes = [vp, C.POINTER(SlxScatter), C.c_int, vp, vp, vp]
+        L.slx_reference_defaults.argtypes = [C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_int)]
         L.slx_synchronize.argtypes = [vp]
         L.slx_get_stream.argtypes = [vp, C.POINTER(vp)]
         L.slx_get_output.argtypes = [vp, C.c_int, vp, sz, C.c_int]
@@ -593,6 +594,21 @@ def gather_plan_ex(shards, rank, height, width, first, count, local_plane_stride
         raise SlxError(rc, "slx_gather_plan_ex")
     return ([(m.peer, m.send, m.offset, m.count) for m in buf[: n.value]],
             [(q.src, q.dst, q.run, q.n_runs, q.src_stride, q.dst_stride) for q in sbuf[: ns.value]], st.value)
+
+
+REFERENCE_DEFAULT_NAMES = ("PROJECTOR_RESLINE", "PROJECTOR_RESROW", "CAMERA_RESLINE", "CAMERA_RESROW", "GRAY_V_NUMDIGIT", "PHASE_NUMDIGIT",
+                           "FOV_MIN_DISTANCE", "FOV_MAX_DISTANCE", "RECO_WINDOW_SIZE", "DYNAFRAME_MAXNUM")
+
+
+def reference_defaults():
+    """{name: value} of the reference's compiled-in configuration as the C++ mirror classes default to it (slx_reference_defaults)."""
+    n = C.c_int(0)
+    lib().slx_reference_defaults(None, 0, C.byref(n))
+    v = (C.c_int * n.value)()
+    rc = lib().slx_reference_defaults(v, n.value, C.byref(n))
+    if rc != OK or n.value != len(REFERENCE_DEFAULT_NAMES):
+        raise SlxError(rc, "slx_reference_defaults")
+    return dict(zip(REFERENCE_DEFAULT_NAMES, [int(x) for x in v]))
 
 
 def shard_table(shards):

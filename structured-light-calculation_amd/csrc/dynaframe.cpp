@@ -372,3 +372,17 @@ std::vector<double> CCalculation::GetY() { return Fetch(SLX_OUT_Y); }
 std::vector<double> CCalculation::GetProjectorU() { return Fetch(SLX_OUT_U); }
 
 }  // namespace slx
+
+// The compiled-in configuration the mirror classes default to -- the reference's R/StaticParameters.cpp -- for bindings in other
+// languages and for the test that pins it to the reference's own compiled translation unit.
+extern "C" int slx_reference_defaults(int *values, int capacity, int *n)
+{
+    const slx::StaticParameters sp;
+    const int v[] = {sp.PROJECTOR_RESLINE, sp.PROJECTOR_RESROW, sp.CAMERA_RESLINE, sp.CAMERA_RESROW, sp.GRAY_V_NUMDIGIT, sp.PHASE_NUMDIGIT,
+                     (int)sp.FOV_MIN_DISTANCE, (int)sp.FOV_MAX_DISTANCE, slx::kRecoWindowSize, slx::kDynaFrameMaxNum};
+    const int count = (int)(sizeof v / sizeof v[0]);
+    if (n) *n = count;
+    if (!values || capacity < count) return SLX_ERR_INVALID_ARG;
+    for (int i = 0; i < count; i++) values[i] = v[i];
+    return SLX_OK;
+}

@@ -29,6 +29,11 @@ struct Image8 {
     bool empty() const { return data == nullptr || rows <= 0 || cols <= 0; }
 };
 
+// R/StaticParameters.cpp:34, :38: the compiled-in defaults of the dynamic-frame loop (pinned, with the struct below, against the
+// reference's own compiled translation unit: tests/test_oracle_golden.py::test_reference_static_parameters)
+constexpr int kRecoWindowSize = 21;      // RECO_WINDOW_SIZE
+constexpr int kDynaFrameMaxNum = 100;    // DYNAFRAME_MAXNUM
+
 // Run-time stand-in for R/StaticParameters.cpp:4-35.
 struct StaticParameters {
     int PROJECTOR_RESLINE = 1280, PROJECTOR_RESROW = 800;
@@ -116,7 +121,7 @@ public:
     // Dynamic frames, R/CCalculation.cpp:208-320.  StripRegression(0) is what CalculateFirst ends with in the reference
     // (:203); here the camera image comes in explicitly.  CalculateOtherFrame(fN, image) = StripRegression(fN) +
     // FillOtherDeltaProU(fN) + FillCoordinate(fN); afterwards GetZ/GetX/GetY/GetProjectorU/GetDeltaZ/Result refer to frame fN.
-    bool StripRegression0(const Image8 &dynaCam0, int recoWindowSize = 21);
+    bool StripRegression0(const Image8 &dynaCam0, int recoWindowSize = kRecoWindowSize);
     bool CalculateOtherFrame(int fN, const Image8 &dynaCam);
     // n consecutive frames fN0 .. fN0 + n - 1 in one call (slx_track_next_batch: the host images ride ONE transfer, the frames run
     // back to back); afterwards the getters refer to the last of them.  deltaZ, when given, receives every frame's deltaZ map
@@ -124,7 +129,7 @@ public:
     bool CalculateOtherFrames(int fN0, const Image8 *dynaCams, int n, std::vector<double> *deltaZ = nullptr);
     // The whole loop of CalculateOther over the sensor's dynaCam images (group 2): frame fN's point cloud goes to
     // <pointCloudPrefix><fN>.txt like m_pcSucceedName (R/CCalculation.cpp:309-314).  Returns the number of frames done.
-    int CalculateOther(CSensor &sensor, const std::string &pointCloudPrefix, int recoWindowSize = 21);
+    int CalculateOther(CSensor &sensor, const std::string &pointCloudPrefix, int recoWindowSize = kRecoWindowSize);
     std::vector<double> GetDeltaZ();
     std::vector<double> GetPointCloud();            // the same points, packed x y z
     // m_zMat[0], m_xMat[0], m_yMat[0], m_ProjectorU[0] (CV_64FC1, rows x cols)

@@ -35,7 +35,7 @@ bool WritePointCloudText(const std::string &path, const double *xyz, size_t n_po
 
 class CSensor {
 public:
-    explicit CSensor(const StaticParameters &sp = StaticParameters(), int dynaFrameMaxNum = 100);
+    explicit CSensor(const StaticParameters &sp = StaticParameters(), int dynaFrameMaxNum = kDynaFrameMaxNum);
     ~CSensor();
     // R/CSensorV.cpp:31: fixes the directory layout; groupDataPath replaces DATA_PATH + "20161103\\MoveBoard1103\\"
     bool InitSensor(const std::string &groupDataPath);

@@ -306,3 +306,29 @@ def test_bad_config_rejected(oracle, synth):
         oracle.pipeline(dict(spec, n_steps=0), ph, None)
     with pytest.raises(ValueError):
         oracle.pipeline(dict(spec, periods=[0, 1, 2]), ph, None)
+
+
+def test_reference_static_parameters(api, synth, golden_dir):
+    """The reference's compiled-in configuration (R/StaticParameters.cpp) -- the one translation unit of the reference that compiles
+    here without OpenCV.  tests/golden/static_parameters.json holds the constants read out of the COMPILED unit
+    (oracle/_ref/libdynaframe_static.so, `make -C oracle ref`, tests/golden/make_static_parameters.py).  Pinned against them:
+    the live shared object wherever it exists (this container; a GPU box that received it), the REF configuration of the tests and
+    the bench, the defaults of the product's C++ mirror classes (slx_reference_defaults), and the two integer divisions the host
+    loop derives from them (R/CCalculation.cpp:550, :562-563).  This pins CONFIGURATION, not arithmetic: parity stays unpinned."""
+    import json
+    import os
+    import sys
+    gold = json.load(open(os.path.join(golden_dir, "static_parameters.json")))["constants"]
+    sys.path.insert(0, os.path.join(os.path.dirname(golden_dir), "..", "oracle"))
+    import ref_static
+    if ref_static.available():
+        assert ref_static.constants() == gold                       # the fixture IS what the compiled reference unit holds
+    ref = synth.make_spec("REF")
+    assert (ref["width"], ref["height"], ref["proj_width"]) == (gold["CAMERA_RESLINE"], gold["CAMERA_RESROW"], gold["PROJECTOR_RESLINE"])
+    assert (ref["gray_bits"], ref["n_steps"], ref["n_freq"]) == (gold["GRAY_V_NUMDIGIT"], gold["PHASE_NUMDIGIT"], 1)
+    assert ref["periods"] == [gold["PROJECTOR_RESLINE"] // (1 << (gold["GRAY_V_NUMDIGIT"] - 1))] == [40]      # `1 << G - 1`, R/CCalculation.cpp:550
+    assert ref["gray_stripe"] == gold["PROJECTOR_RESLINE"] // (1 << gold["GRAY_V_NUMDIGIT"]) == 20             # :562-563
+    # the FOV window of the synthetic REF scene is the reference's, times the 10 x that puts its depths in millimetres (SURVEY 8d)
+    assert (ref["fov_min"], ref["fov_max"]) == (10.0 * gold["FOV_MIN_DISTANCE"], 10.0 * gold["FOV_MAX_DISTANCE"])
+    mine = api.reference_defaults()
+    assert mine == {k: gold[k] for k in mine}, (mine, gold)
