@@ -64,10 +64,16 @@ def ensure_built():
     wait.  Runs before any GPU call of this process."""
     with open(os.path.join(ROOT, ".build.lock"), "w") as lock:
         fcntl.flock(lock, fcntl.LOCK_EX)
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)                      # whatever the build tools print belongs on stderr: stdout carries the result line and nothing else
         try:
             import __graft_entry__
             __graft_entry__.build()
         finally:
+            sys.stdout.flush()
+            os.dup2(saved, 1)
+            os.close(saved)
             fcntl.flock(lock, fcntl.LOCK_UN)
 
 
