@@ -403,7 +403,9 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     # the chip needs ~100 launches (~35 ms) of this kernel after an idle spell before its clock settles
     # (tools/ramp.py: 504, 359, 331, 325, 317, 316 ... us per launch in blocks of 25), hence the warm-up default
-    ap.add_argument("--steps", type=int, default=1000)      # 0.3 s of launches: the ramp of the warm-up launches weighs < 10 % in a kernel trace of the command
+    # default: 3 000 steps at N = 1 (0.8 s of launches: the clock ramp of the first ~100 launches after an idle spell then weighs a third of what
+    # it does in 1 000, in a kernel trace of the command as much as anywhere), 200 at N > 1 (a step is a whole decode + gather there)
+    ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--sets-per-gpu", type=int, default=32)
     ap.add_argument("--config", default="C4")
@@ -1162,6 +1164,8 @@ def selftest_rank(args):
 
 def main():
     args = parse_args()
+    if args.steps is None:
+        args.steps = 3000 if (args.gpus <= 1 and int(os.environ.get("WORLD_SIZE", "1")) <= 1) else 200
     if "WORLD_SIZE" not in os.environ and "RANK" not in os.environ and args.gpus > 1:
         sys.exit(launch_ranks(args, sys.argv[1:]))
     if args.selftest_launcher:
