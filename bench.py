@@ -891,9 +891,16 @@ def run_rank(args):
                         comm.decode_gather(table, full_h, args.gather_chunk, gphase, ggray, scratch, full, root=0, ctx=gctx)
 
                     def gather_only():
-                        # the finished tiles again, no decode in front: what the links and RCCL deliver by themselves
-                        comm.gather_depth(table, full_h, W, (full[set0:, row0:] if rank == 0 else scratch), full, root=0,
-                                          local_plane_stride=(full_h * W if rank == 0 else 0))
+                        # the finished tiles again, no decode in front: what the links and RCCL deliver by themselves -- in the same
+                        # chunks (groups of sends / receives) as the pipelined path, one slx_gather_depth per chunk
+                        for first in range(0, most_sets, args.gather_chunk):
+                            sub = []
+                            for (s0, nn, r0, rws) in table:
+                                lo = min(first, nn)
+                                sub.append((s0 + lo, min(first + args.gather_chunk, nn) - lo, r0, rws))
+                            lo = min(first, gn)
+                            comm.gather_depth(sub, full_h, W, (full[set0 + lo:, row0:] if rank == 0 else scratch[lo:]), full, root=0,
+                                              local_plane_stride=(full_h * W if rank == 0 else 0))
 
                     def drain():
                         comm.synchronize()
@@ -932,21 +939,9 @@ def run_rank(args):
                 drain()
                 torch.cuda.synchronize()
                 tg = time.perf_counter() - t0g
-                progress.update(phase="gather_only", step=None)
-                gather_only()                      # untimed: the staged shape's slots grow to a whole step's tiles on the first call
-                drain()
-                fence()
-                n_go = max(3, min(n_steps, 10))
-                t0o = time.perf_counter()
-                for i in range(n_go):
-                    progress.update(step=i)
-                    gather_only()
-                drain()
-                torch.cuda.synchronize()
-                to = (time.perf_counter() - t0o) / n_go
                 progress.update(phase="check", step=None)
                 fence()
-                tk_max, tg_max, to_max = max_over_ranks([tk, tg, to])
+                tk_max, tg_max = max_over_ranks([tk, tg])
                 # the gathered array against what every rank decoded: wrapping int64 sums of the bit patterns, per rank
                 mine = (full[set0:set0 + gn, row0:row0 + grows] if (rank == 0 and backend == "nccl") else
                         (scratch if backend == "nccl" else local))
@@ -961,28 +956,47 @@ def run_rank(args):
                         if ok and n and rows:
                             part = got_full[s0:s0 + n, r0:r0 + rows].contiguous().view(torch.int64).sum()
                             ok = ok and int(part) == int(sums[r])
+                if split == "rows" and ok is not False:
+                    row_times[key] = (tg_max, shape)
+                    if headline is None or tg_max < headline:      # (a gather that delivers other bytes than the ranks decoded is a failure, not a number)
+                        headline, headline_shape[0] = tg_max, shape
+                # the gather ALONE, a side measurement in a try of its own: whatever happens here, the numbers above stand
+                progress.update(phase="gather_only", step=None)
+                to_max, n_go, go_error = None, max(3, min(n_steps, 10)), None
+                try:
+                    gather_only()                  # untimed: the first call sizes what it needs
+                    drain()
+                    fence()
+                    t0o = time.perf_counter()
+                    for i in range(n_go):
+                        progress.update(step=i)
+                        gather_only()
+                    drain()
+                    torch.cuda.synchronize()
+                    to = (time.perf_counter() - t0o) / n_go
+                    fence()
+                    to_max = max_over_ranks([to])[0]
+                except Exception as e:
+                    go_error = "%s: %s" % (type(e).__name__, e)
                 into_root = int(((total - gn) * full_h if split == "framesets" else total * (full_h - grows)) * W * 8)
-                link_gbps = into_root / to_max / 1e9 / max(world - 1, 1)
+                link_gbps = (into_root / to_max / 1e9 / max(world - 1, 1)) if to_max else None
                 res = {"split": split, "gather_shape": shape,
                        "kernel_only": {"value": total * n_steps / tk_max, "unit": "frames/s", "ms_per_step": tk_max / n_steps * 1e3},
                        "end_to_end": {"value": total * n_steps / tg_max, "unit": "frames/s", "ms_per_step": tg_max / n_steps * 1e3},
                        # what the gather adds to a step beyond the decode it overlaps with, and the gather by itself
                        "gather_wait_ms_per_step": (tg_max - tk_max) / n_steps * 1e3,
-                       "gather_only": {"ms_per_step": to_max * 1e3, "steps": n_go, "gbps_into_root": into_root / to_max / 1e9,
-                                       "gbps_per_link": link_gbps, "links": world - 1, "xgmi_link_peak_gbps": XGMI_LINK_GBPS,
-                                       "frac_of_link_peak": link_gbps / XGMI_LINK_GBPS if backend == "nccl" else None,
-                                       "what": "slx_gather_depth of the finished tiles, no decode; bytes into the root / time / (N-1) links"
-                                               if backend == "nccl" else "gloo through host memory (one-GPU rehearsal): not a link measurement"},
+                       "gather_only": ({"error": go_error} if to_max is None else
+                                       {"ms_per_step": to_max * 1e3, "steps": n_go, "gbps_into_root": into_root / to_max / 1e9,
+                                        "gbps_per_link": link_gbps, "links": world - 1, "xgmi_link_peak_gbps": XGMI_LINK_GBPS,
+                                        "frac_of_link_peak": link_gbps / XGMI_LINK_GBPS if backend == "nccl" else None,
+                                        "what": "slx_gather_depth of the finished tiles chunk by chunk, no decode; bytes into the root / time / (N-1) links"
+                                                if backend == "nccl" else "gloo through host memory (one-GPU rehearsal): not a link measurement"}),
                        "steps": n_steps, "warmup": n_warm,
                        "bytes_into_root_per_step": into_root,
                        "gathered_shape": [total, full_h, W], "messages_at_root_per_step": n_msgs_root,
                        "bytes_per_message": (into_root // n_msgs_root) if n_msgs_root else None,
                        "root_staging_bytes": 2 * staging_bytes if staging_bytes else 0,
                        "gathered_equals_local_decodes": ok}
-                if split == "rows" and ok is not False:
-                    row_times[key] = (tg_max, shape)
-                    if headline is None or tg_max < headline:      # (a gather that delivers other bytes than the ranks decoded is a failure, not a number)
-                        headline, headline_shape[0] = tg_max, shape
             except Exception as e:      # the decode-only measurement above must still be reported
                 res = {"split": split, "gather_shape": shape, "error": "%s: %s" % (type(e).__name__, e)}
                 gather_ok = False
