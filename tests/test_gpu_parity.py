@@ -1961,6 +1961,38 @@ def test_cpp_gather_host_loop(tmp_path, oracle, synth, split):
         assert np.array_equal(got[s], oracle.pipeline(spec, planes[s], None, want=("z",))["z"], equal_nan=True), s
 
 
+@pytest.mark.parametrize("world,split,shape,size,sets,chunk", [(3, "rows", "staged", (128, 37), 5, 2), (3, "rows", "in_place", (128, 37), 5, 2),
+                                                                (8, "rows", "staged", (256, 50), 7, 3), (8, "rows", "in_place", (256, 50), 7, 3),
+                                                                (4, "framesets", "staged", (64, 20), 9, 2), (2, "rows", "staged", (1920, 1200), 6, 2)])
+def test_gather_code_with_peers_as_threads_of_one_process(tmp_path, oracle, synth, world, split, shape, size, sets, chunk):
+    """tests/cpp/gather_threads.cpp: every rank of the multi-GPU host loop as a THREAD on this one GPU, libslx.so as built, only the
+    wire replaced (the executable defines the nccl* entry points: grouped sends / receives matched per ordered pair of ranks in
+    posting order, equal counts demanded, data moved in stream order by device copies).  So the library's gather code runs WITH
+    PEERS: gather_range, the two staging slots of the staged shape and the events that order their reuse, the row-scatter kernel on
+    its own stream, the chunk pipeline of slx_decode_gather (twice in a row: the second call must wait for the first one's gather),
+    slx_gather_depth from separate local buffers.  Worlds of 2 - 8, ragged tiles, ragged last chunks, both shapes, both splits, and
+    configuration 4's real frame size; the gathered maps against the oracle, bit for bit.  (What this cannot show is RCCL and xGMI
+    themselves: that is the driver's 8-GPU run.)"""
+    import subprocess
+    from conftest import ROOT, _ensure_built
+    _ensure_built()
+    exe = os.path.join(ROOT, "tests", "cpp", "gather_threads")
+    assert os.path.exists(exe)
+    W, H = size
+    spec = {"name": "gather", "width": W, "height": H, "row_offset": 0, "proj_width": 1920, "mode": synth.MODE_MULTIFREQ, "n_freq": 3, "n_steps": 4,
+            "periods": [1920, 240, 30], "gray_bits": 0, "gray_stripe": 0, "gray_lut": None, "fov_min": -1e300, "fov_max": 1e300,
+            "calib": {"cam": [3600, 0, (W - 1) / 2.0, 0, 3600, (H - 1) / 2.0, 0, 0, 1], "pro": [3000, 0, 900, 0, 3000, 600, 0, 0, 1],
+                      "rot": [0.99, -0.01, 0.13, 0.02, 0.99, -0.1, -0.13, 0.1, 0.98], "trans": [-31.7, -9.3, 39.4]}}
+    planes = [synth.random_planes(spec, seed=1700 + s)[0] for s in range(sets)]
+    np.stack(planes).tofile(str(tmp_path / "in.bin"))
+    r = subprocess.run([exe, str(world), split, shape, str(W), str(H), str(sets), str(chunk), str(tmp_path / "in.bin"), str(tmp_path / "out.bin")],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
+    got = np.fromfile(str(tmp_path / "out.bin"), dtype=np.float64).reshape(sets, H, W)
+    for s in range(sets):
+        assert np.array_equal(got[s], oracle.pipeline(spec, planes[s], None, want=("z",), threads=8)["z"], equal_nan=True), s
+
+
 # ------------------------------------------------------------------ multi-frequency: every input of a coarser frequency
 @pytest.mark.parametrize("periods", [[1920, 240, 30], [4096, 512, 64, 8], [1000, 37], [16384, 9], [777, 333, 111]])
 def test_coarse_frequencies_exhaustive_inputs(api, oracle, synth, periods):
