@@ -200,10 +200,17 @@ __global__ __launch_bounds__(256) void slx_track_update_kernel(const float *raw,
 // HBM: a workgroup computes it for its band of kFusedRows rows plus one halo row above and below and one halo column either
 // side (the strips of those halo pixels are computed a second time by the neighbouring workgroup: 25 % more scan work for
 // 8 bytes per pixel less traffic and one launch less), keeps it in LDS, and blurs from there.
-//   phase 1  a lane per column: the 30 image bytes its column contributes to the 10 rows' sliding sums -> sums in LDS
-//   phase 2  236 lanes: the +-10 scan of every row (max3 / min3 over keys, as in the band kernel), strips out for the pixels
-//            this workgroup owns, deltaP selection -> LDS
-//   phase 3  234 lanes: 3x3 box sum from LDS (BORDER_REFLECT_101 at the image border), U, depth, x, y, deltaZ
+// Tile geometry (round 5): 254 of a workgroup's 256 lanes own an output column (the first and the last lane stand on the blur's halo
+// columns and only scan).  The sliding sums cover the 2 HW = 20 columns the scan reaches beyond them as well, 276 in all, and are formed
+// TWO columns per lane by the first 138 lanes (16-bit loads, both columns in the halves of one register).  Before, the scan's reach
+// took 22 of every workgroup's lanes: 1920 columns were 9 tiles of 234, the ninth a fifth full, 1 350 workgroups for 256 CUs; now 8
+// tiles of 254, 1 200 workgroups: 32.4 -> 31.3 us per frame on one box (profiles/r05_track_tile_geometry_ab.log).  Two versions
+// that formed the extra sums columns, or scanned the halo columns, in a SECOND pass of a few lanes were 14 % and 25 % slower than
+// the 234-column tiles: the phase before the first barrier is on every workgroup's critical path, and so is every row's scan.
+//   phase 1  two columns per lane: the 30 image bytes each column contributes to the 10 rows' sliding sums -> LDS
+//   phase 2  the +-10 scan of every row (max3 / min3 over keys, as in the band kernel), strips out for the pixels this workgroup
+//            owns, deltaP selection -> LDS
+//   phase 3  3x3 box sum from LDS (BORDER_REFLECT_101 at the image border), U, depth, x, y, deltaZ
 // a7's second pass divides by the constants fu, fv: the refined reciprocal is formed once, the quotient takes the residual
 // correction of the IEEE sequence, and anything that sequence cannot do unscaled (zero / NaN) goes to the literal division.
 constexpr int kFusedRows = 8;
@@ -214,17 +221,20 @@ __global__ __launch_bounds__(kTile) void slx_track_fused_kernel(const uint8_t *c
                                                                 double *deltaZ, const SlxKParams p, unsigned tiles_x)
 {
     static_assert(2 * HW <= 31, "the neighbour rank must fit 5 bits");
-    constexpr int OUT = kTile - 2 * HW - 2;                          // output columns per workgroup
+    constexpr int OUT = kTile - 2;                                   // output columns per workgroup: every lane but the first and the last
     constexpr int RR = kFusedRows + 2;                               // rows of unblurred deltaP a band needs
-    __shared__ uint32_t sums[RR][kTile];
-    __shared__ float rawt[RR][kTile];
+    constexpr int XS = 2 * HW;                                       // extra columns of sliding sums: the scan's reach, both sides
+    constexpr int SW = kTile + XS;                                   // sums column si holds image column c0 - 1 - HW + si
+    static_assert(SW % 2 == 0, "two columns of sums per lane");
+    __shared__ __attribute__((aligned(8))) uint32_t sums[RR][SW];
+    __shared__ float rawt[RR][kTile];                                // rawt column tx holds image column c0 - 1 + tx: lane tx's own
     const int W = p.width, H = p.height;
     const int tx = threadIdx.x;
     // XCD-aware tile order (round 5).  The dispatcher deals workgroups round-robin over the 8 XCDs, each with its own L2; a band shares 22
     // of its 30 image rows and 2 of its 10 rows of the previous frame's strips with the bands above and below it, and in plain order
-    // those neighbours (9 workgroups apart at 1920 columns) sit on other XCDs: the shared rows came from HBM once per band (74.9 MB read
-    // per frame for 57.6 algorithmic, profiles/r05_track_pmc_summary.json).  Here XCD x takes a contiguous run of tiles in row-major
-    // order, so that a tile's vertical neighbours run on its own XCD at about the same time and the shared rows are L2 hits.
+    // those neighbours sit on other XCDs: the shared rows came from HBM once per band (74.9 MB read per frame for 57.6 algorithmic,
+    // profiles/r05_track_pmc_summary.json).  Here XCD x takes a contiguous run of tiles in row-major order, so that a tile's vertical
+    // neighbours run on its own XCD at about the same time and the shared rows are L2 hits (58.6 MB).
     // Placement only affects speed; any order gives the same result.
     unsigned tile = blockIdx.x;
     {
@@ -232,15 +242,13 @@ __global__ __launch_bounds__(kTile) void slx_track_fused_kernel(const uint8_t *c
         tile = x * q + (x < r ? x : r) + within;
     }
     const int tile_x = (int)(tile % tiles_x), tile_y = (int)(tile / tiles_x);
-    const int c = tile_x * OUT + tx - (HW + 1);                      // image column of this lane
+    const int c0 = tile_x * OUT, c = c0 - 1 + tx;                    // image column of this lane; lanes 0 and kTile - 1 are the blur's halo columns
     const int r0 = tile_y * kFusedRows;
     const int r1 = r0 + kFusedRows < H ? r0 + kFusedRows : H;
     const int ra = r0 - 1;                                           // image row of tile row 0
-    const bool col_in = c >= 0 && c < W;
-    const bool col_interior = c >= HW && c < W - HW;                 // valSum is 0 elsewhere
     const int ha = ra > HW ? ra : HW, hb = ra + RR < H - HW ? ra + RR : H - HW;   // interior rows of the tile: [ha, hb)
-    const bool scans = tx >= HW && tx < kTile - HW;
-    const bool owns_col = tx >= HW + 1 && tx < kTile - HW - 1 && c < W;
+    const bool col_in = c >= 0 && c < W;
+    const bool owns_col = tx >= 1 && tx < kTile - 1 && c < W;
     // Everything a workgroup reads besides the image is asked for up front -- the previous frame's strips for all ten rows here,
     // U and z two rows ahead of their use below -- so that those latencies pass behind the sums and the scans: all workgroups of
     // a frame are resident at once, and a workgroup's own dependent chain is what the launch lasts.
@@ -248,7 +256,7 @@ __global__ __launch_bounds__(kTile) void slx_track_fused_kernel(const uint8_t *c
 #pragma unroll
     for (int j = 0; j < RR; j++) {
         const int h = ra + j;
-        const bool need = scans && col_in && h >= 0 && h < H;
+        const bool need = col_in && h >= 0 && h < H;
         const size_t o = (size_t)(need ? h : 0) * W + (need ? c : 0);
         pB[j] = need ? prevB[o] : 0.f;
         pW[j] = need ? prevW[o] : 0.f;
@@ -264,32 +272,40 @@ __global__ __launch_bounds__(kTile) void slx_track_fused_kernel(const uint8_t *c
     fetch_row(1);
     fetch_row(2);
     fetch_row(3);
-    if (ha < hb) {
+    // Sliding sums, TWO image columns per lane: lanes 0 .. SW/2 - 1 load the 30 rows of columns c0 - 1 - HW + 2 tx and + 1 as one
+    // 16-bit word each (any alignment), keep the two bytes in the halves of a register (a sum of 21 bytes fits 16 bits, and a sliding
+    // sum never borrows: what is subtracted was added before) and run ONE sliding sum over both; the last wave has no part in this phase.
+    if (ha < hb && tx < SW / 2) {
+        const int cs = c0 - 1 - HW + 2 * tx;                         // the even one of this lane's two columns
+        const uint32_t keep = ((cs >= HW && cs < W - HW) ? 0xffffu : 0u) | ((cs + 1 >= HW && cs + 1 < W - HW) ? 0xffff0000u : 0u);   // valSum is 0 elsewhere
+        const int cl = cs < 0 ? 0 : cs > W - 2 ? W - 2 : cs;         // a pair that had to move holds no interior column (HW >= 1)
         uint32_t b[RR + 2 * HW];
 #pragma unroll
         for (int k = 0; k < RR + 2 * HW; k++) {
             const int r = ha - HW + k;
-            b[k] = (col_interior && r < hb + HW) ? cam[(size_t)r * stride + c] : 0u;
+            uint16_t two = 0;
+            if (r < hb + HW) __builtin_memcpy(&two, cam + (size_t)r * stride + cl, 2);
+            b[k] = ((uint32_t)two | ((uint32_t)two << 8)) & 0x00ff00ffu;
         }
         uint32_t sum = 0;
 #pragma unroll
         for (int k = 0; k <= 2 * HW; k++) sum += b[k];
 #pragma unroll
         for (int j = 0; j < RR; j++) {
-            sums[j][tx] = sum << 5;                                  // row ha + j; 0 outside the interior columns
+            const uint32_t m = sum & keep;
+            *reinterpret_cast<uint2 *>(&sums[j][2 * tx]) = make_uint2((m & 0xffffu) << 5, (m >> 16) << 5);   // row ha + j
             if (j + 1 < RR) sum = sum - b[j] + b[j + 2 * HW + 1];
         }
     }
     __syncthreads();
-    // strips and deltaP selection of tile row j (image row ra + j) -> rawt[j]
+    // strips and deltaP selection of this lane's column at tile row j (image row ra + j) -> rawt[j][tx]; strips out when owned
     auto scan_row = [&](int j) {
         const int h = ra + j;
         float r = 0.f;
-        if (scans && col_in && h >= 0 && h < H) {
-            const size_t o = (size_t)h * W + c;
+        if (col_in && h >= 0 && h < H) {
             float mxi = 0.f, mni = 0.f;
-            if (col_interior && h >= ha && h < hb) {
-                const uint32_t *row = &sums[h - ha][tx];
+            if (c >= HW && c < W - HW && h >= ha && h < hb) {
+                const uint32_t *row = &sums[h - ha][tx + HW];
                 uint32_t kmax = row[0] | (uint32_t)(2 * HW), kmin = row[0];
 #pragma unroll
                 for (int i = -HW; i < HW; i += 2) {
@@ -304,6 +320,7 @@ __global__ __launch_bounds__(kTile) void slx_track_fused_kernel(const uint8_t *c
                 mni = q == 0 ? 0.f : (float)(q - HW - 1);
             }
             if (owns_col && h >= r0 && h < r1) {
+                const size_t o = (size_t)h * W + c;
                 stripB[o] = mni;
                 stripW[o] = mxi;
             }
@@ -316,6 +333,7 @@ __global__ __launch_bounds__(kTile) void slx_track_fused_kernel(const uint8_t *c
     const double aC = (uc * p.fv) * p.P00, aD = (uc * p.fv) * p.P20;
     const double rfu = slx_refined_rcp_f64(p.fu), rfv = slx_refined_rcp_f64(p.fv);
     const int dl = c - 1 < 0 ? 1 : -1, dr = c + 1 >= W ? -1 : 1;     // BORDER_REFLECT_101: column -1 is column 1, column W is column W-2
+    const int ri = owns_col ? tx : 1;                                // this lane's column of rawt (the halo lanes read nothing)
     // Row by row: the scan of row j+1 and the output of row j alternate, so that a workgroup's loads and stores are spread
     // over its lifetime instead of coming in one burst at the end (every workgroup of a frame is resident at once and they all
     // run the same timeline: phases would otherwise line up across the whole chip).
@@ -333,7 +351,7 @@ __global__ __launch_bounds__(kTile) void slx_track_fused_kernel(const uint8_t *c
         if (!owns_col) continue;
         const int ju = v - 1 < 0 ? j + 1 : j - 1, jd = v + 1 >= H ? j - 1 : j + 1;
         double s = 0.0;                                              // sums of small integers: exact in any order
-        for (int jj : {ju, j, jd}) s += ((double)rawt[jj][tx + dl] + (double)rawt[jj][tx]) + (double)rawt[jj][tx + dr];
+        for (int jj : {ju, j, jd}) s += ((double)rawt[jj][ri + dl] + (double)rawt[jj][ri]) + (double)rawt[jj][ri + dr];
         const float dp = (float)(s * (1. / 9));                     // cv::blur: the box sum times 1./9 (:650)
         deltaP[i] = dp;
         const double Uv = Uin + (double)dp;                         // :656-658
@@ -404,7 +422,7 @@ bool slx_track_fusable(int W, int H, int win) { return win / 2 == 10 && (win & 1
 int slx_launch_track_fused(const SlxKParams &kp, const uint8_t *cam, size_t stride, float *stripW, float *stripB, const float *prevW, const float *prevB,
                            float *deltaP, double *U, double *z, double *x, double *y, double *deltaZ, void *stream)
 {
-    constexpr int out_cols = kTile - 2 * 10 - 2;
+    constexpr int out_cols = kTile - 2;                              // every lane but the two halo lanes owns an output column (slx_track_fused_kernel)
     const unsigned tiles_x = (unsigned)((kp.width + out_cols - 1) / out_cols), tiles_y = (unsigned)((kp.height + kFusedRows - 1) / kFusedRows);
     if ((unsigned long long)tiles_x * tiles_y >= (1ull << 31)) return (int)hipErrorInvalidValue;
     hipLaunchKernelGGL(slx_track_fused_kernel<10>, dim3(tiles_x * tiles_y), dim3(kTile), 0, (hipStream_t)stream, cam, stride, stripW, stripB, prevW, prevB,

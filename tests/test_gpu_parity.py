@@ -1071,7 +1071,10 @@ def dyna_images(h, w, n, seed):
                                           # band / tile edges of the 21-pixel kernel: a single interior pixel, one interior row,
                                           # bands of 8 rows starting exactly at / next to the interior, exactly one and two tiles
                                           ((21, 21), 21), ((21, 80), 21), ((22, 45), 21), ((29, 64), 21), ((37, 256), 21), ((34, 472), 21),
-                                          ((27, 473), 21)])
+                                          ((27, 473), 21),
+                                          # 254 output columns per workgroup (round 5): exactly one tile, one column more, the halo lane on the
+                                          # last image column, two tiles and one more, an odd width (the sums go two columns per lane)
+                                          ((26, 254), 21), ((26, 255), 21), ((23, 253), 21), ((30, 508), 21), ((26, 509), 21), ((31, 763), 21)])
 def test_dynamic_frames(api, oracle, synth, shape, window):
     h, w = shape
     spec = small_spec(synth, "C1x4", w, h)
