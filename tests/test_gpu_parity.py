@@ -1073,8 +1073,9 @@ def dyna_images(h, w, n, seed):
                                           ((21, 21), 21), ((21, 80), 21), ((22, 45), 21), ((29, 64), 21), ((37, 256), 21), ((34, 472), 21),
                                           ((27, 473), 21),
                                           # 254 output columns per workgroup (round 5): exactly one tile, one column more, the halo lane on the
-                                          # last image column, two tiles and one more, an odd width (the sums go two columns per lane)
-                                          ((26, 254), 21), ((26, 255), 21), ((23, 253), 21), ((30, 508), 21), ((26, 509), 21), ((31, 763), 21)])
+                                          # last image column, two tiles and one more, odd widths (the sums go two columns per lane)
+                                          ((26, 254), 21), ((26, 255), 21), ((23, 253), 21), ((30, 508), 21), ((26, 509), 21), ((31, 763), 21),
+                                          ((26, 240), 21), ((41, 433), 21), ((72, 305), 21), ((130, 192), 21)])
 def test_dynamic_frames(api, oracle, synth, shape, window):
     h, w = shape
     spec = small_spec(synth, "C1x4", w, h)
@@ -1112,6 +1113,41 @@ def test_dynamic_frames(api, oracle, synth, shape, window):
         with pytest.raises(api.SlxError) as e:
             ctx.track_begin(imgs[0])
         assert e.value.code == api.ERR_UNAVAILABLE
+
+
+def test_tracked_frame_cloud_full_size(api, oracle, synth, torch_cuda):
+    """The reference writes a cloud after every dynamic frame (main loop: CalculateOther, Result): 1920 x 1200, three tracked frames in a
+    row, the cloud of each into host memory (count first), as the context's pinned view, into a device buffer for every pixel and into
+    one exactly as large as the cloud -- by the fused launch and by count + write, against the oracle."""
+    import ctypes
+    torch = torch_cuda
+    spec = synth.make_spec("C4")
+    H, W = spec["height"], spec["width"]
+    ph, gr, _ = synth.render(spec, "sphere", noise_sigma=2.0)
+    imgs = dyna_images(H, W, 4, seed=11)
+    dev = torch.full((H * W, 3), -7.0, dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    with api.Context(spec, aux=("U",)) as ctx:
+        ctx.set_frames(ph, gr)
+        ctx.decode()
+        ctx.track_begin(imgs[0])
+        for f in (1, 2, 3):
+            ctx.track_next(imgs[f])
+            ref = oracle.point_cloud(spec, ctx.get_depth())
+            assert 0 < len(ref) < H * W
+            for passes in (0, 1, 2):
+                ctx.set_tuning(cloud_passes=passes)
+                got = ctx.get_point_cloud()                      # count only, then into host memory
+                assert got.shape == ref.shape and np.array_equal(got, ref, equal_nan=True), (f, passes)
+            ctx.set_tuning(cloud_passes=0)
+            assert np.array_equal(ctx.get_point_cloud_view(), ref, equal_nan=True), f
+            n = ctypes.c_size_t(0)
+            assert api.lib().slx_get_point_cloud(ctx._h, dev.data_ptr(), H * W, ctypes.byref(n), api.MEM_DEVICE) == 0
+            assert n.value == len(ref) and np.array_equal(dev[:n.value].cpu().numpy(), ref, equal_nan=True), f
+            tight = torch.full((len(ref) + 1, 3), -7.0, dtype=torch.float64, device="cuda")
+            torch.cuda.synchronize()                             # (the fill runs on torch's stream, the library on its own)
+            assert api.lib().slx_get_point_cloud(ctx._h, tight.data_ptr(), len(ref), ctypes.byref(n), api.MEM_DEVICE) == 0
+            assert n.value == len(ref) and np.array_equal(tight[:-1].cpu().numpy(), ref, equal_nan=True) and bool((tight[-1] == -7.0).all()), f
 
 
 def test_dynamic_frames_device_images_full_size(api, oracle, synth, torch_cuda):

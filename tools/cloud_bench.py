@@ -20,7 +20,8 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--config", default="C4")
 ap.add_argument("--reps", type=int, default=50)
 ap.add_argument("--lib", default="", help="another build of libslx.so (e.g. tmp_ab/libslx_cloudexp1.so: timing diagnostics)")
-ap.add_argument("--passes", type=int, default=0, help="slx_set_tuning(cloud_passes): 0 automatic (the fused launch), 2 count + write")
+ap.add_argument("--passes", type=int, default=0, help="slx_set_tuning(cloud_passes): 0 automatic (the fused launch), 1 the fused launch or an error, 2 count + write")
+ap.add_argument("--tracked", action="store_true", help="the depth plane of a TRACKED frame (slx_track_begin + slx_track_next first): the reference's per-frame cloud")
 a = ap.parse_args()
 if a.lib:
     api.LIB_PATH = os.path.join(ROOT, a.lib)
@@ -28,10 +29,17 @@ spec = synth.make_spec(a.config)
 H, W = spec["height"], spec["width"]
 ph, gr, _ = synth.render(spec, "sphere", seed=9, noise_sigma=1.0)
 xyz = torch.empty((H * W, 3), dtype=torch.float64, device="cuda")
-with api.Context(spec) as ctx:
+with api.Context(spec, aux=("U",) if a.tracked else ()) as ctx:
     ctx.set_tuning(cloud_passes=a.passes)
     ctx.set_frames(phase=ph, gray=gr)
     ctx.decode()
+    if a.tracked:
+        import numpy as np
+        rng = np.random.default_rng(3)
+        u = np.arange(W)[None, :] + 0.02 * np.arange(H)[:, None]
+        imgs = [np.clip(128 + 100 * np.sign(np.sin(2 * np.pi * (u + 1.7 * f) / 14.0)) + rng.normal(0, 6, (H, W)), 0, 255).astype(np.uint8) for f in range(2)]
+        ctx.track_begin(imgs[0])
+        ctx.track_next(imgs[1])
     ctx.synchronize()
     n = C.c_size_t(0)
     L = api.lib()
@@ -45,6 +53,6 @@ with api.Context(spec) as ctx:
 # algorithmic bytes: the depth read ONCE + 24 B per kept point written (the two-launch path moves 8 B per pixel more: it reads the depth twice)
 bytes_ = 8 * H * W + 24 * n.value
 moved = bytes_ + (8 * H * W if a.passes == 2 else 0)
-print(json.dumps({"metric": "point clouds/s (device to device, host wait for the point count included)", "config": a.config, "lib": a.lib or "product", "passes": a.passes or "auto (fused)",
+print(json.dumps({"metric": "point clouds/s (device to device, host wait for the point count included)", "config": a.config, "lib": a.lib or "product", "passes": a.passes or "auto (fused)", "tracked_frame": a.tracked,
                   "points": n.value, "pixels": H * W, "us_per_cloud": dt * 1e6, "value": 1 / dt, "algorithmic_bytes": bytes_,
                   "achieved_GBps": bytes_ / dt / 1e9, "frac_of_hbm_peak": bytes_ / dt / 8e12, "bytes_moved": moved}))
