@@ -250,3 +250,25 @@ def test_fused_cloud_kernel_registers_match_the_plan(tmp_path):
         need = 6 if m.group(3) == "4" else 4                          # 3 / 2 workgroups of 8 waves per CU = 24 / 16 waves on 4 SIMDs
         assert waves_per_simd >= need, (m.groups(), v["vgpr_count"], waves_per_simd)
     assert seen == 8
+
+
+def test_tracker_kernel_keeps_a_whole_frame_resident(tmp_path):
+    """slx_track_fused_kernel<10> (csrc/slx_track.hip): the 1 200 workgroups of a 1920 x 1200 frame run as ONE wave of dependent chains (DESIGN.md
+    section 7) -- 4.7 per CU, so the compiled code must allow 5 four-wave workgroups per CU: <= 96 VGPRs (5 waves per SIMD), <= 32 KiB of LDS, and
+    neither spills nor scratch; the sliding sums come in by 16-bit loads, two columns per lane (30 per lane, no byte loads of the image)."""
+    if not os.path.exists(HIPCC):
+        pytest.skip("hipcc is not installed")
+    out = str(tmp_path / "slx_track.s")
+    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-I" + os.path.join(ROOT, "include"),
+                           "-I" + CSRC, "-S", "--cuda-device-only", os.path.join(CSRC, "slx_track.hip"), "-o", out], stderr=subprocess.DEVNULL)
+    text = open(out).read()
+    meta = text[text.index("amdhsa.kernels:"):]
+    blk = [b for b in re.split(r"\n  - \.agpr_count:", meta) if re.search(r"\.name:\s+\S*slx_track_fused_kernelILi10E", b)]
+    assert len(blk) == 1
+    v = {f: int(re.search(r"\.%s:\s+(\d+)" % f, blk[0]).group(1)) for f in ("vgpr_count", "vgpr_spill_count", "private_segment_fixed_size", "group_segment_fixed_size")}
+    assert v["vgpr_spill_count"] == 0 and v["private_segment_fixed_size"] == 0, v
+    assert 512 // ((v["vgpr_count"] + 7) // 8 * 8) >= 5 and v["group_segment_fixed_size"] <= 32 * 1024, v
+    name = re.search(r"\.name:\s+(\S*slx_track_fused_kernelILi10E\S*)", blk[0]).group(1)
+    body = text[text.index("\n" + name + ":"):]
+    body = body[:body.index("s_endpgm")]
+    assert len(re.findall(r"global_load_ushort", body)) == 30 and not re.findall(r"global_load_ubyte", body)
