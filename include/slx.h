@@ -27,7 +27,8 @@
  *                                                           one rank per GPU, the final depth-map gather over RCCL
  *   cv::FileStorage (calibration) R/CCalculation.cpp:124  -> slx_read_calibration_yaml
  *   cv::imread (CSensor)          R/CSensorV.cpp:111      -> slx_read_bmp_gray / slx_read_pgm_gray (+ slx::CSensor, csrc/sensor.hpp)
- *   CCalculation::Result (file)   R/CCalculation.cpp:323  -> slx_get_point_cloud + slx_write_point_cloud_text
+ *   CCalculation::Result (file)   R/CCalculation.cpp:323  -> slx_get_point_cloud_text (formatted on the device), or
+ *                                                           slx_get_point_cloud + slx_write_point_cloud_text (on the host)
  *   CSensor::GetCamPicture loop   R/CSensorV.cpp:171      -> slx_pipe_* (pinned host slots, copy/decode overlap)
  *   CCalculation::Result          R/CCalculation.cpp:323  -> slx_get_point_cloud / slx_point_cloud_of_depth (+ slx::CCalculation::Result text writer)
  *   CCalculation::CalculateOther  R/CCalculation.cpp:208  -> slx_track_begin / slx_track_next (+ slx::CCalculation::CalculateOther)
@@ -204,6 +205,15 @@ int slx_get_point_cloud(slx_ctx *ctx, double *xyz, size_t capacity_points, size_
  * valid until the next point-cloud call on this context (or its destruction); the caller only reads it.  What
  * slx::CCalculation::Result formats its text file from. */
 int slx_get_point_cloud_view(slx_ctx *ctx, const double **xyz, size_t *n_points);
+/* The same cloud as the TEXT CCalculation::Result writes (R/CCalculation.cpp:323-357): "x y z\n" per point, every number as
+ * `ostream << double` prints it (%g, 6 significant digits) -- formatted ON THE DEVICE (formatting is the cost of that function: 8-10 ms
+ * per 1.3 M points on 16 host threads), byte for byte what slx_write_point_cloud_text writes; only the text crosses PCIe.  *text: pinned
+ * host memory the context owns, *n_bytes long (not NUL-terminated), valid until the next point-cloud call on this context; write it to
+ * the file as it is.  SLX_ERR_UNAVAILABLE when a coordinate lies outside the device formatter's range (0 < |v| < 1e-5, |v| >= 1e15, NaN,
+ * infinity): take slx_get_point_cloud_view + slx_write_point_cloud_text for that frame (slx::CCalculation::Result does). */
+int slx_get_point_cloud_text(slx_ctx *ctx, const char **text, size_t *n_bytes, size_t *n_points);
+/* The text of any n_points packed (x, y, z) triples in DEVICE memory (a cloud slx_point_cloud_of_depth left there), same contract. */
+int slx_format_points_text(slx_ctx *ctx, const double *xyz_dev, size_t n_points, const char **text, size_t *n_bytes);
 /* The same for any depth map of the context's geometry in device memory (height x width f64, contiguous): one plane of
  * slx_decode_batch's output, so that a batch host loop gets CCalculation::Result's data per frame-set without another
  * decode.  Ordered after the context's last launch (whatever stream it ran on); `depth` is borrowed until the call returns. */

@@ -30,7 +30,7 @@ SYMBOLS = [
     "slx_validate_config", "slx_create", "slx_destroy", "slx_last_error", "slx_set_gray_lut",
     "slx_set_frame", "slx_decode", "slx_decode_batch", "slx_synchronize", "slx_get_stream", "slx_get_output",
     "slx_get_depth", "slx_get_point_cloud", "slx_point_cloud_of_depth", "slx_track_begin", "slx_track_next", "slx_track_image_buffer", "slx_track_next_batch", "slx_track_stage_frames", "slx_track_frames_buffer", "slx_output_device_ptr", "slx_get_calibration", "slx_enable_timing",
-    "slx_last_decode_ms", "slx_debug_stamps", "slx_set_variant", "slx_set_tuning", "slx_last_kernel", "slx_read_bmp_gray", "slx_read_pgm_gray", "slx_read_calibration_yaml", "slx_write_point_cloud_text", "slx_get_point_cloud_view", "slx_version",
+    "slx_last_decode_ms", "slx_debug_stamps", "slx_set_variant", "slx_set_tuning", "slx_last_kernel", "slx_read_bmp_gray", "slx_read_pgm_gray", "slx_read_calibration_yaml", "slx_write_point_cloud_text", "slx_get_point_cloud_view", "slx_get_point_cloud_text", "slx_format_points_text", "slx_version",
     "slx_decode_batch_ex", "slx_comm_unique_id", "slx_comm_create", "slx_comm_adopt", "slx_comm_destroy", "slx_comm_info", "slx_comm_last_error",
     "slx_comm_synchronize", "slx_gather_depth", "slx_decode_gather", "slx_gather_plan", "slx_gather_plan_ex", "slx_comm_set_gather_shape", "slx_scatter_rows", "slx_reference_defaults",
     "slx_pipe_create", "slx_pipe_destroy", "slx_pipe_layout", "slx_pipe_acquire", "slx_pipe_submit", "slx_pipe_collect", "slx_pipe_last_error",
@@ -136,6 +136,8 @@ def lib():
         L.slx_get_point_cloud.argtypes = [vp, vp, sz, C.POINTER(sz), C.c_int]
         L.slx_point_cloud_of_depth.argtypes = [vp, vp, vp, sz, C.POINTER(sz), C.c_int]
         L.slx_get_point_cloud_view.argtypes = [vp, C.POINTER(vp), C.POINTER(sz)]
+        L.slx_get_point_cloud_text.argtypes = [vp, C.POINTER(vp), C.POINTER(sz), C.POINTER(sz)]
+        L.slx_format_points_text.argtypes = [vp, vp, sz, C.POINTER(vp), C.POINTER(sz)]
         L.slx_track_begin.argtypes = [vp, vp, sz, C.c_int, C.c_int]
         L.slx_track_next.argtypes = [vp, vp, sz, C.c_int]
         L.slx_track_next_batch.argtypes = [vp, vp, sz, sz, C.c_int, C.c_int, vp, C.c_int]
@@ -348,6 +350,20 @@ class Context:
         a = np.empty((n.value, 3), dtype=np.float64)
         self._check(lib().slx_get_point_cloud(self._h, a.ctypes.data, n.value, C.byref(n), MEM_HOST))
         return a
+
+    def get_point_cloud_text(self):
+        """The cloud as the text CCalculation::Result writes, formatted on the device (slx_get_point_cloud_text): (bytes, number of points).
+        SlxError ERR_UNAVAILABLE when a coordinate lies outside the device formatter's range."""
+        p, nb, npts = C.c_void_p(), C.c_size_t(0), C.c_size_t(0)
+        self._check(lib().slx_get_point_cloud_text(self._h, C.byref(p), C.byref(nb), C.byref(npts)))
+        return (C.string_at(p.value, nb.value) if nb.value else b""), npts.value
+
+    def format_points_text(self, xyz):
+        """Text of packed (x, y, z) triples in device memory (a CUDA f64 tensor [n, 3]), formatted on the device: bytes."""
+        assert xyz.is_cuda and xyz.is_contiguous() and xyz.element_size() == 8 and xyz.numel() % 3 == 0
+        p, nb = C.c_void_p(), C.c_size_t(0)
+        self._check(lib().slx_format_points_text(self._h, xyz.data_ptr(), xyz.numel() // 3, C.byref(p), C.byref(nb)))
+        return C.string_at(p.value, nb.value) if nb.value else b""
 
     def get_point_cloud_view(self):
         """The same cloud as a read-only numpy view [n, 3] of pinned memory the context owns (slx_get_point_cloud_view): valid until

@@ -1,6 +1,7 @@
 // dynaframe.cpp -- see dynaframe.hpp.  Thin C++ over the C ABI; no arithmetic lives here.
 #include "dynaframe.hpp"
 
+#include <cstdio>
 #include <cstring>
 #include <fstream>
 
@@ -298,6 +299,19 @@ bool CCalculation::Result(std::string fileName, int i)
 {
     if (i != m_frame || !m_ctx || !m_done) return false;        // only the current frame's maps exist on the device
     // the reference opens the file first and reports that failure (R/CCalculation.cpp:325-331); so does this
+    // The text is formatted on the device and arrives ready to be written (slx_get_point_cloud_text); a frame with a coordinate the
+    // device formatter does not take (NaN, infinity, 0 < |v| < 1e-5, |v| >= 1e15) goes through the host formatter below.
+    const char *text = nullptr;
+    size_t n_bytes = 0;
+    if (slx_get_point_cloud_text(m_ctx, &text, &n_bytes, nullptr) == SLX_OK) {
+        std::FILE *f = std::fopen(fileName.c_str(), "w");
+        const bool ok = f && (n_bytes == 0 || std::fwrite(text, 1, n_bytes, f) == n_bytes);
+        if (!(f && std::fclose(f) == 0 && ok)) {
+            m_err = "CCalculation::Result() OpenFile Error:" + fileName;
+            return false;
+        }
+        return true;
+    }
     const double *pts = nullptr;                                   // pinned memory of the context: no vector to size and zero first
     size_t n = 0;
     if (slx_get_point_cloud_view(m_ctx, &pts, &n) != SLX_OK) n = 0;      // (as before: a cloud that cannot be had is an empty file)

@@ -60,6 +60,15 @@ struct slx_ctx {
     unsigned *h_cloud_total = nullptr;                                // pinned: the write kernel stores the point count here
     unsigned long long *d_cloud_words = nullptr;                      // fused cloud: ticket counter + epoch-tagged counts (slx_cloud.hip)
     unsigned cloud_epoch = 0;                                         // launches since the words were zeroed
+    // the cloud's text formatted on the device (slx_text.hip): device text + workgroup lengths, the text in pinned memory, [length, flag]
+    unsigned char *d_text = nullptr;
+    size_t d_text_capacity = 0;
+    unsigned *d_text_sums = nullptr;                                  // slx_text_workgroups() words + the 8-byte length behind them
+    size_t d_text_sums_capacity = 0;
+    char *h_text = nullptr;
+    size_t h_text_capacity = 0;
+    unsigned long long *h_text_info = nullptr;                        // pinned: [0] the length of the text, [1] the range flag (a tag)
+    unsigned text_tag = 0;
     size_t cloud_capacity = 0;
     // dynamic-frame tracker: previous frame's strips, unblurred deltaP, staged camera image
     float *d_stripW_prev = nullptr, *d_stripB_prev = nullptr, *d_deltaP_raw = nullptr;
@@ -325,6 +334,10 @@ void slx_destroy(slx_ctx *ctx)
     }
     if (ctx->h_cloud_total) (void)hipHostFree(ctx->h_cloud_total);
     if (ctx->h_cloud) (void)hipHostFree(ctx->h_cloud);
+    if (ctx->d_text) (void)hipFree(ctx->d_text);
+    if (ctx->d_text_sums) (void)hipFree(ctx->d_text_sums);
+    if (ctx->h_text) (void)hipHostFree(ctx->h_text);
+    if (ctx->h_text_info) (void)hipHostFree(ctx->h_text_info);
     for (hipEvent_t e : {ctx->ev0, ctx->ev1, ctx->ev_done, ctx->ev_track_copied[0], ctx->ev_track_copied[1], ctx->ev_track_used[0], ctx->ev_track_used[1]})
         if (e) (void)hipEventDestroy(e);
     if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
@@ -781,6 +794,89 @@ int slx_point_cloud_of_depth(slx_ctx *ctx, const double *depth, double *xyz, siz
     }
     SLX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return SLX_OK;
+}
+
+// Text of n packed (x, y, z) triples in device memory, formatted there (slx_text.hip), in the context's pinned buffer.
+int slx_format_points_text(slx_ctx *ctx, const double *xyz_dev, size_t n_points, const char **text, size_t *n_bytes)
+{
+    if (!ctx || !text || !n_bytes) return SLX_ERR_INVALID_ARG;
+    *text = "";
+    *n_bytes = 0;
+    if (n_points == 0) return SLX_OK;
+    if (!xyz_dev) return fail(ctx, SLX_ERR_INVALID_ARG, "xyz is NULL");
+    if ((uintptr_t)xyz_dev % sizeof(double)) return fail(ctx, SLX_ERR_INVALID_ARG, "xyz is not aligned to 8 bytes");
+    if (n_points >= (1ull << 40) / SLX_TEXT_LINE_MAX) return fail(ctx, SLX_ERR_INVALID_ARG, "%zu points: too many for one text", n_points);
+    SLX_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t need = n_points * SLX_TEXT_LINE_MAX + 16, wgs = (size_t)slx_text_workgroups(n_points);
+    if (ctx->d_text_capacity < need) {
+        SLX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->d_text) (void)hipFree(ctx->d_text);
+        ctx->d_text = nullptr;
+        ctx->d_text_capacity = 0;
+        SLX_HIP(ctx, hipMalloc((void **)&ctx->d_text, need));
+        ctx->d_text_capacity = need;
+    }
+    if (ctx->d_text_sums_capacity < wgs) {
+        SLX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->d_text_sums) (void)hipFree(ctx->d_text_sums);
+        ctx->d_text_sums = nullptr;
+        ctx->d_text_sums_capacity = 0;
+        SLX_HIP(ctx, hipMalloc((void **)&ctx->d_text_sums, (wgs + 4) * sizeof(unsigned)));   // + the length of the text, 8-byte aligned
+        ctx->d_text_sums_capacity = wgs;
+    }
+    if (!ctx->h_text_info) {
+        SLX_HIP(ctx, hipHostMalloc((void **)&ctx->h_text_info, 2 * sizeof(unsigned long long), hipHostMallocDefault));
+        ctx->h_text_info[0] = ctx->h_text_info[1] = 0;
+    }
+    if (int rc = order_after_done(ctx, ctx->stream)) return rc;       // the points may come from a launch on a caller's stream
+    unsigned long long *total_dev = (unsigned long long *)(ctx->d_text_sums + ((ctx->d_text_sums_capacity + 1) & ~(size_t)1));
+    if (++ctx->text_tag == 0) ctx->text_tag = 1;                       // (the flag word starts as 0 and keeps the last raised tag)
+    const int e = slx_launch_text(xyz_dev, n_points, ctx->d_text_sums, (unsigned *)&ctx->h_text_info[1], ctx->text_tag, ctx->d_text, total_dev,
+                                  &ctx->h_text_info[0], ctx->stream);
+    if (e != 0) return hip_fail(ctx, (hipError_t)e, "point-cloud text launch");
+    SLX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (*(volatile unsigned *)&ctx->h_text_info[1] == ctx->text_tag)
+        return fail(ctx, SLX_ERR_UNAVAILABLE, "a coordinate outside the device formatter's range (|v| < 1e-5, |v| >= 1e15, NaN or infinity): format this cloud on the host");
+    const size_t total = (size_t)*(volatile unsigned long long *)&ctx->h_text_info[0];
+    if (total > need) return fail(ctx, SLX_ERR_HIP, "the device reports %zu bytes of text for %zu points", total, n_points);
+    if (ctx->h_text_capacity < total) {
+        if (ctx->h_text) (void)hipHostFree(ctx->h_text);
+        ctx->h_text = nullptr;
+        ctx->h_text_capacity = 0;
+        const size_t cap = total + total / 8 + 4096;                  // successive frames differ by a few per cent
+        SLX_HIP(ctx, hipHostMalloc((void **)&ctx->h_text, cap, hipHostMallocDefault));
+        ctx->h_text_capacity = cap;
+    }
+    SLX_HIP(ctx, hipMemcpyAsync(ctx->h_text, ctx->d_text, total, hipMemcpyDeviceToHost, ctx->stream));
+    SLX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *text = ctx->h_text;
+    *n_bytes = total;
+    return SLX_OK;
+}
+
+int slx_get_point_cloud_text(slx_ctx *ctx, const char **text, size_t *n_bytes, size_t *n_points)
+{
+    if (!ctx || !text || !n_bytes) return SLX_ERR_INVALID_ARG;
+    *text = "";
+    *n_bytes = 0;
+    if (n_points) *n_points = 0;
+    if (!mode_has_depth(ctx->cfg.mode)) return fail(ctx, SLX_ERR_UNAVAILABLE, "mode %d produces no depth", ctx->cfg.mode);
+    if (!ctx->decoded) return fail(ctx, SLX_ERR_NOT_DECODED, "no decode has run yet");
+    SLX_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t all = (size_t)ctx->cfg.width * (size_t)ctx->cfg.height;
+    if (ctx->cloud_capacity < all) {                                  // the context's device buffer for a cloud: one triple per pixel
+        SLX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->d_cloud) (void)hipFree(ctx->d_cloud);
+        ctx->d_cloud = nullptr;
+        ctx->cloud_capacity = 0;
+        SLX_HIP(ctx, hipMalloc((void **)&ctx->d_cloud, all * 3 * sizeof(double)));
+        ctx->cloud_capacity = all;
+    }
+    size_t n = 0;
+    int rc = slx_point_cloud_of_depth(ctx, (const double *)ctx->out[SLX_OUT_Z], ctx->d_cloud, all, &n, SLX_MEM_DEVICE);
+    if (rc != SLX_OK) return rc;
+    if (n_points) *n_points = n;
+    return slx_format_points_text(ctx, ctx->d_cloud, n, text, n_bytes);
 }
 
 int slx_get_point_cloud_view(slx_ctx *ctx, const double **xyz, size_t *n_points)

@@ -120,6 +120,16 @@ size_t slx_cloud_fused_lds_bytes(int rows_per_part);          // dynamic LDS of 
 size_t slx_cloud_fused_words(int groups, int parts);
 int slx_launch_cloud_fused(const SlxCloudFused &q, void *stream);
 
+// The point-cloud text of CCalculation::Result formatted on the device (slx_text.hip): n_points packed (x, y, z) triples -> "x y z\n" lines,
+// every number as `ostream << double` prints it.  sums: slx_text_workgroups(n_points) words (device); flag: receives `tag` when a number is
+// outside the device formatter's range (pinned host word: the text is then void); text: device, 4-byte aligned, room for
+// n_points * SLX_TEXT_LINE_MAX bytes; total_dev / total_host: the length of the text (device word; pinned host word or null).
+#define SLX_TEXT_POINTS_PER_WG 1024
+#define SLX_TEXT_LINE_MAX 39         /* three numbers of at most 12 characters ("-1.23457e-05"), two blanks, the newline */
+inline unsigned long long slx_text_workgroups(unsigned long long n_points) { return (n_points + SLX_TEXT_POINTS_PER_WG - 1ull) / SLX_TEXT_POINTS_PER_WG; }
+int slx_launch_text(const double *xyz, unsigned long long n_points, unsigned *sums, unsigned *flag, unsigned tag, unsigned char *text,
+                    unsigned long long *total_dev, unsigned long long *total_host, void *stream);
+
 // Dynamic-frame tracker (slx_track.hip).  Device pointers; 0 or a hipError_t.
 // prevW / prevB / raw non-null: also raw = the deltaP selection between the previous frame's strips and the new ones
 // (fused into the strip kernel for the 21-pixel window, a second launch otherwise).

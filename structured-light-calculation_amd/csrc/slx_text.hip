@@ -1,0 +1,281 @@
+// slx_text.hip -- the point-cloud TEXT of CCalculation::Result, formatted on the device.
+//
+// CCalculation::Result (R/CCalculation.cpp:323-357) writes "x y z\n" for every point, each number as `ostream << double` prints it
+// (%g with 6 significant digits).  Formatting IS the cost of that function (3.6 s per 1920 x 1200 frame in the reference's loop;
+// 8-10 ms with the host-side writer of sensor.cpp on 16 threads, more than the rest of a dynamic frame together).  Here the packed
+// (x, y, z) triples the cloud kernels leave in device memory become that text in device memory -- exactly the bytes of the host writer
+// (fmt_g6_fast, sensor.cpp: six significant digits = round-half-even of the EXACT binary value scaled by a power of ten, in integer
+// arithmetic) -- and only the text crosses PCIe.
+//
+// Two launches over the points, 1 024 per workgroup (4 consecutive points per lane):
+//   slx_text_len_kernel   the length of every workgroup's text (digits and exponent of each number, no characters)
+//   slx_text_emit_kernel  a workgroup sums the lengths of the workgroups before it (a few thousand words, read by all lanes at once),
+//                         scans its lanes' lengths, writes the characters into LDS at their place and copies the packed text out as
+//                         aligned dwords (the partial dwords at its two ends byte by byte: they are shared with the neighbours)
+// A number outside the fast range (|v| < 1e-5 other than zero, |v| >= 1e15, NaN, infinity) raises a flag instead: the caller formats
+// that cloud on the host (std::to_chars / the C library's spelling of nan and inf).
+#include <hip/hip_runtime.h>
+
+#include "slx_kernels.h"
+
+namespace {
+
+constexpr unsigned kThreads = 256, kPerLane = SLX_TEXT_POINTS_PER_WG / kThreads;
+static_assert(kPerLane * kThreads == SLX_TEXT_POINTS_PER_WG && kPerLane == 4, "4 consecutive points per lane");
+
+__device__ const unsigned long long kPow10[20] = {1ull, 10ull, 100ull, 1000ull, 10000ull, 100000ull, 1000000ull, 10000000ull, 100000000ull, 1000000000ull,
+                                                  10000000000ull, 100000000000ull, 1000000000000ull, 10000000000000ull, 100000000000000ull,
+                                                  1000000000000000ull, 10000000000000000ull, 100000000000000000ull, 1000000000000000000ull,
+                                                  10000000000000000000ull};
+
+// One number, digested: the six significant digits as BCD (digit i, the most significant first, in bits 20 - 4 i ..), the decimal
+// exponent X of the first digit, the sign, the count of digits left once %g has dropped the trailing zeros.
+struct G6 {
+    unsigned bcd;
+    int X;
+    unsigned nd;
+    bool neg, zero, ok;
+};
+
+// sensor.cpp fmt_g6_fast, operation for operation (the same integers, so the same digits)
+__device__ __forceinline__ G6 g6_digits(double v)
+{
+    G6 g{0u, 0, 1u, false, false, true};
+    const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
+    g.neg = (bits >> 63) != 0;
+    const unsigned long long mag = bits & 0x7fffffffffffffffull;
+    if (mag == 0) {
+        g.zero = true;
+        return g;
+    }
+    const int k = (int)(mag >> 52) - 1023;
+    const double a = __builtin_fabs(v);
+    if (k < -17 || k > 49 || !(a >= 1e-5 && a < 1e15)) {             // 1e-5 > 2^-17, 1e15 < 2^50
+        g.ok = false;
+        return g;
+    }
+    const unsigned long long m = (mag & 0x000fffffffffffffull) | 0x0010000000000000ull;   // a = m * 2^(k - 52), exactly
+    const int s = 52 - k;                                            // > 0 in this range: a = m / 2^s
+    int X = k >= 0 ? (k * 1233) >> 12 : -(((-k) * 1233 + 4095) >> 12);   // within one of floor(log10 a)
+    unsigned long long q = 0;
+    for (int tries = 0; tries < 4; tries++) {                        // at most two corrections of the estimate
+        const int p = 5 - X;                                         // digits = a * 10^p, wanted in [10^5, 10^6)
+        bool up;
+        if (p >= 0) {
+            const unsigned __int128 T = (unsigned __int128)m * kPow10[p];   // p <= 10: T < 2^87
+            q = (unsigned long long)(T >> s);
+            if (q < 100000ull) { X--; continue; }
+            if (q >= 1000000ull) { X++; continue; }
+            const unsigned __int128 rem = T & ((((unsigned __int128)1) << s) - 1), half = ((unsigned __int128)1) << (s - 1);
+            up = rem > half || (rem == half && (q & 1ull));
+        } else {
+            const unsigned long long D = kPow10[-p] << s;            // -p <= 9, s <= 33: < 2^63
+            q = m / D;
+            if (q < 100000ull) { X--; continue; }
+            if (q >= 1000000ull) { X++; continue; }
+            const unsigned long long rem = m - q * D;
+            up = 2 * rem > D || (2 * rem == D && (q & 1ull));
+        }
+        if (up && ++q == 1000000ull) { q = 100000ull; X++; }
+        break;
+    }
+    g.X = X;
+    unsigned t = (unsigned)q, bcd = 0, nd = 6;
+    bool tail = true;                                                // still inside the run of trailing zeros
+#pragma unroll
+    for (int i = 0; i < 6; i++) {                                    // least significant digit first
+        const unsigned d = t % 10u;
+        t /= 10u;
+        bcd |= d << (4 * i);
+        tail = tail && d == 0u && i < 5;
+        nd -= tail ? 1u : 0u;                                        // %g drops trailing zeros
+    }
+    g.bcd = bcd;
+    g.nd = nd;
+    return g;
+}
+
+__device__ __forceinline__ unsigned g6_length(const G6 &g)
+{
+    unsigned n = g.neg ? 1u : 0u;
+    if (g.zero) return n + 1u;
+    const int X = g.X;
+    const unsigned nd = g.nd;
+    if (X < -4 || X >= 6) return n + (nd > 1 ? nd + 5u : 5u);        // d[.ddd]e+XX
+    if (X >= 0) return n + (unsigned)(X + 1) + (nd > (unsigned)(X + 1) ? 1u + nd - (unsigned)(X + 1) : 0u);
+    return n + 2u + (unsigned)(-X - 1) + nd;                         // 0.000ddd
+}
+
+// the characters, at out[0 ..): returns the end.  d(i) = digit i of q, the most significant first.
+__device__ __forceinline__ unsigned g6_put(const G6 &g, unsigned char *out, unsigned o)
+{
+    if (g.neg) out[o++] = '-';
+    if (g.zero) {
+        out[o++] = '0';
+        return o;
+    }
+    const unsigned bcd = g.bcd, nd = g.nd;
+    auto d = [&](unsigned i) { return (unsigned char)('0' + ((bcd >> (20u - 4u * i)) & 15u)); };
+    const int X = g.X;
+    if (X < -4 || X >= 6) {
+        out[o++] = d(0);
+        if (nd > 1) {
+            out[o++] = '.';
+            for (unsigned i = 1; i < nd; i++) out[o++] = d(i);
+        }
+        out[o++] = 'e';
+        int e = X;
+        if (e < 0) {
+            out[o++] = '-';
+            e = -e;
+        } else {
+            out[o++] = '+';
+        }
+        out[o++] = (unsigned char)('0' + e / 10);
+        out[o++] = (unsigned char)('0' + e % 10);
+    } else if (X >= 0) {
+        for (unsigned i = 0; i <= (unsigned)X; i++) out[o++] = i < nd ? d(i) : (unsigned char)'0';
+        if (nd > (unsigned)(X + 1)) {
+            out[o++] = '.';
+            for (unsigned i = (unsigned)X + 1u; i < nd; i++) out[o++] = d(i);
+        }
+    } else {
+        out[o++] = '0';
+        out[o++] = '.';
+        for (int i = 0; i < -X - 1; i++) out[o++] = '0';
+        for (unsigned i = 0; i < nd; i++) out[o++] = d(i);
+    }
+    return o;
+}
+
+// sum over the workgroup of one value per lane; every lane gets it
+__device__ __forceinline__ unsigned long long wg_sum(unsigned long long v, unsigned long long *scratch)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+    if ((threadIdx.x & 63u) == 0) scratch[threadIdx.x >> 6] = v;
+    __syncthreads();
+    unsigned long long t = 0;
+#pragma unroll
+    for (unsigned k = 0; k < kThreads / 64u; k++) t += scratch[k];
+    __syncthreads();
+    return t;
+}
+
+// flag: a word (pinned host memory) that receives `tag` when a number is outside the formatter's range -- tags differ from call to call,
+// so nothing has to be cleared
+__global__ __launch_bounds__(kThreads) void slx_text_len_kernel(const double *__restrict__ xyz, unsigned long long n_points, unsigned *__restrict__ sums,
+                                                               unsigned *__restrict__ flag, unsigned tag)
+{
+    __shared__ unsigned long long scratch[kThreads / 64u];
+    const unsigned long long first = ((unsigned long long)blockIdx.x * kThreads + threadIdx.x) * kPerLane;
+    unsigned len = 0;
+    bool bad = false;
+#pragma unroll
+    for (unsigned i = 0; i < kPerLane; i++) {
+        const unsigned long long pt = first + i;
+        if (pt >= n_points) break;
+#pragma unroll
+        for (unsigned c = 0; c < 3; c++) {
+            const G6 g = g6_digits(__builtin_nontemporal_load(xyz + 3ull * pt + c));
+            bad = bad || !g.ok;
+            len += g6_length(g) + 1u;                                // + the blank or the newline behind it
+        }
+    }
+    if (bad) *flag = tag;
+    const unsigned long long total = wg_sum(len, scratch);
+    if (threadIdx.x == 0) sums[blockIdx.x] = (unsigned)total;
+}
+
+__global__ __launch_bounds__(kThreads) void slx_text_emit_kernel(const double *__restrict__ xyz, unsigned long long n_points, const unsigned *__restrict__ sums,
+                                                                unsigned char *__restrict__ text, unsigned long long *__restrict__ total_dev,
+                                                                unsigned long long *__restrict__ total_host)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char buf[SLX_TEXT_POINTS_PER_WG * SLX_TEXT_LINE_MAX + 16];
+    __shared__ unsigned long long scratch[kThreads / 64u];
+    __shared__ unsigned wave_len[kThreads / 64u];
+    const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    // the numbers first: their loads are what everything waits for
+    const unsigned long long first = ((unsigned long long)blockIdx.x * kThreads + tid) * kPerLane;
+    G6 g[kPerLane][3];
+    unsigned len = 0;
+#pragma unroll
+    for (unsigned i = 0; i < kPerLane; i++) {
+        const unsigned long long pt = first + i;
+#pragma unroll
+        for (unsigned c = 0; c < 3; c++) {
+            g[i][c] = g6_digits(pt < n_points ? __builtin_nontemporal_load(xyz + 3ull * pt + c) : 0.0);
+            if (pt < n_points) len += g6_length(g[i][c]) + 1u;
+        }
+    }
+    // where this workgroup's text starts: the lengths of all workgroups before it
+    unsigned long long before = 0;
+    {
+        constexpr unsigned UNROLL = 8;                               // all of a lane's loads in flight (2 220 workgroups for a 1920 x 1200 cloud: 9 per lane)
+        for (unsigned i = tid; i < blockIdx.x; i += kThreads * UNROLL) {
+            unsigned t[UNROLL];
+#pragma unroll
+            for (unsigned k = 0; k < UNROLL; k++) t[k] = sums[i + kThreads * k < blockIdx.x ? i + kThreads * k : i];
+#pragma unroll
+            for (unsigned k = 0; k < UNROLL; k++) before += i + kThreads * k < blockIdx.x ? t[k] : 0u;
+        }
+    }
+    before = wg_sum(before, scratch);
+    // where this lane's text starts within the workgroup's
+    unsigned incl = len;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned t = __shfl_up(incl, d);
+        if (lane >= (unsigned)d) incl += t;
+    }
+    if (lane == 63u) wave_len[wave] = incl;
+    __syncthreads();
+    unsigned start = incl - len, mine = 0;
+#pragma unroll
+    for (unsigned k = 0; k < kThreads / 64u; k++) {
+        start += k < wave ? wave_len[k] : 0u;
+        mine += wave_len[k];
+    }
+    // characters into LDS: the buffer starts `mis` bytes in, so that its dwords are the aligned dwords of the text
+    const unsigned mis = (unsigned)(before & 3ull);
+    unsigned o = mis + start;
+#pragma unroll
+    for (unsigned i = 0; i < kPerLane; i++) {
+        if (first + i >= n_points) break;
+#pragma unroll
+        for (unsigned c = 0; c < 3; c++) {
+            o = g6_put(g[i][c], buf, o);
+            buf[o++] = c == 2 ? '\n' : ' ';
+        }
+    }
+    __syncthreads();
+    // out: whole dwords where all four bytes are this workgroup's, single bytes at the two ends
+    unsigned char *dst = text + (before - mis);
+    const unsigned end = mis + mine;
+    for (unsigned w = tid; 4u * w < end; w += kThreads) {
+        const unsigned lo = 4u * w;
+        if (lo >= mis && lo + 4u <= end) {
+            __builtin_nontemporal_store(*reinterpret_cast<const unsigned *>(buf + lo), reinterpret_cast<unsigned *>(dst + lo));
+        } else {
+            for (unsigned b = lo; b < lo + 4u; b++)
+                if (b >= mis && b < end) dst[b] = buf[b];
+        }
+    }
+    if (blockIdx.x + 1u == gridDim.x && tid == 0) {                  // the last workgroup knows the length of the text
+        *total_dev = before + mine;
+        if (total_host) *total_host = before + mine;
+    }
+}
+
+}  // namespace
+
+int slx_launch_text(const double *xyz, unsigned long long n_points, unsigned *sums, unsigned *flag, unsigned tag, unsigned char *text,
+                    unsigned long long *total_dev, unsigned long long *total_host, void *stream)
+{
+    if (!xyz || n_points == 0 || !sums || !flag || !text || !total_dev || (reinterpret_cast<uintptr_t>(text) & 3u)) return (int)hipErrorInvalidValue;
+    const unsigned long long wgs = (n_points + SLX_TEXT_POINTS_PER_WG - 1ull) / SLX_TEXT_POINTS_PER_WG;
+    if (wgs >= (1ull << 31)) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(slx_text_len_kernel, dim3((unsigned)wgs), dim3(kThreads), 0, (hipStream_t)stream, xyz, n_points, sums, flag, tag);
+    hipLaunchKernelGGL(slx_text_emit_kernel, dim3((unsigned)wgs), dim3(kThreads), 0, (hipStream_t)stream, xyz, n_points, sums, text, total_dev, total_host);
+    return (int)hipGetLastError();
+}

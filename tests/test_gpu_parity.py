@@ -1115,6 +1115,74 @@ def test_dynamic_frames(api, oracle, synth, shape, window):
         assert e.value.code == api.ERR_UNAVAILABLE
 
 
+def test_point_cloud_text_formatted_on_the_device(api, oracle, synth, torch_cuda, tmp_path):
+    """slx_format_points_text / slx_get_point_cloud_text (csrc/slx_text.hip): the text of CCalculation::Result (R/CCalculation.cpp:351-353,
+    `file << x << ' ' << y << ' ' << z << endl`) formatted on the device must be the bytes of the host writer (slx_write_point_cloud_text)
+    and of "%g": magnitudes across the formatter's whole range, both notations and their borders (X = -5, -4, 5, 6), ties of the sixth
+    digit on exactly representable values (round half to even), carries into a new digit (999999.5 -> 1e+06, 99999.95 -> 100000),
+    zeros of both signs, lengths that put the workgroups' boundaries at every alignment, a last workgroup with one point; a value
+    outside the range (tiny, huge, NaN, infinity) makes the call fail with SLX_ERR_UNAVAILABLE so that the caller formats on the host.
+    Then the cloud of a decoded frame and of a tracked frame at 1920 x 1200 against the host writer's file."""
+    torch = torch_cuda
+    rng = np.random.default_rng(17)
+    spec = synth.make_spec("C4")
+    H, W = spec["height"], spec["width"]
+
+    def fmt(a):
+        return ("".join("%g %g %g\n" % tuple(p) for p in a)).encode()
+
+    with api.Context(spec, aux=("U",)) as ctx:
+        cases = []
+        a = (rng.random((70001, 3)) - 0.3) * 1500.0
+        a[::5] = rng.standard_normal((a[::5].shape[0], 3)) * 10.0 ** rng.integers(-4, 14, size=(a[::5].shape[0], 1))
+        a[np.abs(a) < 1e-5] = 0.0
+        a[:8] = [[0.0, -0.0, 1.0], [999999.5, 999999.4, 0.0001], [0.00009999995, 123456.5, 1234565.0], [100000.5, 99999.95, 123.4565],
+                 [0.5, 2.5, 1.5], [1e-5, 9.99999e-5, 0.000123456], [999999.0, 1e6, 9.999995e14], [-1e-5, -123456.5, -0.0001234565]]
+        cases.append(a)
+        # ties: integers and halves are exact in binary: x.5 at the sixth digit must round to even
+        t = np.array([[100000.5 + 2 * k, 100001.5 + 2 * k, 12345.65 + k] for k in range(300)])
+        cases.append(np.concatenate([t, t / 1024.0, t * 4096.0, -t]))
+        cases.append(np.array([[1.0, 2.0, 3.0]]))                                # one point
+        cases.append((rng.random((1025, 3)) - 0.5) * 10.0 ** rng.integers(-5, 15, size=(1025, 1)))   # one workgroup and one point
+        cases[-1][np.abs(cases[-1]) < 1e-5] = 0.0
+        for k, a in enumerate(cases):
+            a = np.ascontiguousarray(a, dtype=np.float64)
+            dev = torch.from_numpy(a).cuda()
+            torch.cuda.synchronize()
+            got = ctx.format_points_text(dev)
+            want = fmt(a)
+            assert len(got) == len(want) and got == want, (k, [(i, g, w) for i, (g, w) in enumerate(zip(got.split(b"\n"), want.split(b"\n"))) if g != w][:3])
+            path = str(tmp_path / "host.txt")
+            api.write_point_cloud_text(path, a)
+            assert open(path, "rb").read() == got, k
+        assert ctx.format_points_text(torch.empty((0, 3), dtype=torch.float64, device="cuda")) == b""
+        for bad in (1e-7, -3e-6, 1e15, -2.5e200, np.nan, np.inf, -np.inf, 5e-324):
+            a = np.ones((2050, 3))
+            a[2049, 1] = bad
+            dev = torch.from_numpy(a).cuda()
+            torch.cuda.synchronize()
+            with pytest.raises(api.SlxError) as e:
+                ctx.format_points_text(dev)
+            assert e.value.code == api.ERR_UNAVAILABLE, bad
+            assert ctx.format_points_text(dev[:2049]) == fmt(a[:2049])          # the next call is not affected
+        # a decoded frame's cloud, then a tracked frame's
+        ph, gr, _ = synth.render(spec, "sphere", noise_sigma=2.0)
+        imgs = dyna_images(H, W, 2, seed=4)
+        ctx.set_frames(ph, gr)
+        ctx.decode()
+        for step in range(2):
+            if step == 1:
+                ctx.track_begin(imgs[0])
+                ctx.track_next(imgs[1])
+            text, n = ctx.get_point_cloud_text()
+            cloud = ctx.get_point_cloud()
+            assert n == len(cloud) and 0 < n < H * W
+            path = str(tmp_path / "cloud.txt")
+            api.write_point_cloud_text(path, cloud)
+            assert open(path, "rb").read() == text, step
+            assert text[:200] == fmt(cloud[:40])[:200]
+
+
 def test_tracked_frame_cloud_full_size(api, oracle, synth, torch_cuda):
     """The reference writes a cloud after every dynamic frame (main loop: CalculateOther, Result): 1920 x 1200, three tracked frames in a
     row, the cloud of each into host memory (count first), as the context's pinned view, into a device buffer for every pixel and into
