@@ -68,6 +68,20 @@ def one_case(seed):
     def check(tag, got, want):
         if not np.array_equal(got, want, equal_nan=True):
             bad.append(tag)
+
+    def check_text(tag, ctx, cloud):
+        """The cloud's text formatted on the device (slx_get_point_cloud_text) = "%g %g %g\\n" of the oracle's cloud, or -- a coordinate
+        outside the device formatter's range -- the call declines."""
+        a = np.abs(cloud)
+        in_range = bool(np.all(np.isfinite(cloud)) and np.all((a == 0) | ((a >= 1e-5) & (a < 1e15))))
+        try:
+            text, n = ctx.get_point_cloud_text()
+        except api.SlxError as e:
+            if in_range or e.code != api.ERR_UNAVAILABLE:
+                bad.append(tag + " (declined: %s)" % str(e)[:60])
+            return
+        if not in_range or n != len(cloud) or text != ("".join("%g %g %g\n" % tuple(p) for p in cloud)).encode():
+            bad.append(tag)
     # ---- the single frame-set call, every plane it can give, and the cloud of its depth
     wants = ["z", "x", "y", "U", "pix"] + (["gray"] if spec["gray_bits"] else []) + (["mask"] if spec["mode"] in (3, 4) else []) + \
             (["k"] if spec["mode"] in (3, 4) and spec["n_freq"] > 1 else [])
@@ -83,6 +97,8 @@ def one_case(seed):
         ctx.set_frames(ph, gr)
         ctx.decode()
         check("cloud0", ctx.get_point_cloud(), O.point_cloud(spec, ref["z"]))
+        if h * w <= 40000:
+            check_text("text0", ctx, O.point_cloud(spec, ref["z"]))
         if h < 1 or w < 1:
             return what, bad
         try:
@@ -135,6 +151,8 @@ def one_case(seed):
                 check("track f%d feed%d %s" % (f - 1, feed, n_), ctx.get_output(n_), want)
             if rng.random() < 0.5:
                 check("cloud f%d" % (f - 1), ctx.get_point_cloud(), O.point_cloud(spec, tri["z"]))
+                if h * w <= 40000 and rng.random() < 0.5:
+                    check_text("text f%d" % (f - 1), ctx, O.point_cloud(spec, tri["z"]))
     return what, bad
 
 
