@@ -212,6 +212,75 @@ PROBE_LAUNCHES = 8               # launches of every workload in a traffic-probe
 SMI_CMD = ["/opt/rocm/bin/rocm-smi", "--showpower", "--showclocks", "--showmaxpower", "--json"]
 
 
+def around_the_path(torch, np, api, synth, O, dev_index, device):
+    """The callers of the path in the reference's loop, one short measurement each at 1920 x 1200, taken by this run's
+    clock and checked against the oracle: a dynamic frame (CalculateOther), the point cloud of its depth and the cloud's text file
+    (CCalculation::Result).  Never the headline; a failure is reported in the entry and changes nothing else."""
+    out = {}
+    try:
+        spec = synth.make_spec("C4")
+        H, W = spec["height"], spec["width"]
+        ph, gr, _ = synth.render(spec, "sphere", seed=9, noise_sigma=1.0)
+        u = torch.arange(W, device=device)[None, :] + 0.02 * torch.arange(H, device=device)[:, None]
+        gen = torch.Generator(device=device).manual_seed(3)
+        imgs = [(128 + 100 * torch.sign(torch.sin(2 * np.pi * (u + 1.7 * f) / 14.0)) + 6 * torch.randn((H, W), device=device, generator=gen)).clamp(0, 255).to(torch.uint8)
+                for f in range(4)]
+        xyz = torch.empty((H * W, 3), dtype=torch.float64, device=device)
+        torch.cuda.synchronize()
+        import ctypes as C
+        with api.Context(spec, aux=("U",), device=dev_index) as ctx:
+            ctx.set_frames(ph, gr)
+            ctx.decode()
+            ctx.track_begin(imgs[0])
+            ref0 = O.pipeline(spec, ph, gr, want=("z", "U"), threads=min(usable_cpus(), 16))
+            ctx.track_next(imgs[1])
+            sw0, sb0 = O.strip_regression(imgs[0].cpu().numpy())
+            sw1, sb1 = O.strip_regression(imgs[1].cpu().numpy())
+            U1 = ref0["U"] + O.delta_p(sw0, sb0, sw1, sb1).astype(np.float64)
+            z1 = O.triangulate(spec, U1)["z"]
+            track_ok = bool(np.array_equal(ctx.get_depth(), z1, equal_nan=True))
+            cloud_ref = O.point_cloud(spec, z1)
+            cloud_ok = bool(np.array_equal(ctx.get_point_cloud(), cloud_ref, equal_nan=True))
+            text, n_pts = ctx.get_point_cloud_text()
+            import tempfile
+            with tempfile.NamedTemporaryFile(suffix=".txt") as tf:
+                api.write_point_cloud_text(tf.name, cloud_ref)      # the host formatter: the same bytes as `ostream << double`
+                text_ok = bool(open(tf.name, "rb").read() == text)
+            n = C.c_size_t(0)
+            L = api.lib()
+            t0 = time.perf_counter()
+            for _ in range(50):
+                assert L.slx_get_point_cloud(ctx._h, xyz.data_ptr(), H * W, C.byref(n), api.MEM_DEVICE) == 0
+            cloud_us = (time.perf_counter() - t0) / 50 * 1e6
+            tp, tb, tn = C.c_void_p(), C.c_size_t(0), C.c_size_t(0)
+            t0 = time.perf_counter()
+            for _ in range(8):                                       # (the C call: the text stays in the context's pinned buffer)
+                assert L.slx_get_point_cloud_text(ctx._h, C.byref(tp), C.byref(tb), C.byref(tn)) == 0
+            text_ms = (time.perf_counter() - t0) / 8 * 1e3
+            for f in range(60):
+                ctx.track_next(imgs[f % 4])
+            ctx.synchronize()
+            t0 = time.perf_counter()
+            for f in range(400):
+                ctx.track_next(imgs[f % 4])
+            ctx.synchronize()
+            track_us = (time.perf_counter() - t0) / 400 * 1e6
+        cloud_bytes = 8 * H * W + 24 * n.value
+        out["dynamic_frame"] = {"what": "slx_track_next, image resident in HBM, 1920x1200, window 21 (CCalculation::CalculateOther)", "us_per_frame": track_us,
+                                "bytes_per_pixel": 77, "roofline": {"bound": "hbm", "achieved": 77 * H * W / track_us / 1e3, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                                                     "frac": 77 * H * W / track_us / 1e3 / HBM_PEAK_GBPS}, "parity_vs_oracle": track_ok}
+        out["point_cloud"] = {"what": "slx_get_point_cloud into device memory, the host's wait for the count included (CCalculation::Result's points)",
+                              "us_per_cloud": cloud_us, "points": int(n.value), "algorithmic_bytes": cloud_bytes,
+                              "roofline": {"bound": "hbm", "achieved": cloud_bytes / cloud_us / 1e3, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                           "frac": cloud_bytes / cloud_us / 1e3 / HBM_PEAK_GBPS, "note": "launch + completion wait of a 20 us kernel included"},
+                              "parity_vs_oracle": cloud_ok}
+        out["point_cloud_text"] = {"what": "slx_get_point_cloud_text: the cloud and its text file's bytes, formatted on the device, in pinned host memory (PCIe included)",
+                                   "ms_per_frame": text_ms, "points": int(n_pts), "text_bytes": len(text), "same_bytes_as_the_host_formatter": text_ok}
+    except Exception as e:
+        out["error"] = "%s: %s" % (type(e).__name__, e)
+    return out
+
+
 def smi_sample(device_index):
     """One reading of the card's power management (sysfs through rocm-smi, no GPU context): socket power, its cap, shader clock.
     None when the tool is missing or prints something else."""
@@ -1119,7 +1188,12 @@ def run_rank(args):
                     del oph, ogr, outs
                 except Exception as e:
                     other[label] = {"error": "%s: %s" % (type(e).__name__, e)}
+        around = None
+        if world == 1 and not args.no_other_configs:
+            around = around_the_path(torch, np, api, synth, O, dev_index, device)
         result = make_result(gather, cpu_single, cpu_multi, parity, other, headline=headline)
+        if around is not None:
+            result["around_the_path"] = around
         emit(json.dumps(result))
     ctx.close()
     if world > 1 or solo_gather:
