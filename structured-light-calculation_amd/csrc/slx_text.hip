@@ -7,7 +7,7 @@
 // (fmt_g6_fast, sensor.cpp: six significant digits = round-half-even of the EXACT binary value scaled by a power of ten, in integer
 // arithmetic) -- and only the text crosses PCIe.
 //
-// Two launches over the points, 1 024 per workgroup (4 consecutive points per lane):
+// Two launches over the points, 1 024 per workgroup (a wave takes 256 consecutive points, a lane every 64th of them):
 //   slx_text_len_kernel   the length of every workgroup's text (digits and exponent of each number, no characters)
 //   slx_text_emit_kernel  a workgroup sums the lengths of the workgroups before it (a few thousand words, read by all lanes at once),
 //                         scans its lanes' lengths, writes the characters into LDS at their place and copies the packed text out as
@@ -21,45 +21,64 @@
 namespace {
 
 constexpr unsigned kThreads = 256, kPerLane = SLX_TEXT_POINTS_PER_WG / kThreads;
-static_assert(kPerLane * kThreads == SLX_TEXT_POINTS_PER_WG && kPerLane == 4, "4 consecutive points per lane");
+static_assert(kPerLane * kThreads == SLX_TEXT_POINTS_PER_WG && kPerLane == 4, "4 points per lane");
 
 __device__ const unsigned long long kPow10[20] = {1ull, 10ull, 100ull, 1000ull, 10000ull, 100000ull, 1000000ull, 10000000ull, 100000000ull, 1000000000ull,
                                                   10000000000ull, 100000000000ull, 1000000000000ull, 10000000000000ull, 100000000000000ull,
                                                   1000000000000000ull, 10000000000000000ull, 100000000000000000ull, 1000000000000000000ull,
                                                   10000000000000000000ull};
 
-// One number, digested: the six significant digits as BCD (digit i, the most significant first, in bits 20 - 4 i ..), the decimal
-// exponent X of the first digit, the sign, the count of digits left once %g has dropped the trailing zeros.
-struct G6 {
-    unsigned bcd;
-    int X;
-    unsigned nd;
-    bool neg, zero, ok;
-};
-
-// sensor.cpp fmt_g6_fast, operation for operation (the same integers, so the same digits)
-__device__ __forceinline__ G6 g6_digits(double v)
+// One number, digested, in a word: the six significant digits as BCD (digit i, the most significant first, in bits 20 - 4 i ..; all zero
+// for a zero), bits 24-28 the decimal exponent X of the first digit + 16, bit 29 the sign.  (The kernels keep ONE copy of the digit
+// arithmetic in a loop over a lane's twelve numbers: unrolled it was 24 000 instructions, more than the instruction cache holds.)
+constexpr unsigned kG6Neg = 1u << 29;
+__device__ __forceinline__ unsigned g6_bcd(unsigned g) { return g & 0xffffffu; }
+__device__ __forceinline__ int g6_X(unsigned g) { return (int)((g >> 24) & 31u) - 16; }
+__device__ __forceinline__ unsigned g6_nd(unsigned g)               // digits left once %g has dropped the trailing zeros
 {
-    G6 g{0u, 0, 1u, false, false, true};
+    const unsigned z = (unsigned)__builtin_ctz(g6_bcd(g) | 0x100000u) >> 2;   // trailing zero digits, 5 at most
+    return 6u - z;
+}
+
+// sensor.cpp fmt_g6_fast: the same six digits.  The integer arithmetic of that function (the EXACT value a * 10^p, rounded half to even) is
+// what decides a tie; in front of it stands a shortcut in double arithmetic for everything that is not near one: t = fl(a * 10^p)
+// -- one rounding, 10^p is exact; p >= 0, i.e. |v| < 10^6 -- lies within 2^-33 of the exact value e (e < 10^6 < 2^20), so whenever t is farther than
+// 2^-30 from every half-integer, rint(e) = rint(t); and whenever t is farther than 10^-6 from 10^5 and 10^6, floor(t) and floor(e) fall on
+// the same side of the range test.  Anything nearer (a tie or near-tie of the sixth digit: decimal-looking inputs such as 123.4565) takes
+// the integer path.  Measured cloud coordinates never do; the kernels were 87 + 117 us per 2.27 M points without the shortcut.
+__device__ __forceinline__ unsigned g6_digits(double v, bool &ok)
+{
     const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
-    g.neg = (bits >> 63) != 0;
+    const unsigned neg = (bits >> 63) ? kG6Neg : 0u;
     const unsigned long long mag = bits & 0x7fffffffffffffffull;
-    if (mag == 0) {
-        g.zero = true;
-        return g;
-    }
+    if (mag == 0) return neg | (16u << 24);                          // zero: no digits
     const int k = (int)(mag >> 52) - 1023;
     const double a = __builtin_fabs(v);
     if (k < -17 || k > 49 || !(a >= 1e-5 && a < 1e15)) {             // 1e-5 > 2^-17, 1e15 < 2^50
-        g.ok = false;
-        return g;
+        ok = false;
+        return neg | (16u << 24);
     }
     const unsigned long long m = (mag & 0x000fffffffffffffull) | 0x0010000000000000ull;   // a = m * 2^(k - 52), exactly
     const int s = 52 - k;                                            // > 0 in this range: a = m / 2^s
     int X = k >= 0 ? (k * 1233) >> 12 : -(((-k) * 1233 + 4095) >> 12);   // within one of floor(log10 a)
     unsigned long long q = 0;
+#pragma unroll 1
     for (int tries = 0; tries < 4; tries++) {                        // at most two corrections of the estimate
         const int p = 5 - X;                                         // digits = a * 10^p, wanted in [10^5, 10^6)
+        if (p >= 0 && p <= 10) {                                     // (|v| >= 10^6, a division: rare in a cloud, left to the integers)
+            // 10^p from its bits: exact products below 2^53, no table in memory on the way
+            const double P = ((p & 1) ? 10.0 : 1.0) * ((p & 2) ? 100.0 : 1.0) * (((p & 4) ? 1e4 : 1.0) * ((p & 8) ? 1e8 : 1.0));
+            const double t = a * P;
+            const double f = __builtin_floor(t), fr = t - f;
+            if (__builtin_fabs(fr - 0.5) > 0x1p-30 && __builtin_fabs(t - 1e5) > 1e-6 && __builtin_fabs(t - 1e6) > 1e-6) {
+                if (f < 1e5) { X--; continue; }
+                if (f >= 1e6) { X++; continue; }
+                unsigned q32 = (unsigned)f + (fr > 0.5 ? 1u : 0u);   // f < 2^20
+                if (q32 == 1000000u) { q32 = 100000u; X++; }
+                q = q32;
+                break;
+            }
+        }
         bool up;
         if (p >= 0) {
             const unsigned __int128 T = (unsigned __int128)m * kPow10[p];   // p <= 10: T < 2^87
@@ -79,44 +98,37 @@ __device__ __forceinline__ G6 g6_digits(double v)
         if (up && ++q == 1000000ull) { q = 100000ull; X++; }
         break;
     }
-    g.X = X;
-    unsigned t = (unsigned)q, bcd = 0, nd = 6;
-    bool tail = true;                                                // still inside the run of trailing zeros
+    unsigned t = (unsigned)q, bcd = 0;
 #pragma unroll
     for (int i = 0; i < 6; i++) {                                    // least significant digit first
-        const unsigned d = t % 10u;
+        bcd |= (t % 10u) << (4 * i);
         t /= 10u;
-        bcd |= d << (4 * i);
-        tail = tail && d == 0u && i < 5;
-        nd -= tail ? 1u : 0u;                                        // %g drops trailing zeros
     }
-    g.bcd = bcd;
-    g.nd = nd;
-    return g;
+    return neg | ((unsigned)(X + 16) << 24) | bcd;
 }
 
-__device__ __forceinline__ unsigned g6_length(const G6 &g)
+__device__ __forceinline__ unsigned g6_length(unsigned g)
 {
-    unsigned n = g.neg ? 1u : 0u;
-    if (g.zero) return n + 1u;
-    const int X = g.X;
-    const unsigned nd = g.nd;
+    const unsigned n = (g & kG6Neg) ? 1u : 0u;
+    if (g6_bcd(g) == 0u) return n + 1u;
+    const int X = g6_X(g);
+    const unsigned nd = g6_nd(g);
     if (X < -4 || X >= 6) return n + (nd > 1 ? nd + 5u : 5u);        // d[.ddd]e+XX
     if (X >= 0) return n + (unsigned)(X + 1) + (nd > (unsigned)(X + 1) ? 1u + nd - (unsigned)(X + 1) : 0u);
     return n + 2u + (unsigned)(-X - 1) + nd;                         // 0.000ddd
 }
 
 // the characters, at out[0 ..): returns the end.  d(i) = digit i of q, the most significant first.
-__device__ __forceinline__ unsigned g6_put(const G6 &g, unsigned char *out, unsigned o)
+__device__ __forceinline__ unsigned g6_put(unsigned g, unsigned char *out, unsigned o)
 {
-    if (g.neg) out[o++] = '-';
-    if (g.zero) {
+    if (g & kG6Neg) out[o++] = '-';
+    const unsigned bcd = g6_bcd(g), nd = g6_nd(g);
+    if (bcd == 0u) {
         out[o++] = '0';
         return o;
     }
-    const unsigned bcd = g.bcd, nd = g.nd;
     auto d = [&](unsigned i) { return (unsigned char)('0' + ((bcd >> (20u - 4u * i)) & 15u)); };
-    const int X = g.X;
+    const int X = g6_X(g);
     if (X < -4 || X >= 6) {
         out[o++] = d(0);
         if (nd > 1) {
@@ -168,20 +180,26 @@ __global__ __launch_bounds__(kThreads) void slx_text_len_kernel(const double *__
                                                                unsigned *__restrict__ flag, unsigned tag)
 {
     __shared__ unsigned long long scratch[kThreads / 64u];
-    const unsigned long long first = ((unsigned long long)blockIdx.x * kThreads + threadIdx.x) * kPerLane;
+    // a wave takes 256 consecutive points, a lane every 64th of them: the lanes of a load stand 24 bytes apart
+    const unsigned long long base = (unsigned long long)blockIdx.x * SLX_TEXT_POINTS_PER_WG + (threadIdx.x >> 6) * (64u * kPerLane) + (threadIdx.x & 63u);
     unsigned len = 0;
     bool bad = false;
+    double v[kPerLane * 3];
 #pragma unroll
-    for (unsigned i = 0; i < kPerLane; i++) {
-        const unsigned long long pt = first + i;
-        if (pt >= n_points) break;
+    for (unsigned i = 0; i < kPerLane; i++)                          // all twelve loads first
 #pragma unroll
-        for (unsigned c = 0; c < 3; c++) {
-            const G6 g = g6_digits(__builtin_nontemporal_load(xyz + 3ull * pt + c));
-            bad = bad || !g.ok;
-            len += g6_length(g) + 1u;                                // + the blank or the newline behind it
-        }
+        for (unsigned c = 0; c < 3; c++) v[3 * i + c] = base + 64u * i < n_points ? xyz[3ull * (base + 64u * i) + c] : 1.0;
+    const unsigned mine_n = base >= n_points ? 0u : (unsigned)((n_points - base + 63u) / 64u < kPerLane ? (n_points - base + 63u) / 64u : kPerLane) * 3u;
+    bool ok = true;
+#pragma unroll 1
+    for (unsigned j = 0; j < kPerLane * 3u; j++) {                   // ONE copy of the digit arithmetic
+        double x = v[0];
+#pragma unroll
+        for (unsigned k = 1; k < kPerLane * 3u; k++) x = j == k ? v[k] : x;
+        const unsigned g = g6_digits(x, ok);
+        len += j < mine_n ? g6_length(g) + 1u : 0u;                  // + the blank or the newline behind it
     }
+    bad = !ok;
     if (bad) *flag = tag;
     const unsigned long long total = wg_sum(len, scratch);
     if (threadIdx.x == 0) sums[blockIdx.x] = (unsigned)total;
@@ -194,18 +212,31 @@ __global__ __launch_bounds__(kThreads) void slx_text_emit_kernel(const double *_
     __shared__ __attribute__((aligned(16))) unsigned char buf[SLX_TEXT_POINTS_PER_WG * SLX_TEXT_LINE_MAX + 16];
     __shared__ unsigned long long scratch[kThreads / 64u];
     __shared__ unsigned wave_len[kThreads / 64u];
+    __shared__ unsigned digested[kPerLane * 3][kThreads];
     const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    // the numbers first: their loads are what everything waits for
-    const unsigned long long first = ((unsigned long long)blockIdx.x * kThreads + tid) * kPerLane;
-    G6 g[kPerLane][3];
-    unsigned len = 0;
+    // the numbers first: their loads are what everything waits for.  A wave takes 256 consecutive points, a lane every 64th of them
+    // (the lanes of a load stand 24 bytes apart); part i of a wave is its points 64 i .. 64 i + 63.
+    const unsigned long long base = (unsigned long long)blockIdx.x * SLX_TEXT_POINTS_PER_WG + wave * (64u * kPerLane) + lane;
+    double v[kPerLane * 3];
 #pragma unroll
-    for (unsigned i = 0; i < kPerLane; i++) {
-        const unsigned long long pt = first + i;
+    for (unsigned i = 0; i < kPerLane; i++)
 #pragma unroll
-        for (unsigned c = 0; c < 3; c++) {
-            g[i][c] = g6_digits(pt < n_points ? __builtin_nontemporal_load(xyz + 3ull * pt + c) : 0.0);
-            if (pt < n_points) len += g6_length(g[i][c]) + 1u;
+        for (unsigned c = 0; c < 3; c++) v[3 * i + c] = base + 64u * i < n_points ? xyz[3ull * (base + 64u * i) + c] : 1.0;
+    unsigned plen[kPerLane];                                         // length of this lane's line of part i
+#pragma unroll
+    for (unsigned i = 0; i < kPerLane; i++) plen[i] = 0;
+    {
+        bool ok = true;
+#pragma unroll 1
+        for (unsigned j = 0; j < kPerLane * 3u; j++) {               // ONE copy of the digit arithmetic; the digested numbers wait in LDS
+            double x = v[0];
+#pragma unroll
+            for (unsigned k = 1; k < kPerLane * 3u; k++) x = j == k ? v[k] : x;
+            const unsigned g = g6_digits(x, ok);
+            digested[j][tid] = g;
+            const unsigned l = base + 64u * (j / 3u) < n_points ? g6_length(g) + 1u : 0u;
+#pragma unroll
+            for (unsigned i = 0; i < kPerLane; i++) plen[i] += j / 3u == i ? l : 0u;
         }
     }
     // where this workgroup's text starts: the lengths of all workgroups before it
@@ -221,16 +252,22 @@ __global__ __launch_bounds__(kThreads) void slx_text_emit_kernel(const double *_
         }
     }
     before = wg_sum(before, scratch);
-    // where this lane's text starts within the workgroup's
-    unsigned incl = len;
+    // where this lane's lines start within the workgroup's text: part after part of the wave, lane after lane within a part
+    unsigned pstart[kPerLane], wave_total = 0;
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const unsigned t = __shfl_up(incl, d);
-        if (lane >= (unsigned)d) incl += t;
+    for (unsigned i = 0; i < kPerLane; i++) {
+        unsigned incl = plen[i];
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const unsigned t = __shfl_up(incl, d);
+            if (lane >= (unsigned)d) incl += t;
+        }
+        pstart[i] = wave_total + incl - plen[i];
+        wave_total += __shfl(incl, 63);
     }
-    if (lane == 63u) wave_len[wave] = incl;
+    if (lane == 0) wave_len[wave] = wave_total;
     __syncthreads();
-    unsigned start = incl - len, mine = 0;
+    unsigned start = 0, mine = 0;
 #pragma unroll
     for (unsigned k = 0; k < kThreads / 64u; k++) {
         start += k < wave ? wave_len[k] : 0u;
@@ -238,15 +275,18 @@ __global__ __launch_bounds__(kThreads) void slx_text_emit_kernel(const double *_
     }
     // characters into LDS: the buffer starts `mis` bytes in, so that its dwords are the aligned dwords of the text
     const unsigned mis = (unsigned)(before & 3ull);
-    unsigned o = mis + start;
+#pragma unroll 1
+    for (unsigned j = 0, o = 0; j < kPerLane * 3u; j++) {
+        const unsigned i = j / 3u, c = j - 3u * i;
+        if (base + 64u * i >= n_points) break;
+        if (c == 0) {
+            unsigned ps = pstart[0];
 #pragma unroll
-    for (unsigned i = 0; i < kPerLane; i++) {
-        if (first + i >= n_points) break;
-#pragma unroll
-        for (unsigned c = 0; c < 3; c++) {
-            o = g6_put(g[i][c], buf, o);
-            buf[o++] = c == 2 ? '\n' : ' ';
+            for (unsigned k = 1; k < kPerLane; k++) ps = i == k ? pstart[k] : ps;
+            o = mis + start + ps;
         }
+        o = g6_put(digested[j][tid], buf, o);
+        buf[o++] = c == 2 ? '\n' : ' ';
     }
     __syncthreads();
     // out: whole dwords where all four bytes are this workgroup's, single bytes at the two ends
