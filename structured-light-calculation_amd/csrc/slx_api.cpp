@@ -271,7 +271,16 @@ int wait_done_host(slx_ctx *ctx)
 {
     if (ctx->own_pending) SLX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     else if (ctx->ev_pending) SLX_HIP(ctx, hipEventSynchronize(ctx->ev_done));
+    ctx->own_pending = ctx->ev_pending = false;                      // waited for: nothing later has to be ordered behind it
     return SLX_OK;
+}
+// A caller's stream that is being captured into a hipGraph: the launch becomes a node of the graph, ordered by the graph; the context
+// neither waits for events recorded outside the capture (it could not) nor records one of its own for it.
+bool capturing(slx_ctx *ctx, hipStream_t s)
+{
+    if (s == ctx->stream) return false;
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    return hipStreamIsCapturing(s, &st) == hipSuccess && st == hipStreamCaptureStatusActive;
 }
 int order_after_done(slx_ctx *ctx, hipStream_t s)
 {
@@ -533,18 +542,29 @@ static int launch(slx_ctx *ctx, SlxKParams &kp, int n_sets, bool aux, void *stre
         return fail(ctx, SLX_ERR_UNAVAILABLE, "variant %d (cheap exact arithmetic) needs a depth mode, periods <= 2^14 and moderate calibration magnitudes", ctx->variant);
     // ordered after the last work on the context's outputs when that ran on another stream (tracker / cloud kernels on the
     // context's stream, an earlier decode on a caller's stream)
-    if (int rc2 = order_after_done(ctx, s)) return rc2;
+    const bool captured = capturing(ctx, s);
+    if (captured) {
+        // everything the context itself has in flight must be done before the capture began (the graph cannot depend on it)
+        if (ctx->own_pending || ctx->ev_pending)
+            return fail(ctx, SLX_ERR_INVALID_ARG, "capture into a hipGraph: call slx_synchronize before the capture begins (work of this context is still in flight)");
+        if (ctx->timed) return fail(ctx, SLX_ERR_INVALID_ARG, "capture into a hipGraph: switch slx_enable_timing off");
+    } else if (int rc2 = order_after_done(ctx, s)) {
+        return rc2;
+    }
     if (ctx->timed) SLX_HIP(ctx, hipEventRecord(ctx->ev0, s));
-    if (!ctx->stream_state.counters && c.mode == SLX_MODE_MULTIFREQ && n_sets > 1) {
+    if (!captured && !ctx->stream_state.counters && c.mode == SLX_MODE_MULTIFREQ && n_sets > 1) {
         // queue counters of the stream kernel: zeroed by the launcher whenever the geometry they count for changes
         SLX_HIP(ctx, hipMalloc((void **)&ctx->stream_state.counters, (size_t)SLX_STREAM_MAX_QUEUES * 32u * sizeof(unsigned)));
         ctx->stream_state.key = 0;
     }
-    int e = slx_launch_fused(kp, c.mode, aux, n_sets, ctx->variant, s, &ctx->tune, &ctx->stream_state);
-    if (e != 0) ctx->stream_state.key = 0;      // whatever a failed launch left in the counters is not trusted
+    // (a replayed graph repeats its kernel arguments: the stream kernel, whose queue counters advance from launch to launch, stays out of it)
+    SlxTuning tune = ctx->tune;
+    if (captured) tune.stream = 1;
+    int e = slx_launch_fused(kp, c.mode, aux, n_sets, ctx->variant, s, &tune, captured ? nullptr : &ctx->stream_state);
+    if (e != 0 && !captured) ctx->stream_state.key = 0;      // whatever a failed launch left in the counters is not trusted
     if (e != 0) return hip_fail(ctx, (hipError_t)e, "kernel launch");
     if (ctx->timed) SLX_HIP(ctx, hipEventRecord(ctx->ev1, s));
-    return mark_done(ctx, s);
+    return captured ? SLX_OK : mark_done(ctx, s);
 }
 
 int slx_decode(slx_ctx *ctx, void *stream)

@@ -1115,6 +1115,57 @@ def test_dynamic_frames(api, oracle, synth, shape, window):
         assert e.value.code == api.ERR_UNAVAILABLE
 
 
+def test_decodes_captured_into_a_hip_graph(api, oracle, synth, torch_cuda):
+    """slx_decode_batch_ex on a caller's stream inside a stream capture (include/slx.h, "hipGraphs"): four single-frame-set launches and a
+    32-set batch (the planner's stream kernel must stay out of a graph: its queue counters advance from launch to launch) become one
+    graph; three replays over changing inputs give what plain launches give, frame-set 0 also against the oracle; a capture that
+    begins while work of the context is in flight is refused, not mis-ordered."""
+    torch = torch_cuda
+    spec = small_spec(synth, "C4", 1920, 304)
+    H, W = spec["height"], spec["width"]
+    ph = torch.randint(0, 256, (36, 12, H, W), dtype=torch.uint8, device="cuda", generator=torch.Generator(device="cuda").manual_seed(21))
+    z = torch.empty((36, H, W), dtype=torch.float64, device="cuda")
+    want = torch.empty_like(z)
+    torch.cuda.synchronize()
+    with api.Context(spec) as ctx:
+        def launches(out, stream=None):
+            for r in range(4):
+                ctx.decode_batch_ex(1, ph[r:r + 1], None, z=out[r:r + 1], stream=stream)
+            ctx.decode_batch_ex(32, ph[4:], None, z=out[4:], stream=stream)
+        ctx.set_tuning(stream=2)                                              # the stream kernel whenever it can run ...
+        launches(want)
+        assert ctx.last_kernel().startswith("slx_stream_kernel<3>")          # ... which a plain 32-set launch can
+        ctx.synchronize()
+        ref = oracle.pipeline(spec, ph[0].cpu().numpy(), None, want=("z",))["z"]
+        assert np.array_equal(want[0].cpu().numpy(), ref, equal_nan=True)
+        s = torch.cuda.Stream()
+        ctx.decode_batch_ex(1, ph[0:1], None, z=z[0:1])                       # in flight on the context's stream ...
+        g = torch.cuda.CUDAGraph()
+        with pytest.raises(api.SlxError) as e:                                # ... so a capture may not begin
+            with torch.cuda.graph(g, stream=s):
+                ctx.decode_batch_ex(1, ph[0:1], None, z=z[0:1], stream=s.cuda_stream)
+        assert e.value.code == api.ERR_INVALID_ARG
+        ctx.synchronize()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            launches(z, stream=s.cuda_stream)
+        for rep in range(3):
+            z.fill_(-1.0)
+            if rep:
+                ph.copy_(ph.flip(0))                                          # the graph reads the buffers as they are at replay
+                torch.cuda.synchronize()                                      # (torch's stream: the context's own does not wait for it)
+                launches(want)
+                ctx.synchronize()
+            torch.cuda.synchronize()
+            g.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(z, want), rep
+        launches(z)                                                           # plain launches again after the graph
+        ctx.synchronize()
+        assert torch.equal(z, want)
+
+
 def test_point_cloud_text_formatted_on_the_device(api, oracle, synth, torch_cuda, tmp_path):
     """slx_format_points_text / slx_get_point_cloud_text (csrc/slx_text.hip): the text of CCalculation::Result (R/CCalculation.cpp:351-353,
     `file << x << ' ' << y << ' ' << z << endl`) formatted on the device must be the bytes of the host writer (slx_write_point_cloud_text)

@@ -71,5 +71,5 @@ with api.Context(spec) as ctx:
         out["graph_error"] = "%s: %s" % (type(e).__name__, str(e)[:300])
 for k in list(out):
     if k.endswith("_us"):
-        out[k.replace("_us", "_frac_of_hbm_peak")] = bytes_per / out[k] / 1e6 / 8e6
+        out[k.replace("_us", "_frac_of_hbm_peak")] = bytes_per / (out[k] * 1e-6) / 8e12
 print(json.dumps(out))
