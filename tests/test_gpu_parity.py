@@ -1115,6 +1115,7 @@ def test_dynamic_frames(api, oracle, synth, shape, window):
         assert e.value.code == api.ERR_UNAVAILABLE
 
 
+@pytest.mark.filterwarnings("ignore:The CUDA Graph is empty")       # (the capture this test expects to be refused)
 def test_decodes_captured_into_a_hip_graph(api, oracle, synth, torch_cuda):
     """slx_decode_batch_ex on a caller's stream inside a stream capture (include/slx.h, "hipGraphs"): four single-frame-set launches and a
     32-set batch (the planner's stream kernel must stay out of a graph: its queue counters advance from launch to launch) become one
