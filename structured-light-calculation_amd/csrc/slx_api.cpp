@@ -851,6 +851,8 @@ int slx_format_points_text(slx_ctx *ctx, const double *xyz_dev, size_t n_points,
     if (int rc = order_after_done(ctx, ctx->stream)) return rc;       // the points may come from a launch on a caller's stream
     unsigned long long *total_dev = (unsigned long long *)(ctx->d_text_sums + ((ctx->d_text_sums_capacity + 1) & ~(size_t)1));
     if (++ctx->text_tag == 0) ctx->text_tag = 1;                       // (the flag word starts as 0 and keeps the last raised tag)
+    // (The emit kernel storing straight into pinned host memory instead -- no device text, no copy, one wait fewer -- was measured: 1.38 ms
+    // against 1.18 ms per 56 MB text; the kernel's stores cross PCIe slower than the copy engine.)
     const int e = slx_launch_text(xyz_dev, n_points, ctx->d_text_sums, (unsigned *)&ctx->h_text_info[1], ctx->text_tag, ctx->d_text, total_dev,
                                   &ctx->h_text_info[0], ctx->stream);
     if (e != 0) return hip_fail(ctx, (hipError_t)e, "point-cloud text launch");

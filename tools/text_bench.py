@@ -13,7 +13,10 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--config", default="C4")
 ap.add_argument("--reps", type=int, default=8)
 ap.add_argument("--dir", default="/tmp")
+ap.add_argument("--lib", default="", help="another build of libslx.so")
 a = ap.parse_args()
+if a.lib:
+    api.LIB_PATH = os.path.join(ROOT, a.lib)
 spec = synth.make_spec(a.config)
 ph, gr, _ = synth.render(spec, "sphere", seed=9, noise_sigma=1.0)
 L = api.lib()
