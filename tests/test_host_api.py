@@ -108,6 +108,11 @@ def test_null_arguments(api):
     assert L.slx_set_frame(None, 0, 0, None, 0, 0) == api.ERR_INVALID_ARG
     L.slx_destroy(None)                                  # no-op, must not crash
     assert isinstance(L.slx_last_error(None), bytes)
+    import ctypes as C
+    p, n, m = C.c_void_p(), C.c_size_t(7), C.c_size_t(7)
+    assert L.slx_get_point_cloud_text(None, C.byref(p), C.byref(n), C.byref(m)) == api.ERR_INVALID_ARG
+    assert L.slx_format_points_text(None, None, 0, C.byref(p), C.byref(n)) == api.ERR_INVALID_ARG
+    assert L.slx_get_point_cloud_view(None, C.byref(p), C.byref(n)) == api.ERR_INVALID_ARG
 
 
 def test_create_fails_loudly_without_gpu(api, synth):
