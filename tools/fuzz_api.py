@@ -134,8 +134,20 @@ def one_case(seed):
                 if bogus and rng.random() < 0.3:
                     expect_error(lambda: ctx.get_output(bogus[0]), "a plane that was not enabled (%s)" % bogus[0])
             elif op == 6 and cur is not None:
-                same("point cloud", ctx.get_point_cloud() if rng.random() < 0.5 else np.array(ctx.get_point_cloud_view()), O.point_cloud(spec, cur["z"]))
+                want_cloud = O.point_cloud(spec, cur["z"])
+                same("point cloud", ctx.get_point_cloud() if rng.random() < 0.5 else np.array(ctx.get_point_cloud_view()), want_cloud)
                 say("cloud")
+                if rng.random() < 0.4:                               # ... and its text, formatted on the device (round 5)
+                    mag = np.abs(want_cloud)
+                    in_range = bool(np.all(np.isfinite(want_cloud)) and np.all((mag == 0) | ((mag >= 1e-5) & (mag < 1e15))))
+                    try:
+                        text, n_pts = ctx.get_point_cloud_text()
+                        if not in_range or n_pts != len(want_cloud) or text != ("".join("%g %g %g\n" % tuple(q) for q in want_cloud)).encode():
+                            raise Mismatch("the point cloud's text differs")
+                    except api.SlxError as e:
+                        if in_range or e.code != api.ERR_UNAVAILABLE:
+                            raise Mismatch("the point cloud's text: %s" % str(e)[:80])
+                    say("text")
             elif op == 7:                                            # a batch decode into the caller's buffers, context planes untouched
                 n = int(rng.integers(1, 4))
                 bph = rng.integers(0, 256, size=(n, n_phase, h, w), dtype=np.uint8) if n_phase else None
