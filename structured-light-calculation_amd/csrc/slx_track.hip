@@ -238,8 +238,8 @@ __global__ __launch_bounds__(kTile) void slx_track_fused_kernel(const uint8_t *c
     // Placement only affects speed; any order gives the same result.
     unsigned tile = blockIdx.x;
     {
-        const unsigned nb = gridDim.x, q = nb >> 3, r = nb & 7u, x = tile & 7u, within = tile >> 3;
-        tile = x * q + (x < r ? x : r) + within;
+        const unsigned nb = gridDim.x, q = nb >> 3, r = nb & 7u, xcd = tile & 7u, within = tile >> 3;
+        tile = xcd * q + (xcd < r ? xcd : r) + within;
     }
     const int tile_x = (int)(tile % tiles_x), tile_y = (int)(tile / tiles_x);
     const int c0 = tile_x * OUT, c = c0 - 1 + tx;                    // image column of this lane; lanes 0 and kTile - 1 are the blur's halo columns
