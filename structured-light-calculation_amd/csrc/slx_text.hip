@@ -209,7 +209,7 @@ __global__ __launch_bounds__(kThreads) void slx_text_emit_kernel(const double *_
                                                                 unsigned char *__restrict__ text, unsigned long long *__restrict__ total_dev,
                                                                 unsigned long long *__restrict__ total_host)
 {
-    __shared__ __attribute__((aligned(16))) unsigned char buf[SLX_TEXT_POINTS_PER_WG * SLX_TEXT_LINE_MAX + 16];
+    __shared__ __attribute__((aligned(16))) unsigned char buf[SLX_TEXT_POINTS_PER_WG * SLX_TEXT_LINE_MAX + 128 + 16];
     __shared__ unsigned long long scratch[kThreads / 64u];
     __shared__ unsigned wave_len[kThreads / 64u];
     __shared__ unsigned digested[kPerLane * 3][kThreads];
@@ -273,8 +273,9 @@ __global__ __launch_bounds__(kThreads) void slx_text_emit_kernel(const double *_
         start += k < wave ? wave_len[k] : 0u;
         mine += wave_len[k];
     }
-    // characters into LDS: the buffer starts `mis` bytes in, so that its dwords are the aligned dwords of the text
-    const unsigned mis = (unsigned)(before & 3ull);
+    // characters into LDS: the buffer starts `mis` bytes in, so that its dwords are the aligned dwords of the text and a wave's 64 dwords
+    // of the copy below one aligned 256-byte piece of it (with mis = before & 3 the stores straddled lines: 64.1 MB written for 56.1 MB)
+    const unsigned mis = (unsigned)(before & 127ull);
 #pragma unroll 1
     for (unsigned j = 0, o = 0; j < kPerLane * 3u; j++) {
         const unsigned i = j / 3u, c = j - 3u * i;
