@@ -496,6 +496,8 @@ def parse_args(argv=None):
                     help="how ranks split the batch in the decode-only region (kernel_only, roofline): a row tile of every frame-set "
                          "(north_star's wording; the default for N > 1) or whole frame-sets; the per-GPU bytes are the same.  "
                          "The N > 1 headline is always the row-tile split with its gather; with_gather reports both splits")
+    ap.add_argument("--no-oracle-check", action="store_true",
+                    help="N > 1: skip the comparison of gathered depth maps with the oracle on rank 0 (parity_vs_oracle stays null)")
     ap.add_argument("--gather-chunk", type=int, default=8, help="frame-sets per pipelined decode+gather chunk")
     ap.add_argument("--gather-timeout", type=float, default=240.0,
                     help="N > 1: seconds the whole with_gather phase may take before the line is printed without it (a stuck collective must not cost the decode-only result)")
@@ -696,6 +698,19 @@ def run_rank(args):
                             else torch.empty((16, c4["height"], c4["width"]), dtype=torch.float64, device=device)) for name in ("z", "x", "y", "U", "k")}
     t0 = time.perf_counter()
     phase_full, gray_full = make_batch(torch, synth, full_spec, args.sets_per_gpu, device, seed=0x5EED + 4 + rank)
+    if world > 1:
+        # N > 1: every rank works on RANK 0's frame-sets (a row tile of each, or its share of them), so that rank 0 holds the whole input
+        # of every gathered depth map and can check gathered maps against the oracle (parity_vs_oracle below) -- not only against what
+        # the ranks themselves decoded.  Outside every timing.
+        for tns in (phase_full, gray_full):
+            if tns is not None and tns.numel():
+                if backend == "nccl":
+                    dist.broadcast(tns, src=0)
+                else:
+                    host = tns.cpu()
+                    dist.broadcast(host, src=0)
+                    tns.copy_(host)
+        torch.cuda.synchronize()
     if full_spec["mode"] in (synth.MODE_PHASE_ONLY, synth.MODE_GRAY_ONLY) and (world > 1 or not args.no_cpu_baseline):
         raise SystemExit("bench: --config %s (a decoder object alone) is a profiling workload: N = 1 with --no-cpu-baseline" % args.config)
     if spec is full_spec:
@@ -865,6 +880,7 @@ def run_rank(args):
     headline_shape = [None]         # ... and which shape that was
     stuck_at = [None]               # set by the watchdog: where the collective phase hung
     gather_ok = True
+    gather_parity = [None]          # N > 1: gathered maps against the oracle (rank 0): True / False, None when not checked
     if (world > 1 or solo_gather) and not args.no_gather:
         import threading
         gather = {}
@@ -908,6 +924,16 @@ def run_rank(args):
             comm = None
             gather["error"] = "communicator: %s: %s" % (type(e).__name__, e)
         total = world * args.sets_per_gpu
+        # The oracle beside the gathered maps (rank 0, outside every timing): frame-set 0 -- all of its rows, i.e. every rank's tile --
+        # and one frame-set of the LAST chunk of every measurement's gathered array against O.pipeline on the full frame.  Every rank
+        # decodes rank 0's frame-sets (broadcast above), gathered set s is input set s % sets_per_gpu.
+        O_gather = None
+        oracle_checks = []
+        if rank == 0 and not args.no_oracle_check:
+            try:
+                O_gather = load_oracle()
+            except Exception as e:
+                oracle_checks.append({"error": "oracle: %s: %s" % (type(e).__name__, e)})
         # Three measurements through one communicator:
         #   rows          north_star's split, the IN-PLACE gather shape: one message per (peer, frame-set) landing at its rows
         #   rows_staged   the same split, the STAGED shape: one message per (peer, chunk) into a staging slot of the root + a row-scatter
@@ -1025,6 +1051,20 @@ def run_rank(args):
                         if ok and n and rows:
                             part = got_full[s0:s0 + n, r0:r0 + rows].contiguous().view(torch.int64).sum()
                             ok = ok and int(part) == int(sums[r])
+                # ... and against the ORACLE: a tile decoded wrongly on one rank and gathered faithfully passes the sums above, not this
+                oracle_ok, ok_local = None, ok
+                if rank == 0 and O_gather is not None and ok:
+                    progress.update(phase="oracle", step=None)
+                    picks = sorted({0, total - 1 - ((total - 1) % max(1, args.gather_chunk)) // 2})   # set 0, and one of the last chunk
+                    oracle_ok = True
+                    for sset in picks:
+                        src_set = sset % args.sets_per_gpu
+                        ref = O_gather.pipeline(full_spec, phase_full[src_set].cpu().numpy(), None if gray_full is None else gray_full[src_set].cpu().numpy(),
+                                                want=("z",), threads=min(usable_cpus(), 16))["z"]
+                        same = bool(np.array_equal(got_full[sset].cpu().numpy(), ref, equal_nan=True))
+                        oracle_checks.append({"measurement": key, "gathered_set": int(sset), "equal": same})
+                        oracle_ok = oracle_ok and same
+                    ok = ok and oracle_ok
                 if split == "rows" and ok is not False:
                     row_times[key] = (tg_max, shape)
                     if headline is None or tg_max < headline:      # (a gather that delivers other bytes than the ranks decoded is a failure, not a number)
@@ -1065,7 +1105,7 @@ def run_rank(args):
                        "gathered_shape": [total, full_h, W], "messages_at_root_per_step": n_msgs_root,
                        "bytes_per_message": (into_root // n_msgs_root) if n_msgs_root else None,
                        "root_staging_bytes": 2 * staging_bytes if staging_bytes else 0,
-                       "gathered_equals_local_decodes": ok}
+                       "gathered_equals_local_decodes": ok_local, "gathered_equals_oracle": oracle_ok}
             except Exception as e:      # the decode-only measurement above must still be reported
                 res = {"split": split, "gather_shape": shape, "error": "%s: %s" % (type(e).__name__, e)}
                 # the in-place row split is the library's default gather and the measurement `value` stands on: its failure fails the run
@@ -1080,10 +1120,13 @@ def run_rank(args):
                         except Exception:
                             pass
                     gctx.close()
-            if res.get("gathered_equals_local_decodes") is False:
+            if res.get("gathered_equals_local_decodes") is False or res.get("gathered_equals_oracle") is False:
                 gather_ok = False
             gather[key] = res
         gather["value_is"] = ("rows_staged" if headline_shape[0] == "staged" else "rows") if headline is not None else None
+        gather["oracle_checks"] = oracle_checks
+        if rank == 0 and oracle_checks:
+            gather_parity[0] = all(c.get("equal") is True for c in oracle_checks)
         if comm is not None:
             try:
                 comm.close()
@@ -1165,6 +1208,16 @@ def run_rank(args):
                         blocks = sorted(timed(ostep, n_launch, on=own_stream(octx))[1] for _ in range(5))
                         oms = blocks[2]
                         okernel = octx.last_kernel()
+                        # the card's power management under THIS workload (is the launch at the cap, or waiting for memory?): batch
+                        # launches only, after the entry's timed blocks
+                        opower = None
+                        if sets > 1 and not args.no_power_probe:
+                            try:
+                                opower = power_window(ostep, torch.cuda.synchronize, dev_index, seconds=1.0)
+                                if opower:
+                                    opower["source"] = "rocm-smi while this entry's launch runs back to back, after its timed blocks"
+                            except Exception as e:
+                                opower = {"error": "%s: %s" % (type(e).__name__, e)}
                     obytes = sets * oH * oW * (synth.algorithmic_bytes_per_pixel(ospec) + aux_bpp)
                     # HBM traffic: this run's counter passes; when the probe was skipped or failed, the committed capture (labelled as such)
                     otraffic, osource = (None, "not measured") if aux or sets == 1 else traffic_entry(name, sets)
@@ -1180,6 +1233,8 @@ def run_rank(args):
                                                  "frac": obytes / (oms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "traffic": otraffic, "traffic_source": osource,
                                                  "kernel": okernel, "algorithmic_bytes_per_launch": obytes},
                                     "parity_vs_oracle": ok}
+                    if opower is not None:
+                        other[label]["power"] = opower
                     if sets == 1:
                         other[label]["note"] = ("ONE frame-set per launch, back-to-back launches rotating over %d distinct frame-sets and depth maps (%.0f MB: beyond the "
                                                 "256 MiB Infinity Cache, every launch reads HBM); launch_ms includes the gap between two launches"
@@ -1191,6 +1246,8 @@ def run_rank(args):
         around = None
         if world == 1 and not args.no_other_configs:
             around = around_the_path(torch, np, api, synth, O, dev_index, device)
+        if parity is None and gather_parity[0] is not None:
+            parity = gather_parity[0]                                # N > 1: the gathered maps against the oracle
         result = make_result(gather, cpu_single, cpu_multi, parity, other, headline=headline)
         if around is not None:
             result["around_the_path"] = around
@@ -1206,8 +1263,8 @@ def run_rank(args):
         dist.destroy_process_group()
         bye.cancel()
     if (world > 1 or solo_gather) and not args.no_gather and not (gather_ok and headline is not None):
-        # the line is out with value null: the gather failed or delivered other bytes than the ranks decoded
-        log("[bench] rank %d: a gathered measurement failed or delivered other bytes than the ranks decoded (see with_gather in the line)" % rank)
+        # the line is out with value null: the gather failed, delivered other bytes than the ranks decoded, or a gathered map differs from the oracle
+        log("[bench] rank %d: a gathered measurement failed, delivered other bytes than the ranks decoded, or differs from the oracle (see with_gather in the line)" % rank)
         sys.exit(6)
 
 

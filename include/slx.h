@@ -214,12 +214,25 @@ int slx_get_point_cloud(slx_ctx *ctx, double *xyz, size_t capacity_points, size_
  * valid until the next point-cloud call on this context (or its destruction); the caller only reads it.  What
  * slx::CCalculation::Result formats its text file from. */
 int slx_get_point_cloud_view(slx_ctx *ctx, const double **xyz, size_t *n_points);
-/* The same cloud as the TEXT CCalculation::Result writes (R/CCalculation.cpp:323-357): "x y z\n" per point, every number as
+/* The same cloud as the TEXT CCalculation::Result writes (R/CCalculation.cpp:323-357): "x y z" and a line end per point, every number as
  * `ostream << double` prints it (%g, 6 significant digits) -- formatted ON THE DEVICE (formatting is the cost of that function: 8-10 ms
- * per 1.3 M points on 16 host threads), byte for byte what slx_write_point_cloud_text writes; only the text crosses PCIe.  *text: pinned
- * host memory the context owns, *n_bytes long (not NUL-terminated), valid until the next point-cloud call on this context; write it to
- * the file as it is.  SLX_ERR_UNAVAILABLE when a coordinate lies outside the device formatter's range (0 < |v| < 1e-5, |v| >= 1e15, NaN,
- * infinity): take slx_get_point_cloud_view + slx_write_point_cloud_text for that frame (slx::CCalculation::Result does). */
+ * per 1.3 M points on 16 host threads), byte for byte what slx_write_point_cloud_text(_ex) writes in the same dialect; only the text
+ * crosses PCIe.  *text: pinned host memory the context owns, *n_bytes long (not NUL-terminated), valid until the next point-cloud call on
+ * this context; write it to the file as it is (a BINARY-mode stream: the line ends are already in it).
+ * SLX_ERR_UNAVAILABLE when a coordinate lies outside the device formatter's range (0 < |v| < 1e-5, |v| >= 1e15, NaN,
+ * infinity): take slx_get_point_cloud_view + slx_write_point_cloud_text_ex for that frame (slx::CCalculation::Result does).
+ *
+ * WHICH bytes "ostream << double" means depends on the C++ runtime the reference is built with, and this library offers both:
+ *   SLX_TEXT_LIBSTDCXX (default)  what that loop writes when compiled on Linux (libstdc++ over glibc's printf): two exponent digits
+ *                                 ("5e-05"), '\n'.
+ *   SLX_TEXT_MSVC2013             what the reference AS BUILT writes -- DynaFrame.vcxproj targets the MSVC 2013 runtime and opens the file
+ *                                 in text mode: at least three exponent digits ("5e-005") and CR LF line ends.  Numbers in exponent
+ *                                 notation do occur in a cloud (x of the columns next to cx).  The non-finite spellings of that runtime
+ *                                 ("1.#INF", "-1.#IND", "1.#QNAN") come from the host formatter only.
+ * Neither dialect is pinned by an output file of the reference (it ships none): both restate the documented behaviour of the runtimes. */
+enum slx_text_dialect { SLX_TEXT_LIBSTDCXX = 0, SLX_TEXT_MSVC2013 = 1 };
+/* The dialect of slx_get_point_cloud_text / slx_format_points_text on this context (default SLX_TEXT_LIBSTDCXX). */
+int slx_set_text_dialect(slx_ctx *ctx, int dialect);
 int slx_get_point_cloud_text(slx_ctx *ctx, const char **text, size_t *n_bytes, size_t *n_points);
 /* The text of any n_points packed (x, y, z) triples in DEVICE memory (a cloud slx_point_cloud_of_depth left there), same contract. */
 int slx_format_points_text(slx_ctx *ctx, const double *xyz_dev, size_t n_points, const char **text, size_t *n_bytes);
@@ -299,14 +312,17 @@ enum slx_tuning_key {
     SLX_TUNE_PLAIN_ORDER = 6,  /* 1: Gray-mask work items in plain order instead of XCD-grouped         */
     SLX_TUNE_TIERS = 7,        /* tiers of ever shorter work items towards the end of a launch, 1..4    */
     SLX_TUNE_WEAVE = 8,        /* rows woven into one row group (a lane's rows are that far apart), 1..64 */
-    SLX_TUNE_STREAM = 9,       /* stream kernel (resident waves, short items from queues): 0 automatic, 1 never, 2 whenever possible */
-    SLX_TUNE_STREAM_ROWS = 10, /* its rows per work item, 2..16                                          */
+    SLX_TUNE_STREAM = 9,       /* stream kernels (resident waves, short items from queues): 0 automatic, 1 never, 2 whenever possible */
+    SLX_TUNE_STREAM_ROWS = 10, /* their rows per work item, 2..16 (1..16 for the reference's own mode)   */
     SLX_TUNE_CLOUD_PASSES = 11,/* point cloud: 0 automatic, 1 the single fused launch (SLX_ERR_UNAVAILABLE where its plan refuses), 2 the count + write launches */
-    SLX_TUNE_COUNT = 12
+    SLX_TUNE_CLOUD_SPIN = 12,  /* fused point cloud: rounds of polls a look-back wait may last before the workgroup gives up and the frame is
+                                  repeated on the count + write launches, + 1 (1 = a single poll: tests force the fallback with it)     */
+    SLX_TUNE_COUNT = 13
 };
 int slx_set_tuning(slx_ctx *ctx, int key, int value);
 /* Which kernel the context's last decode launch was -- the instantiation, spelled as rocprofv3's kernel trace prints it -- and how
- * its work was cut: "slx_stream_kernel<3>: resident waves, 2-row items from queues", "slx_strip_kernel<3, 3, 0, 4, false>: 16-row
+ * its work was cut: "slx_stream_kernel<3>: resident waves, 2-row items from queues", "slx_gstream_kernel: resident waves, 1-row items from queues"
+ * (the reference's own mode), "slx_strip_kernel<3, 3, 0, 4, false>: 16-row
  * items, 8 rows per row group" (<mode, frequencies, Gray bits on the DMA ring, steps, optional planes>), "slx_decoder_strip_kernel<0>:
  * 3-row items, 2 rows per row group", "slx_fused_kernel<3, 3, true, true>" (<mode, frequencies, 4 steps, optional planes>).  For bench
  * lines, profiles, and tests that must know a launch did not silently take another kernel. */
@@ -420,10 +436,13 @@ int slx_read_bmp_gray(const char *path, uint8_t *pixels, size_t capacity, int *r
 /* Same contract for a binary PGM (P5, maxval <= 255), the other 8-bit format cv::imread takes. */
 int slx_read_pgm_gray(const char *path, uint8_t *pixels, size_t capacity, int *rows, int *cols);
 /* The point-cloud text file of CCalculation::Result (R/CCalculation.cpp:323-357): "x y z\n" per point, every number as
- * `ostream << double` prints it (%g, 6 significant digits) -- the same bytes as that loop, formatted by several threads and
+ * `ostream << double` prints it (%g, 6 significant digits) -- the same bytes as that loop compiled with libstdc++ (SLX_TEXT_LIBSTDCXX;
+ * the MSVC build's bytes: slx_write_point_cloud_text_ex), formatted by several threads and
  * written without its flush per line (2.27 M points: 0.06 s instead of 3.6 s).  xyz: host memory, 3 doubles per point, the
  * layout slx_get_point_cloud fills.  SLX_ERR_UNAVAILABLE: the file cannot be written. */
 int slx_write_point_cloud_text(const char *path, const double *xyz, size_t n_points);
+/* The same file in either dialect (enum slx_text_dialect above; SLX_ERR_INVALID_ARG for another value). */
+int slx_write_point_cloud_text_ex(const char *path, const double *xyz, size_t n_points, int dialect);
 /* CamMat, ProMat, R, T of the cv::FileStorage YAML Init reads (R/CCalculation.cpp:124-132; format of R/Result.yml). */
 int slx_read_calibration_yaml(const char *path, double cam[9], double pro[9], double rot[9], double trans[3]);
 

@@ -30,7 +30,7 @@ SYMBOLS = [
     "slx_validate_config", "slx_create", "slx_destroy", "slx_last_error", "slx_set_gray_lut",
     "slx_set_frame", "slx_decode", "slx_decode_batch", "slx_synchronize", "slx_get_stream", "slx_get_output",
     "slx_get_depth", "slx_get_point_cloud", "slx_point_cloud_of_depth", "slx_track_begin", "slx_track_next", "slx_track_image_buffer", "slx_track_next_batch", "slx_track_stage_frames", "slx_track_frames_buffer", "slx_output_device_ptr", "slx_get_calibration", "slx_enable_timing",
-    "slx_last_decode_ms", "slx_debug_stamps", "slx_set_variant", "slx_set_tuning", "slx_last_kernel", "slx_read_bmp_gray", "slx_read_pgm_gray", "slx_read_calibration_yaml", "slx_write_point_cloud_text", "slx_get_point_cloud_view", "slx_get_point_cloud_text", "slx_format_points_text", "slx_version",
+    "slx_last_decode_ms", "slx_debug_stamps", "slx_set_variant", "slx_set_tuning", "slx_last_kernel", "slx_read_bmp_gray", "slx_read_pgm_gray", "slx_read_calibration_yaml", "slx_write_point_cloud_text", "slx_write_point_cloud_text_ex", "slx_set_text_dialect", "slx_get_point_cloud_view", "slx_get_point_cloud_text", "slx_format_points_text", "slx_version",
     "slx_decode_batch_ex", "slx_comm_unique_id", "slx_comm_create", "slx_comm_adopt", "slx_comm_destroy", "slx_comm_info", "slx_comm_last_error",
     "slx_comm_synchronize", "slx_gather_depth", "slx_decode_gather", "slx_gather_plan", "slx_gather_plan_ex", "slx_comm_set_gather_shape", "slx_scatter_rows", "slx_reference_defaults",
     "slx_pipe_create", "slx_pipe_destroy", "slx_pipe_layout", "slx_pipe_acquire", "slx_pipe_submit", "slx_pipe_collect", "slx_pipe_last_error",
@@ -156,6 +156,8 @@ def lib():
         L.slx_read_pgm_gray.argtypes = [C.c_char_p, vp, sz, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.slx_read_calibration_yaml.argtypes = [C.c_char_p] + [C.POINTER(C.c_double)] * 4
         L.slx_write_point_cloud_text.argtypes = [C.c_char_p, vp, sz]
+        L.slx_write_point_cloud_text_ex.argtypes = [C.c_char_p, vp, sz, C.c_int]
+        L.slx_set_text_dialect.argtypes = [vp, C.c_int]
         L.slx_pipe_create.argtypes = [vp, C.POINTER(SlxPipeConfig), C.POINTER(vp)]
         L.slx_pipe_destroy.argtypes = [vp]
         L.slx_pipe_destroy.restype = None
@@ -358,6 +360,10 @@ class Context:
         self._check(lib().slx_get_point_cloud_text(self._h, C.byref(p), C.byref(nb), C.byref(npts)))
         return (C.string_at(p.value, nb.value) if nb.value else b""), npts.value
 
+    def set_text_dialect(self, dialect):
+        """TEXT_LIBSTDCXX or TEXT_MSVC2013 for get_point_cloud_text / format_points_text (slx_set_text_dialect)."""
+        self._check(lib().slx_set_text_dialect(self._h, int(dialect)))
+
     def format_points_text(self, xyz):
         """Text of packed (x, y, z) triples in device memory (a CUDA f64 tensor [n, 3]), formatted on the device: bytes."""
         assert xyz.is_cuda and xyz.is_contiguous() and xyz.element_size() == 8 and xyz.numel() % 3 == 0
@@ -510,7 +516,7 @@ class Context:
 
 
 VARIANT_AUTO, VARIANT_GENERIC, VARIANT_STRIP, VARIANT_GENERIC_FAST = range(4)
-TUNE_KEYS = {"strip_rows": 0, "tail_pct": 1, "tail_rows": 2, "gray_plain": 3, "strip_waves": 4, "lds_pad_kib": 5, "plain_order": 6, "tiers": 7, "weave": 8, "stream": 9, "stream_rows": 10, "cloud_passes": 11}
+TUNE_KEYS = {"strip_rows": 0, "tail_pct": 1, "tail_rows": 2, "gray_plain": 3, "strip_waves": 4, "lds_pad_kib": 5, "plain_order": 6, "tiers": 7, "weave": 8, "stream": 9, "stream_rows": 10, "cloud_passes": 11, "cloud_spin": 12}
 
 
 class Pipe:
@@ -727,13 +733,17 @@ def read_pgm_gray(path):
     return _read_gray_file(lib().slx_read_pgm_gray, path)
 
 
-def write_point_cloud_text(path, xyz):
+TEXT_LIBSTDCXX, TEXT_MSVC2013 = 0, 1      # enum slx_text_dialect
+
+
+def write_point_cloud_text(path, xyz, dialect=TEXT_LIBSTDCXX):
     """The text file CCalculation::Result writes (R/CCalculation.cpp:323-357): "x y z" per line, numbers as `ostream << double`
-    prints them.  xyz: float64 [n, 3] (what Context.point_cloud returns)."""
+    prints them.  xyz: float64 [n, 3] (what Context.point_cloud returns).  dialect: TEXT_LIBSTDCXX ("5e-05", LF) or TEXT_MSVC2013
+    (the reference as built: "5e-005", CR LF)."""
     a = np.ascontiguousarray(xyz, dtype=np.float64)
     if a.ndim != 2 or a.shape[1] != 3:
         raise ValueError("xyz must be [n, 3]")
-    rc = lib().slx_write_point_cloud_text(os.fsencode(path), a.ctypes.data if a.size else None, a.shape[0])
+    rc = lib().slx_write_point_cloud_text_ex(os.fsencode(path), a.ctypes.data if a.size else None, a.shape[0], int(dialect))
     if rc != OK:
         raise SlxError(rc, "cannot write %s" % path)
 

@@ -5,6 +5,8 @@
 #include <cstring>
 #include <fstream>
 
+#include <sys/stat.h>
+
 namespace slx {
 
 namespace {
@@ -47,6 +49,8 @@ std::vector<double> fetch(slx_ctx *ctx, int which, size_t n, std::string &err)
 
 bool ReadGrayCodeFile(const std::string &path, int grayCodeSize, std::vector<int16_t> &lut)
 {
+    struct stat st;
+    if (stat(path.c_str(), &st) != 0 || !S_ISREG(st.st_mode)) return false;   // (an ifstream "opens" a directory on Linux; the reference's open fails on one)
     std::ifstream codeFile(path.c_str(), std::ios::in);
     if (!codeFile) return false;
     lut.assign((size_t)grayCodeSize, 0);

@@ -10,8 +10,11 @@
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <new>
 #include <sstream>
 #include <thread>
+
+#include <sys/stat.h>
 
 namespace slx {
 
@@ -26,26 +29,38 @@ inline uint8_t luma(unsigned b, unsigned g, unsigned r) { return (uint8_t)((b * 
 }  // namespace
 
 // The whole file in one read (a stream iterator takes it byte by byte: 1.5 ms of the 2 ms a 1.3 MB image took to load).
+// Only regular files (fopen succeeds on a directory and ftell then answers LONG_MAX), and never more than kMaxFileBytes: an image
+// or a calibration file of a data directory is a few megabytes, a size beyond 1 GiB is a mistake or a forgery.
+static constexpr size_t kMaxFileBytes = (size_t)1 << 30;
 static bool read_file(const std::string &path, std::vector<unsigned char> &buf)
 {
     std::FILE *fp = std::fopen(path.c_str(), "rb");
     if (!fp) return false;
     buf.clear();
-    bool ok = true;
-    if (std::fseek(fp, 0, SEEK_END) == 0) {
-        const long n = std::ftell(fp);
-        std::rewind(fp);
-        if (n > 0) {
-            buf.resize((size_t)n);
-            buf.resize(std::fread(buf.data(), 1, (size_t)n, fp));
-        }
-    } else {                                                         // not seekable: in pieces
-        unsigned char piece[65536];
-        size_t got;
-        while ((got = std::fread(piece, 1, sizeof piece, fp)) > 0) buf.insert(buf.end(), piece, piece + got);
+    struct stat st;
+    if (fstat(fileno(fp), &st) != 0 || !S_ISREG(st.st_mode) || st.st_size < 0 || (unsigned long long)st.st_size > kMaxFileBytes) {
+        std::fclose(fp);
+        return false;
     }
-    ok = std::ferror(fp) == 0;
+    bool ok = true;
+    try {
+        buf.resize((size_t)st.st_size);
+        const size_t got = buf.empty() ? 0 : std::fread(buf.data(), 1, buf.size(), fp);
+        buf.resize(got);                                             // a file that shrank meanwhile: what was there
+        if (got == (size_t)st.st_size) {                             // ... or grew (or reports size 0, like /proc files): the rest in pieces
+            unsigned char piece[4096];
+            size_t more;
+            while (ok && (more = std::fread(piece, 1, sizeof piece, fp)) > 0) {
+                if (buf.size() + more > kMaxFileBytes) ok = false;
+                else buf.insert(buf.end(), piece, piece + more);
+            }
+        }
+    } catch (const std::bad_alloc &) {
+        ok = false;
+    }
+    ok = ok && std::ferror(fp) == 0;
     std::fclose(fp);
+    if (!ok) buf.clear();
     return ok;
 }
 
@@ -105,11 +120,9 @@ bool ReadBmpGray(const std::string &path, std::vector<uint8_t> &pixels, int &row
 
 bool ReadCalibrationYaml(const std::string &path, Calibration &calib)
 {
-    std::ifstream f(path.c_str());
-    if (!f) return false;
-    std::stringstream ss;
-    ss << f.rdbuf();
-    const std::string text = ss.str();
+    std::vector<unsigned char> raw;
+    if (!read_file(path, raw)) return false;                         // (a regular file of bounded size, like the images)
+    const std::string text(raw.begin(), raw.end());
     struct Want { const char *key; double *dst; int n; } wants[] = {
         {"CamMat", calib.CamMat, 9}, {"ProMat", calib.ProMat, 9}, {"R", calib.R, 9}, {"T", calib.T, 3}};
     for (const Want &w : wants) {
@@ -326,7 +339,7 @@ bool ReadPgmGray(const std::string &path, std::vector<uint8_t> &pixels, int &row
 namespace {
 
 constexpr size_t kNumberChars = 24;        // "-1.23457e-308" is 13; a non-finite value printed by snprintf stays far below this too
-constexpr size_t kLineChars = 3 * kNumberChars + 3;
+constexpr size_t kLineChars = 3 * kNumberChars + 4;
 
 // One double as printf("%.6g") / `ostream << double` prints it, for the magnitudes a point cloud holds (1e-5 <= |v| < 1e15, and
 // zero), by exact integer arithmetic: the six significant digits are round-half-even of the EXACT binary value scaled by a power
@@ -346,7 +359,7 @@ struct Digits3 {
 };
 static constexpr Digits3 kDigits3{};
 
-static inline int fmt_g6_fast(double v, char *out)
+static inline int fmt_g6_fast(double v, char *out, bool msvc)
 {
     uint64_t bits;
     std::memcpy(&bits, &v, sizeof bits);
@@ -404,6 +417,7 @@ static inline int fmt_g6_fast(double v, char *out)
         *o++ = 'e';
         int e = X;
         if (e < 0) { *o++ = '-'; e = -e; } else *o++ = '+';
+        if (msvc) *o++ = '0';                                                      // that runtime prints three exponent digits: 5e-005
         *o++ = (char)('0' + e / 10);
         *o++ = (char)('0' + e % 10);
     } else if (X >= 0) {
@@ -417,23 +431,42 @@ static inline int fmt_g6_fast(double v, char *out)
     return (int)(o - out);
 }
 
-// one number as `ostream << double` prints it; returns the end
-char *put_number(char *out, double v)
+// one number as `ostream << double` prints it; returns the end.  msvc: the dialect of the reference AS BUILT (MSVC 2013 runtime): at
+// least three exponent digits, and that runtime's spellings of the non-finite values at precision 6 ("1.#INF", "-1.#IND", "1.#QNAN")
+char *put_number(char *out, double v, bool msvc)
 {
-    if (const int n = fmt_g6_fast(v, out)) return out + n;
-    if (std::isfinite(v)) return std::to_chars(out, out + kNumberChars, v, std::chars_format::general, 6).ptr;
-    return out + std::snprintf(out, kNumberChars, "%g", v);          // nan / inf with their signs: the C library's own spelling
+    if (const int n = fmt_g6_fast(v, out, msvc)) return out + n;
+    if (std::isfinite(v)) {
+        char *end = std::to_chars(out, out + kNumberChars, v, std::chars_format::general, 6).ptr;
+        if (msvc) {
+            char *e = end;
+            while (e > out && e[-1] >= '0' && e[-1] <= '9') e--;     // the digits behind "e+" / "e-", when there is an exponent
+            if (e - out >= 2 && (e[-1] == '+' || e[-1] == '-') && e[-2] == 'e' && end - e == 2) {
+                e[2] = e[1];
+                e[1] = e[0];
+                e[0] = '0';
+                end++;
+            }
+        }
+        return end;
+    }
+    if (!msvc) return out + std::snprintf(out, kNumberChars, "%g", v);   // nan / inf with their signs: the C library's own spelling
+    const char *w = std::isinf(v) ? (v < 0 ? "-1.#INF" : "1.#INF") : (std::signbit(v) ? "-1.#IND" : "1.#QNAN");
+    const size_t n = std::strlen(w);
+    std::memcpy(out, w, n);
+    return out + n;
 }
 
-size_t format_points(const double *xyz, size_t n, char *out)
+size_t format_points(const double *xyz, size_t n, char *out, bool msvc)
 {
     char *o = out;
     for (size_t i = 0; i < n; i++) {
-        o = put_number(o, xyz[3 * i + 0]);
+        o = put_number(o, xyz[3 * i + 0], msvc);
         *o++ = ' ';
-        o = put_number(o, xyz[3 * i + 1]);
+        o = put_number(o, xyz[3 * i + 1], msvc);
         *o++ = ' ';
-        o = put_number(o, xyz[3 * i + 2]);
+        o = put_number(o, xyz[3 * i + 2], msvc);
+        if (msvc) *o++ = '\r';                                       // a text-mode stream of that runtime turns endl into CR LF
         *o++ = '\n';
     }
     return (size_t)(o - out);
@@ -441,10 +474,11 @@ size_t format_points(const double *xyz, size_t n, char *out)
 
 }  // namespace
 
-bool WritePointCloudText(const std::string &path, const double *xyz, size_t n_points)
+bool WritePointCloudText(const std::string &path, const double *xyz, size_t n_points, int dialect)
 {
-    if (n_points && !xyz) return false;
-    std::FILE *f = std::fopen(path.c_str(), "w");
+    if ((n_points && !xyz) || (dialect != SLX_TEXT_LIBSTDCXX && dialect != SLX_TEXT_MSVC2013)) return false;
+    const bool msvc = dialect == SLX_TEXT_MSVC2013;
+    std::FILE *f = std::fopen(path.c_str(), "wb");                  // the bytes as formatted: the CR of the MSVC dialect is written out, never added by a stream
     if (!f) return false;
     // rounds of at most `threads` blocks of 64 Ki points: ~6 MB of text per block, so a 12-million-point cloud never holds more
     // than ~100 MB of it; formatting is ~80 ns per number, the write of a round a few milliseconds
@@ -461,7 +495,7 @@ bool WritePointCloudText(const std::string &path, const double *xyz, size_t n_po
         auto work = [&, cur](size_t t) {
             const size_t a = std::min(n_points, first + t * kBlock), b = std::min(n_points, a + kBlock);
             text[cur][t].resize((b - a) * kLineChars);
-            len[cur][t] = format_points(xyz + 3 * a, b - a, text[cur][t].data());
+            len[cur][t] = format_points(xyz + 3 * a, b - a, text[cur][t].data(), msvc);
         };
         std::vector<std::thread> pool;
         for (size_t t = 1; t < threads; t++) pool.emplace_back(work, t);
@@ -479,53 +513,76 @@ bool WritePointCloudText(const std::string &path, const double *xyz, size_t n_po
 
 }  // namespace slx
 
+// (No exception crosses the C boundary: a reader that runs out of memory on a forged size answers like a missing file.)
+template <class F> static int guarded(F &&f)
+{
+    try {
+        return f();
+    } catch (const std::bad_alloc &) {
+        return SLX_ERR_OUT_OF_MEMORY;
+    } catch (...) {
+        return SLX_ERR_UNAVAILABLE;
+    }
+}
+
 // ---- plain-C access to the file readers (declared in include/slx.h) ----
 extern "C" {
 
 int slx_read_bmp_gray(const char *path, uint8_t *pixels, size_t capacity, int *rows, int *cols)
 {
     if (!path || !rows || !cols) return SLX_ERR_INVALID_ARG;
-    std::vector<uint8_t> px;
-    int r = 0, c = 0;
-    if (!slx::ReadBmpGray(path, px, r, c)) return SLX_ERR_UNAVAILABLE;
-    *rows = r;
-    *cols = c;
-    if (!pixels) return SLX_OK;                                   // size query
-    if (capacity < px.size()) return SLX_ERR_INVALID_ARG;
-    std::memcpy(pixels, px.data(), px.size());
-    return SLX_OK;
+    return guarded([&]() -> int {
+        std::vector<uint8_t> px;
+        int r = 0, c = 0;
+        if (!slx::ReadBmpGray(path, px, r, c)) return SLX_ERR_UNAVAILABLE;
+        *rows = r;
+        *cols = c;
+        if (!pixels) return SLX_OK;                               // size query
+        if (capacity < px.size()) return SLX_ERR_INVALID_ARG;
+        std::memcpy(pixels, px.data(), px.size());
+        return SLX_OK;
+    });
 }
 
 int slx_read_pgm_gray(const char *path, uint8_t *pixels, size_t capacity, int *rows, int *cols)
 {
     if (!path || !rows || !cols) return SLX_ERR_INVALID_ARG;
-    std::vector<uint8_t> px;
-    int r = 0, c = 0;
-    if (!slx::ReadPgmGray(path, px, r, c)) return SLX_ERR_UNAVAILABLE;
-    *rows = r;
-    *cols = c;
-    if (!pixels) return SLX_OK;                                   // size query
-    if (capacity < px.size()) return SLX_ERR_INVALID_ARG;
-    std::memcpy(pixels, px.data(), px.size());
-    return SLX_OK;
+    return guarded([&]() -> int {
+        std::vector<uint8_t> px;
+        int r = 0, c = 0;
+        if (!slx::ReadPgmGray(path, px, r, c)) return SLX_ERR_UNAVAILABLE;
+        *rows = r;
+        *cols = c;
+        if (!pixels) return SLX_OK;                               // size query
+        if (capacity < px.size()) return SLX_ERR_INVALID_ARG;
+        std::memcpy(pixels, px.data(), px.size());
+        return SLX_OK;
+    });
+}
+
+int slx_write_point_cloud_text_ex(const char *path, const double *xyz, size_t n_points, int dialect)
+{
+    if (!path || (n_points && !xyz) || (dialect != SLX_TEXT_LIBSTDCXX && dialect != SLX_TEXT_MSVC2013)) return SLX_ERR_INVALID_ARG;
+    return guarded([&]() -> int { return slx::WritePointCloudText(path, xyz, n_points, dialect) ? SLX_OK : SLX_ERR_UNAVAILABLE; });
 }
 
 int slx_write_point_cloud_text(const char *path, const double *xyz, size_t n_points)
 {
-    if (!path || (n_points && !xyz)) return SLX_ERR_INVALID_ARG;
-    return slx::WritePointCloudText(path, xyz, n_points) ? SLX_OK : SLX_ERR_UNAVAILABLE;
+    return slx_write_point_cloud_text_ex(path, xyz, n_points, SLX_TEXT_LIBSTDCXX);
 }
 
 int slx_read_calibration_yaml(const char *path, double cam[9], double pro[9], double rot[9], double trans[3])
 {
     if (!path || !cam || !pro || !rot || !trans) return SLX_ERR_INVALID_ARG;
-    slx::Calibration c;
-    if (!slx::ReadCalibrationYaml(path, c)) return SLX_ERR_UNAVAILABLE;
-    std::memcpy(cam, c.CamMat, sizeof c.CamMat);
-    std::memcpy(pro, c.ProMat, sizeof c.ProMat);
-    std::memcpy(rot, c.R, sizeof c.R);
-    std::memcpy(trans, c.T, sizeof c.T);
-    return SLX_OK;
+    return guarded([&]() -> int {
+        slx::Calibration c;
+        if (!slx::ReadCalibrationYaml(path, c)) return SLX_ERR_UNAVAILABLE;
+        std::memcpy(cam, c.CamMat, sizeof c.CamMat);
+        std::memcpy(pro, c.ProMat, sizeof c.ProMat);
+        std::memcpy(rot, c.R, sizeof c.R);
+        std::memcpy(trans, c.T, sizeof c.T);
+        return SLX_OK;
+    });
 }
 
 }  // extern "C"

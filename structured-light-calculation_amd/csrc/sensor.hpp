@@ -31,7 +31,9 @@ bool ReadCalibrationYaml(const std::string &path, Calibration &calib);
 // `ostream << double` prints it (precision 6, %g).  Same bytes as that loop, without its flush per line: the numbers are formatted
 // by std::to_chars(general, 6) -- specified to give printf("%.6g")'s characters, which is what operator<< gives -- by several
 // threads into memory, and written out in order.  xyz: 3 doubles per point.  False when the file cannot be written.
-bool WritePointCloudText(const std::string &path, const double *xyz, size_t n_points);
+// dialect (enum slx_text_dialect, include/slx.h): SLX_TEXT_LIBSTDCXX = the bytes that loop writes when built with libstdc++ / glibc
+// ("5e-05", '\n'); SLX_TEXT_MSVC2013 = the bytes of the reference AS BUILT (MSVC 2013, text-mode stream): "5e-005", CR LF.
+bool WritePointCloudText(const std::string &path, const double *xyz, size_t n_points, int dialect = SLX_TEXT_LIBSTDCXX);
 
 class CSensor {
 public:

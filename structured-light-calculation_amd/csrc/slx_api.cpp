@@ -57,7 +57,8 @@ struct slx_ctx {
     unsigned *d_cloud_counts = nullptr, *d_cloud_tiles = nullptr;   // slx_cloud_entries() / slx_cloud_tiles() + 1, point-cloud compaction
     double *d_cloud = nullptr;
     double *h_cloud = nullptr;                                        // pinned, one triple per pixel: slx_get_point_cloud_view
-    unsigned *h_cloud_total = nullptr;                                // pinned: the write kernel stores the point count here
+    unsigned *h_cloud_total = nullptr;                                // pinned: [0] the write kernel stores the point count here, [1] the fused kernel's "gave up" tag
+    unsigned cloud_fallbacks = 0;                                     // frames repeated on the two-launch path because the fused launch gave up (diagnostics)
     unsigned long long *d_cloud_words = nullptr;                      // fused cloud: ticket counter + epoch-tagged counts (slx_cloud.hip)
     unsigned cloud_epoch = 0;                                         // launches since the words were zeroed
     // the cloud's text formatted on the device (slx_text.hip): device text + workgroup lengths, the text in pinned memory, [length, flag]
@@ -69,6 +70,7 @@ struct slx_ctx {
     size_t h_text_capacity = 0;
     unsigned long long *h_text_info = nullptr;                        // pinned: [0] the length of the text, [1] the range flag (a tag)
     unsigned text_tag = 0;
+    int text_dialect = SLX_TEXT_LIBSTDCXX;                            // slx_set_text_dialect
     size_t cloud_capacity = 0;
     // dynamic-frame tracker: previous frame's strips, unblurred deltaP, staged camera image
     float *d_stripW_prev = nullptr, *d_stripB_prev = nullptr, *d_deltaP_raw = nullptr;
@@ -552,7 +554,7 @@ static int launch(slx_ctx *ctx, SlxKParams &kp, int n_sets, bool aux, void *stre
         return rc2;
     }
     if (ctx->timed) SLX_HIP(ctx, hipEventRecord(ctx->ev0, s));
-    if (!captured && !ctx->stream_state.counters && c.mode == SLX_MODE_MULTIFREQ && n_sets > 1) {
+    if (!captured && !ctx->stream_state.counters && n_sets > 1 && (c.mode == SLX_MODE_MULTIFREQ || c.mode == SLX_MODE_GRAY_PHASE)) {
         // queue counters of the stream kernel: zeroed by the launcher whenever the geometry they count for changes
         SLX_HIP(ctx, hipMalloc((void **)&ctx->stream_state.counters, (size_t)SLX_STREAM_MAX_QUEUES * 32u * sizeof(unsigned)));
         ctx->stream_state.key = 0;
@@ -560,7 +562,8 @@ static int launch(slx_ctx *ctx, SlxKParams &kp, int n_sets, bool aux, void *stre
     // (a replayed graph repeats its kernel arguments: the stream kernel, whose queue counters advance from launch to launch, stays out of it)
     SlxTuning tune = ctx->tune;
     if (captured) tune.stream = 1;
-    int e = slx_launch_fused(kp, c.mode, aux, n_sets, ctx->variant, s, &tune, captured ? nullptr : &ctx->stream_state);
+    // (captured: tune.stream = 1 keeps the planner off the queue counters; the state is passed all the same, so that slx_last_kernel names a captured launch too)
+    int e = slx_launch_fused(kp, c.mode, aux, n_sets, ctx->variant, s, &tune, &ctx->stream_state);
     if (e != 0 && !captured) ctx->stream_state.key = 0;      // whatever a failed launch left in the counters is not trusted
     if (e != 0) return hip_fail(ctx, (hipError_t)e, "kernel launch");
     if (ctx->timed) SLX_HIP(ctx, hipEventRecord(ctx->ev1, s));
@@ -737,7 +740,10 @@ int slx_point_cloud_of_depth(slx_ctx *ctx, const double *depth, double *xyz, siz
     if (int rc = order_after_done(ctx, ctx->stream)) return rc;   // the decode may have run on a caller stream: device-side wait only
     const int entries = slx_cloud_entries(c.width, c.height), n_tiles = slx_cloud_tiles(c.width, c.height);
     if (!ctx->d_cloud_tiles) SLX_HIP(ctx, hipMalloc((void **)&ctx->d_cloud_tiles, ((size_t)n_tiles + 1) * sizeof(unsigned)));   // + the total
-    if (!ctx->h_cloud_total) SLX_HIP(ctx, hipHostMalloc((void **)&ctx->h_cloud_total, sizeof(unsigned), hipHostMallocDefault));
+    if (!ctx->h_cloud_total) {                                      // pinned: [0] the point count, [1] the fused kernel's "gave up" tag
+        SLX_HIP(ctx, hipHostMalloc((void **)&ctx->h_cloud_total, 2 * sizeof(unsigned), hipHostMallocDefault));
+        ctx->h_cloud_total[0] = ctx->h_cloud_total[1] = 0u;
+    }
     unsigned *total_dev = ctx->d_cloud_tiles + n_tiles;
     const double *z = depth;
     // One launch that reads the depth once (slx_cloud.hip) wherever its plan allows; else count + write (the depth read twice)
@@ -745,8 +751,9 @@ int slx_point_cloud_of_depth(slx_ctx *ctx, const double *depth, double *xyz, siz
     const bool can_fuse = slx_cloud_fused_plan(c.width, c.height, ctx->kp.n_cus, &fq.groups, &fq.parts, &fq.rows_per_part);
     if (ctx->tune.cloud_passes == 1 && !can_fuse) return fail(ctx, SLX_ERR_UNAVAILABLE, "the fused point-cloud launch has no plan for a %d x %d map on this device", c.width, c.height);
     const bool fused = can_fuse && ctx->tune.cloud_passes != 2;
-    auto launch_cloud = [&](double *target) -> int {
-        if (!fused) {
+    unsigned fused_tag = 0;                                         // epoch + 1 of the last fused launch: what its "gave up" flag would carry
+    auto launch_cloud = [&](double *target, bool two_launches) -> int {
+        if (two_launches) {
             if (!ctx->d_cloud_counts) SLX_HIP(ctx, hipMalloc((void **)&ctx->d_cloud_counts, (size_t)entries * sizeof(unsigned)));
             int e2 = slx_launch_cloud_count(ctx->kp, z, ctx->d_cloud_counts, ctx->d_cloud_tiles, ctx->stream);
             if (e2 != 0) return hip_fail(ctx, (hipError_t)e2, "point-cloud count");
@@ -769,6 +776,10 @@ int slx_point_cloud_of_depth(slx_ctx *ctx, const double *depth, double *xyz, siz
         fq.W = c.width;
         fq.H = c.height;
         fq.epoch = ctx->cloud_epoch++;
+        fused_tag = fq.epoch + 1u;
+        fq.spin_limit = ctx->tune.cloud_spin > 0 ? (unsigned)ctx->tune.cloud_spin - 1u : SLX_CLOUD_SPIN_LIMIT;
+        fq.gave_up_host = ctx->h_cloud_total + 1;
+        ctx->h_cloud_total[1] = 0u;                                 // (no launch of this context is in flight here: every cloud call ends with the stream drained ... the decode before it does not touch the word)
         fq.row_offset = ctx->kp.row_offset;
         fq.fov_min = ctx->kp.fov_min;
         fq.fov_max = ctx->kp.fov_max;
@@ -799,14 +810,28 @@ int slx_point_cloud_of_depth(slx_ctx *ctx, const double *depth, double *xyz, siz
         }
         dst = ctx->d_cloud;
     }
-    if (int rc = launch_cloud(dst)) return rc;                      // dst NULL: the total only
-    SLX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    // One fused launch, or -- where its plan refuses, on request, or when a workgroup of the fused launch gave up waiting for its
+    // look-back (slx_cloud.hip: a bounded spin, so that a dispatcher that does not behave as the kernel assumes costs a repeat of the
+    // frame instead of a hung GPU) -- the count + write launches.  Returns with the stream drained and the total in pinned memory.
+    auto run_cloud = [&](double *target) -> int {
+        if (int rc = launch_cloud(target, !fused)) return rc;
+        SLX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (fused && *(volatile unsigned *)(ctx->h_cloud_total + 1) == fused_tag) {
+            ctx->cloud_epoch = 1u << 30;                            // the tagged words of the abandoned launch are not trusted: zeroed before the next fused launch
+            ctx->cloud_fallbacks++;
+            if (int rc = launch_cloud(target, true)) return rc;
+            SLX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            ctx->err = "point cloud: a workgroup of the fused launch gave up waiting for its look-back; the frame was repeated on the count + write launches (result complete)";
+        }
+        return SLX_OK;
+    };
+    if (int rc = run_cloud(dst)) return rc;                         // dst NULL: the total only
     const unsigned total = *(volatile unsigned *)ctx->h_cloud_total;   // stored by the write kernel, visible once the stream has drained
     *n_points = total;
     if (total == 0) return SLX_OK;
     if (!xyz || capacity_points < total) return fail(ctx, SLX_ERR_INVALID_ARG, "the cloud has %u points, the buffer holds %zu", total, capacity_points);
     if (!dst) {                                                     // a device buffer smaller than the frame, now known to be large enough
-        if (int rc = launch_cloud(xyz)) return rc;
+        return run_cloud(xyz);
     } else if (mem_kind == SLX_MEM_HOST) {
         SLX_HIP(ctx, hipMemcpyAsync(xyz, dst, (size_t)total * 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     } else {
@@ -825,9 +850,10 @@ int slx_format_points_text(slx_ctx *ctx, const double *xyz_dev, size_t n_points,
     if (n_points == 0) return SLX_OK;
     if (!xyz_dev) return fail(ctx, SLX_ERR_INVALID_ARG, "xyz is NULL");
     if ((uintptr_t)xyz_dev % sizeof(double)) return fail(ctx, SLX_ERR_INVALID_ARG, "xyz is not aligned to 8 bytes");
-    if (n_points >= (1ull << 40) / SLX_TEXT_LINE_MAX) return fail(ctx, SLX_ERR_INVALID_ARG, "%zu points: too many for one text", n_points);
+    const size_t line_max = ctx->text_dialect == SLX_TEXT_MSVC2013 ? SLX_TEXT_LINE_MAX_MSVC : SLX_TEXT_LINE_MAX;
+    if (n_points >= (1ull << 40) / line_max) return fail(ctx, SLX_ERR_INVALID_ARG, "%zu points: too many for one text", n_points);
     SLX_HIP(ctx, hipSetDevice(ctx->device));
-    const size_t need = n_points * SLX_TEXT_LINE_MAX + 16, wgs = (size_t)slx_text_workgroups(n_points);
+    const size_t need = n_points * line_max + 16, wgs = (size_t)slx_text_workgroups(n_points);
     if (ctx->d_text_capacity < need) {
         SLX_HIP(ctx, hipStreamSynchronize(ctx->stream));
         if (ctx->d_text) (void)hipFree(ctx->d_text);
@@ -854,7 +880,7 @@ int slx_format_points_text(slx_ctx *ctx, const double *xyz_dev, size_t n_points,
     // (The emit kernel storing straight into pinned host memory instead -- no device text, no copy, one wait fewer -- was measured: 1.38 ms
     // against 1.18 ms per 56 MB text; the kernel's stores cross PCIe slower than the copy engine.)
     const int e = slx_launch_text(xyz_dev, n_points, ctx->d_text_sums, (unsigned *)&ctx->h_text_info[1], ctx->text_tag, ctx->d_text, total_dev,
-                                  &ctx->h_text_info[0], ctx->stream);
+                                  &ctx->h_text_info[0], ctx->text_dialect, ctx->stream);
     if (e != 0) return hip_fail(ctx, (hipError_t)e, "point-cloud text launch");
     SLX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (*(volatile unsigned *)&ctx->h_text_info[1] == ctx->text_tag)
@@ -873,6 +899,14 @@ int slx_format_points_text(slx_ctx *ctx, const double *xyz_dev, size_t n_points,
     SLX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     *text = ctx->h_text;
     *n_bytes = total;
+    return SLX_OK;
+}
+
+int slx_set_text_dialect(slx_ctx *ctx, int dialect)
+{
+    if (!ctx) return SLX_ERR_INVALID_ARG;
+    if (dialect != SLX_TEXT_LIBSTDCXX && dialect != SLX_TEXT_MSVC2013) return fail(ctx, SLX_ERR_INVALID_ARG, "unknown text dialect %d", dialect);
+    ctx->text_dialect = dialect;
     return SLX_OK;
 }
 
@@ -1483,9 +1517,10 @@ int slx_last_kernel(slx_ctx *ctx, char *buf, size_t buf_bytes)
     case 2: snprintf(inst, sizeof inst, "%s<%d, %d, %d, %d, %s>", names[2], st.last_mode, st.last_freq, st.last_gray_ring_bits, st.last_steps, aux); break;
     case 3: snprintf(inst, sizeof inst, "%s<%d>", names[3], st.last_freq); break;
     case 4: snprintf(inst, sizeof inst, "%s<%d>", names[4], st.last_mode); break;
+    case 5: snprintf(inst, sizeof inst, "slx_gstream_kernel"); break;
     default: snprintf(inst, sizeof inst, "%s", names[0]); break;
     }
-    if (st.last_kind == 3) snprintf(buf, buf_bytes, "%s: resident waves, %d-row items from queues", inst, st.last_rows);
+    if (st.last_kind == 3 || st.last_kind == 5) snprintf(buf, buf_bytes, "%s: resident waves, %d-row items from queues", inst, st.last_rows);
     else if (st.last_kind == 2 || st.last_kind == 4) snprintf(buf, buf_bytes, "%s: %d-row items, %d rows per row group", inst, st.last_rows, st.last_weave);
     else snprintf(buf, buf_bytes, "%s", inst);
     return SLX_OK;
@@ -1514,7 +1549,7 @@ int slx_set_tuning(slx_ctx *ctx, int key, int value)
     SlxTuning &t = ctx->tune;
     const Range r[SLX_TUNE_COUNT] = {{&t.strip_rows, 0, 32}, {&t.tail_pct, -1, 99}, {&t.tail_rows, 0, 32}, {&t.gray_plain, 0, 1},
                                      {&t.strip_waves, 0, 4}, {&t.lds_pad_kib, 0, 128}, {&t.plain_order, 0, 1}, {&t.tiers, 0, SLX_MAX_TIERS},
-                                     {&t.weave, 0, 64}, {&t.stream, 0, 2}, {&t.stream_rows, 0, 16}, {&t.cloud_passes, 0, 2}};
+                                     {&t.weave, 0, 64}, {&t.stream, 0, 2}, {&t.stream_rows, 0, 16}, {&t.cloud_passes, 0, 2}, {&t.cloud_spin, 0, 1 << 30}};
     if (key < 0 || key >= SLX_TUNE_COUNT) return fail(ctx, SLX_ERR_INVALID_ARG, "unknown tuning key %d", key);
     if (value < r[key].lo || value > r[key].hi) return fail(ctx, SLX_ERR_INVALID_ARG, "tuning key %d takes values in [%d,%d] (got %d)", key, r[key].lo, r[key].hi, value);
     *r[key].field = value;

@@ -52,14 +52,20 @@ __device__ __forceinline__ void publish(unsigned long long *word, unsigned tag, 
 
 // Reads of published words: all of a thread's words are asked for together and re-polled together until every one carries the launch's
 // tag (a loop per word would put one memory round trip behind the other).
+// BOUNDED: after `limit` rounds of polls the thread gives up and the function returns false.  The progress argument at the top of this
+// file rests on how the dispatcher hands out workgroups (in index order, the classes of ticket counters within one of each other, at
+// least `parts` workgroups resident); where that ever fails to hold -- compute-unit masking, a partition mode, another device -- the
+// symptom must be an answer, not a hung GPU: the workgroup then raises the launch's flag, writes nothing, and the host runs the frame
+// again on the two-launch path (slx_point_cloud_of_depth).  A poll is a memory round trip plus s_sleep: ~1 us, so the default of
+// 16 384 rounds is ~15 ms against the few microseconds a wait lasts when all is well.
 template <int N>
-__device__ __forceinline__ void await_words(const unsigned long long *const (&word)[N], const bool (&want)[N], unsigned tag, unsigned (&value)[N])
+__device__ __forceinline__ bool await_words(const unsigned long long *const (&word)[N], const bool (&want)[N], unsigned tag, unsigned (&value)[N], unsigned limit)
 {
     unsigned long long w[N];
     bool ready[N];
 #pragma unroll
     for (int k = 0; k < N; k++) ready[k] = !want[k], value[k] = 0u;
-    for (;;) {
+    for (unsigned round = 0;; round++) {
 #pragma unroll
         for (int k = 0; k < N; k++)
             if (!ready[k]) w[k] = __hip_atomic_load(word[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -72,7 +78,8 @@ __device__ __forceinline__ void await_words(const unsigned long long *const (&wo
             }
             all = all && ready[k];
         }
-        if (all) return;
+        if (all) return true;
+        if (round >= limit) return false;
         __builtin_amdgcn_s_sleep(1);
     }
 }
@@ -86,7 +93,7 @@ template <bool FAST, bool WIDE, unsigned CH>
 __global__ __launch_bounds__(kThreads) void slx_cloud_fused_kernel(const SlxCloudFused q)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];    // [R][16] tile, swizzled | [kWaves][192] runs
-    __shared__ unsigned s_ticket, col_cnt[16], col_off[16], sib[16][16], part_sum[kWaves];
+    __shared__ unsigned s_ticket, s_gave_up, col_cnt[16], col_off[16], sib[16][16], part_sum[kWaves];
     const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const unsigned P = (unsigned)q.parts, R = (unsigned)q.rows_per_part, n_slots = (unsigned)q.groups * P;
     double *tile = lds, *run = lds + (size_t)R * 16u + (size_t)wave * 192u;
@@ -101,6 +108,7 @@ __global__ __launch_bounds__(kThreads) void slx_cloud_fused_kernel(const SlxClou
         const unsigned members = n_slots / SLX_CLOUD_COUNTERS + (c < n_slots % SLX_CLOUD_COUNTERS ? 1u : 0u);
         const unsigned j = atomicAdd(reinterpret_cast<unsigned *>(q.words + c * 16u), 1u) - q.epoch * members;
         s_ticket = c + SLX_CLOUD_COUNTERS * j;
+        s_gave_up = 0u;
     }
     if (tid < 16) col_cnt[tid] = 0;
     __syncthreads();
@@ -169,8 +177,10 @@ __global__ __launch_bounds__(kThreads) void slx_cloud_fused_kernel(const SlxClou
     // idles for the skew of the launch -- ~6 us of a 21 us kernel in the first version)
     constexpr unsigned kCols = 16u / kWaves, kChunks = CH;          // columns a wave owns, 64-row chunks of a part at most
     const double ru = FAST ? slx_refined_rcp_f64(q.fu) : 0.0, rv = FAST ? slx_refined_rcp_f64(q.fv) : 0.0;
-    double xo[kCols][kChunks], yo[kCols][kChunks];
-    if (q.xyz) {
+    // (FAST only: the literal divisions of the other instantiations -- fu or fv outside the cheap sequence's range, never a real
+    // calibration -- need more registers than 5 waves per SIMD leave; they compute x and y in step 3b instead)
+    double xo[FAST ? kCols : 1][FAST ? kChunks : 1], yo[FAST ? kCols : 1][FAST ? kChunks : 1];
+    if (FAST && q.xyz) {
 #pragma unroll
         for (unsigned ci = 0; ci < kCols; ci++) {
             const unsigned c = wave + ci * kWaves;
@@ -181,8 +191,8 @@ __global__ __launch_bounds__(kThreads) void slx_cloud_fused_kernel(const SlxClou
                 const unsigned rc = rr < rows ? rr : (rows ? rows - 1u : 0u);
                 const double zc = tile[rc * 16u + (c ^ (rc & 15u))];
                 const double vc = (double)((int)(v0 + rr) + q.row_offset) - q.cy;               // :763
-                xo[ci][ch] = FAST ? slx_div_item_const(zc * uc, q.fu, ru) : zc * uc / q.fu;     // :766
-                yo[ci][ch] = FAST ? slx_div_item_const(zc * vc, q.fv, rv) : zc * vc / q.fv;     // :767
+                xo[FAST ? ci : 0][FAST ? ch : 0] = slx_div_item_const(zc * uc, q.fu, ru);      // :766
+                yo[FAST ? ci : 0][FAST ? ch : 0] = slx_div_item_const(zc * vc, q.fv, rv);      // :767
             }
         }
     }
@@ -209,21 +219,30 @@ __global__ __launch_bounds__(kThreads) void slx_cloud_fused_kernel(const SlxClou
         }
         const unsigned long long *const wd[4] = {word[0], word[1], word[2], word[3]};
         unsigned got[4];
-        await_words(wd, want, tag, got);
+        bool arrived = await_words(wd, want, tag, got, q.spin_limit);
         if (want[0]) sib[tid >> 4][tid & 15u] = got[0];
         before = got[1] + got[2] + got[3];
-        for (unsigned s = first + tid + 3u * kThreads; s < n_before; s += kThreads) {   // maps with more than 3 x kThreads parts before this one
+        for (unsigned s = first + tid + 3u * kThreads; arrived && s < n_before; s += kThreads) {   // maps with more than 3 x kThreads parts before this one
             const unsigned long long *const one[1] = {totals + s};
             const bool yes[1] = {true};
             unsigned v[1];
-            await_words(one, yes, tag, v);
+            arrived = await_words(one, yes, tag, v, q.spin_limit);
             before += v[0];
         }
+        if (!arrived) s_gave_up = 1u;                               // (every writer stores the same value)
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) before += __shfl_xor(before, d);
     if (lane == 0) part_sum[wave] = before;
     __syncthreads();
+    if (s_gave_up) {
+        // A word this part needs never came within the bound.  Its own counts are published (nobody waits for THIS workgroup in vain);
+        // it writes no point and no total, and tells the host, which repeats the frame on the two-launch path.
+        if (tid == 0) {
+            __hip_atomic_store(q.gave_up_host, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        return;
+    }
     unsigned groups_before = 0;
 #pragma unroll
     for (unsigned k = 0; k < kWaves; k++) groups_before += part_sum[k];
@@ -263,8 +282,15 @@ __global__ __launch_bounds__(kThreads) void slx_cloud_fused_kernel(const SlxClou
             const unsigned long long m = __builtin_amdgcn_ballot_w64(keep);
             if (keep) {
                 const unsigned rank = (unsigned)__builtin_popcountll(m & ((1ull << lane) - 1ull));
-                run[3u * rank + 0u] = xo[ci][ch];
-                run[3u * rank + 1u] = yo[ci][ch];
+                if constexpr (FAST) {
+                    run[3u * rank + 0u] = xo[ci][ch];
+                    run[3u * rank + 1u] = yo[ci][ch];
+                } else {
+                    const double uc = (double)(int)(u0 + c) - q.cx;                              // R/CCalculation.cpp:762
+                    const double vc = (double)((int)(v0 + rr) + q.row_offset) - q.cy;            // :763
+                    run[3u * rank + 0u] = zc * uc / q.fu;                                        // :766
+                    run[3u * rank + 1u] = zc * vc / q.fv;                                        // :767
+                }
                 run[3u * rank + 2u] = zc;
             }
             // the chunk's records leave as one contiguous run of doubles (a wave's LDS accesses execute in order: the reads below

@@ -111,7 +111,10 @@ struct SlxCloudFused {
     unsigned epoch;
     int row_offset;
     double fov_min, fov_max, cx, cy, fu, fv;
+    unsigned spin_limit;                       // rounds of polls a look-back wait may last before the workgroup gives up (slx_cloud.hip)
+    unsigned *gave_up_host;                    // pinned host word: receives epoch + 1 when a workgroup gave up (the cloud of that launch is void)
 };
+#define SLX_CLOUD_SPIN_LIMIT 16384u            /* ~15 ms of polling: three orders of magnitude above a wait when all is well */
 // Plan of the fused cloud for a W x H map on a device of n_cus compute units (0: 256): false when the shape or the device is
 // outside what the kernel's look-back may assume (more parts per column group than workgroups the device keeps resident, more than
 // 16 parts) -- the two-launch path serves those.  Host arithmetic only (slx_plan.cpp).
@@ -123,12 +126,13 @@ int slx_launch_cloud_fused(const SlxCloudFused &q, void *stream);
 // The point-cloud text of CCalculation::Result formatted on the device (slx_text.hip): n_points packed (x, y, z) triples -> "x y z\n" lines,
 // every number as `ostream << double` prints it.  sums: slx_text_workgroups(n_points) words (device); flag: receives `tag` when a number is
 // outside the device formatter's range (pinned host word: the text is then void); text: device, 4-byte aligned, room for
-// n_points * SLX_TEXT_LINE_MAX bytes; total_dev / total_host: the length of the text (device word; pinned host word or null).
+// n_points * SLX_TEXT_LINE_MAX (_MSVC) bytes; total_dev / total_host: the length of the text (device word; pinned host word or null).
 #define SLX_TEXT_POINTS_PER_WG 1024
 #define SLX_TEXT_LINE_MAX 39         /* three numbers of at most 12 characters ("-1.23457e-05"), two blanks, the newline */
+#define SLX_TEXT_LINE_MAX_MSVC 43    /* SLX_TEXT_MSVC2013: "-1.23457e-005" is 13 characters, the line ends CR LF */
 inline unsigned long long slx_text_workgroups(unsigned long long n_points) { return (n_points + SLX_TEXT_POINTS_PER_WG - 1ull) / SLX_TEXT_POINTS_PER_WG; }
 int slx_launch_text(const double *xyz, unsigned long long n_points, unsigned *sums, unsigned *flag, unsigned tag, unsigned char *text,
-                    unsigned long long *total_dev, unsigned long long *total_host, void *stream);
+                    unsigned long long *total_dev, unsigned long long *total_host, int msvc, void *stream);   // msvc: enum slx_text_dialect
 
 // Dynamic-frame tracker (slx_track.hip).  Device pointers; 0 or a hipError_t.
 // prevW / prevB / raw non-null: also raw = the deltaP selection between the previous frame's strips and the new ones
@@ -168,6 +172,7 @@ struct SlxTuning {
     int stream;          // stream kernel: 0 automatic, 1 never, 2 whenever it can run
     int stream_rows;     // its rows per item, 2..16
     int cloud_passes;    // point cloud: 0 automatic (one launch where its plan allows), 1 the fused launch or an error, 2 the two-launch path
+    int cloud_spin;      // fused point cloud: rounds of polls a look-back wait may last, + 1 (1: a single poll); 0 = SLX_CLOUD_SPIN_LIMIT
 };
 
 // Waves per SIMD the VGPR count of a strip-kernel instantiation allows (host-side table, checked against the compiled kernels
@@ -184,7 +189,7 @@ struct SlxLaunchPlan {
     SlxKParams kp;
     int mode, aux;
     int strip;               // 1: slx_strip_kernel, 0: slx_fused_kernel
-    int stream;              // 1: slx_stream_kernel (kp.sq_* filled in except sq_epoch)
+    int stream;              // 1: slx_stream_kernel, 2: slx_gstream_kernel (the reference's own mode) -- kp.sq_* filled in except sq_epoch
     int gray_ring_bits;      // strip kernel: 6 when the Gray planes ride the DMA ring, else 0
     unsigned grid_x, grid_y, block;
     size_t lds_bytes;
@@ -199,7 +204,8 @@ struct SlxStreamState {
     unsigned *counters = nullptr;               // device, SLX_STREAM_MAX_QUEUES * 32 words
     unsigned long long key = 0;                 // geometry the counters count for (0: none yet)
     unsigned epoch = 0;
-    // what the last launch was (slx_last_kernel): 0 none, 1 slx_fused_kernel, 2 slx_strip_kernel, 3 slx_stream_kernel, 4 slx_decoder_strip_kernel
+    // what the last launch was (slx_last_kernel): 0 none, 1 slx_fused_kernel, 2 slx_strip_kernel, 3 slx_stream_kernel, 4 slx_decoder_strip_kernel,
+    // 5 slx_gstream_kernel
     int last_kind = 0, last_rows = 0, last_weave = 0;
     // ... and which instantiation: the template arguments as rocprofv3 prints them (mode, frequencies, Gray bits on the DMA ring, steps, optional planes)
     int last_mode = 0, last_freq = 0, last_gray_ring_bits = 0, last_steps = 0, last_aux = 0;

@@ -1511,6 +1511,280 @@ __global__ __launch_bounds__(256) void slx_stream_kernel(const SlxKParams p)
 }
 
 // ------------------------------------------------------------------------------------------
+// Stream kernel of the reference's own mode (round 6): SLX_MODE_GRAY_PHASE -- a1 + a3 + a4 + a5 + a7, R/CCalculation.cpp:525-592 + :666-708,
+// 6 Gray bits whose 12 planes ride the DMA ring.  The strip kernel serves that mode with 3-row items -- the shortest-lived work items
+// of the library, so what an item sets up (lane geometry by integer division, the buffer descriptors, the column terms of cC / cD)
+// is paid every third row.  Here, as in slx_stream_kernel, a resident wave sets that up once per LAUNCH and takes R-row items of ONE
+// chunk column from its queue (same queues, tickets and counters).  What differs from that kernel:
+//   * a row is TWO ring chunks -- its 4 phase planes (slot 0) and its 12 Gray planes (slot 1) -- so the request side runs one row
+//     ahead: the phase chunk of row r + 1 is requested once the phase dwords of row r have been read, the Gray chunk likewise;
+//   * counted waits (vmcnt retires in issue order):  P(r) G(r) | Z(r-1) P(r+1) | G(r+1) Z(r) ...: the wait for P(r) leaves G(r) in
+//     flight (NGR), the wait for G(r) leaves Z(r-1) and P(r+1) (NZ + NPH; the launch's first row has no Z in front of it);
+//   * items of ONE row (slx_plan.cpp): REF x 32 164.3 us with 1-row items, 171.3 with 2, 177.6 with 3, 192 with 8 -- the waves of a
+//     SIMD wait for their DMA here, and the more often they draw tickets the less they move in step.
+// Same-box A/B against the strip kernel (profiles/r06_gstream_ab.log): REF x 32 169.5 -> 164.3 us (-3.1 %), x 16 -3.5 %, x 8 -2.4 %, x 4
+// +0.7 %; 55.7 M vector instructions per launch for 59.9 M, the same bytes.  The Gray-MASK mode (x3: 62-quad spans with halo lanes)
+// was built on this kernel too, in five versions -- chip-wide queues (1 282 MB read for 885 algorithmic: the two waves that share a
+// halo line almost never share an L2), XCD-local queues (1 017 MB), one ticket per workgroup and item handed over through LDS (942 MB)
+// -- and none beat the strip kernel's statically aligned items by 2 % on config 3 (best: -1.2 %): not in the tree
+// (profiles/experiments/r06_gstream_kernel_gray_mask_mode.patch).
+__global__ __launch_bounds__(256) void slx_gstream_kernel(const SlxKParams p)
+{
+    constexpr int F = 1, GB = 6;
+    constexpr int NPH = F * 4, NGR = 2 * GB;
+    constexpr int NPMAX = NPH > NGR ? NPH : NGR;
+    constexpr unsigned ROW_DW = NPMAX * 64;
+    constexpr int NZ = 2;
+    typedef double vec2 __attribute__((ext_vector_type(2)));
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) void lds_void;
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds_raw[];
+    const unsigned t = threadIdx.x;
+    const unsigned lane = t & 63u;
+    const unsigned wave_in_wg = __builtin_amdgcn_readfirstlane(t >> 6);
+    uint32_t *ring = lds_raw + wave_in_wg * (2u * ROW_DW + 512u);
+    vec2 *stage = reinterpret_cast<vec2 *>(ring + 2u * ROW_DW);
+
+    // ---- this wave's queue (slx_stream_kernel)
+    const unsigned waves_per_wg = blockDim.x >> 6;
+    const unsigned wave_id = blockIdx.x * waves_per_wg + wave_in_wg, total_waves = gridDim.x * waves_per_wg;
+    const unsigned NQ = p.sq_queues, m = p.sq_m, cpg = p.chunks_per_group;
+    const unsigned q = wave_id % NQ;
+    const unsigned c = q % cpg, j = q / cpg;
+    const unsigned Kq = p.sq_groups_total > j ? (p.sq_groups_total - j + m - 1u) / m : 0u;
+    const unsigned Wq = (total_waves - q + NQ - 1u) / NQ;
+    const unsigned ticket0 = p.sq_epoch * (Kq + Wq);
+    unsigned *ctr = p.sq_counters + (size_t)q * 32u;
+    auto fetch_issue = [&](unsigned &raw) {
+        asm volatile("s_mov_b32 %0, 1\n\ts_atomic_add %0, %1, 0x0 glc" : "=&s"(raw) : "s"(ctr) : "memory");
+    };
+    auto fetch_wait = [&](unsigned &raw) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(raw)::"memory"); };
+
+    // ---- per-column state, once per launch
+    const unsigned W = (unsigned)p.width, H = (unsigned)p.height;
+    const unsigned row_stride = (unsigned)p.row_stride, il = p.interleave, R = p.sq_rows;
+    const unsigned QR = p.quads_per_row;
+    const unsigned idx = c * 64u + lane;                           // < il * QR: chunks_per_group * 64 is exactly that
+    const unsigned sub = idx / QR, cq = idx - sub * QR;            // row within the row group, quad column
+    unsigned out_lane[2];                                          // byte offset of store slot k within the group's first row
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        const unsigned slot = (unsigned)k * 64u + lane, vidx = c * 64u + (slot >> 1);
+        const unsigned vsub = vidx / QR, vcq = vidx - vsub * QR;
+        out_lane[k] = (vsub * W + vcq * SLX_QUAD + (slot & 1u) * 2u) * 8u;
+    }
+    const unsigned dma_lane = sub * row_stride + cq * SLX_QUAD;
+    const unsigned dma_last = (H - 1u) * row_stride + cq * SLX_QUAD;     // rows past the tile: harmless re-read of the last row
+    const unsigned dma_step = il * row_stride, out_step = il * W * 8u;
+    const float Tf = (float)p.period[0];
+    // as in slx_strip_kernel: this kernel is short of scalar registers, the per-pixel constants of the triangulation live in vector ones
+    double kK1 = p.K1, kK2 = p.K2, kcA = p.cA, kcB = p.cB, kfmin = p.fov_min, kfmax = p.fov_max;
+    asm volatile("" : "+v"(kK1), "+v"(kK2), "+v"(kcA), "+v"(kcB), "+v"(kfmin), "+v"(kfmax));
+    double aC[SLX_QUAD], aD[SLX_QUAD];
+#pragma unroll
+    for (int jx = 0; jx < SLX_QUAD; jx++) {
+        const double a = ((double)(int)(cq * SLX_QUAD + jx) - p.cx) * p.fv;
+        aC[jx] = a * p.P00;
+        aD[jx] = a * p.P20;
+    }
+
+    // ---- items: ticket -> (frame-set, first row of the row group)
+    struct Item { unsigned valid, set, row_base; };
+    auto decode = [&](unsigned raw) {
+        Item it;
+        const unsigned k = raw - ticket0;
+        it.valid = k < Kq ? 1u : 0u;
+        const unsigned G = it.valid ? k * m + j : 0u;
+        it.set = p.sq_groups_per_set == 1u ? G : __umulhi(G, p.sq_magic);
+        it.row_base = (G - it.set * p.sq_groups_per_set) * R * il;
+        return it;
+    };
+    unsigned raw;
+    fetch_issue(raw);
+    fetch_wait(raw);
+    Item A = decode(raw), B{0u, 0u, 0u};
+    if (!A.valid) return;
+
+    // request side (one row = two chunks ahead): its item, rows of it already requested, the two descriptors, lane offset of the next row
+    Item D = A;
+    unsigned dri = 0;
+    __amdgpu_buffer_rsrc_t drsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(p.plane_base + (size_t)D.set * p.phase_set_stride), 0, 0xFFFFFFFFu, 0x00020000);
+    __amdgpu_buffer_rsrc_t dgrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(p.gray[0] + (size_t)D.set * p.gray_set_stride), 0, 0xFFFFFFFFu, 0x00020000);
+    unsigned dma_off = dma_lane + D.row_base * row_stride;
+    auto next_plane = [](unsigned &so, unsigned step) { asm volatile("s_add_u32 %0, %0, %1" : "+s"(so) : "s"(step) : "scc"); };
+    auto issue_phase = [&]() {                                     // the request row's phase planes into slot 0 (every byte is read once: nontemporal)
+        const unsigned voff = dma_off < dma_last ? dma_off : dma_last;
+        uint32_t *dst = ring;
+        unsigned so = p.phase_first;
+        if (p.dma_imm) {
+            static_for<NPH>([&](auto k) {
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(drsrc, (lds_void *)dst, 4, voff, so, decltype(k)::value * 256, 2 /* nt */);
+                if (decltype(k)::value + 1 < NPH) next_plane(so, p.phase_step - 256u);
+            });
+        } else {
+#pragma unroll
+            for (int k = 0; k < NPH; k++) {
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(drsrc, (lds_void *)(dst + k * 64), 4, voff, so, 0, 2 /* nt */);
+                if (k + 1 < NPH) next_plane(so, p.phase_step);
+            }
+        }
+    };
+    auto issue_gray = [&]() {                                      // ... its Gray planes into slot 1; the request side moves on a row
+        const unsigned voff = dma_off < dma_last ? dma_off : dma_last;
+        uint32_t *dst = ring + ROW_DW;
+        unsigned so = 0u;
+        if (p.dma_imm) {
+            static_for<NGR>([&](auto k) {
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(dgrsrc, (lds_void *)dst, 4, voff, so, decltype(k)::value * 256, 2 /* nt */);
+                if (decltype(k)::value + 1 < NGR) next_plane(so, p.gray_step - 256u);
+            });
+        } else {
+#pragma unroll
+            for (int k = 0; k < NGR; k++) {
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(dgrsrc, (lds_void *)(dst + k * 64), 4, voff, so, 0, 2 /* nt */);
+                if (k + 1 < NGR) next_plane(so, p.gray_step);
+            }
+        }
+        dma_off += dma_step;
+        dri = uniform_u32(dri + 1u);
+    };
+    auto request_moves_to = [&](const Item &to) {
+        D = to;
+        dri = 0;
+        if (to.valid) {
+            drsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(uniform_ptr(p.plane_base + (size_t)to.set * p.phase_set_stride)), 0, 0xFFFFFFFFu, 0x00020000);
+            dgrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(uniform_ptr(p.gray[0] + (size_t)to.set * p.gray_set_stride)), 0, 0xFFFFFFFFu, 0x00020000);
+            dma_off = dma_lane + to.row_base * row_stride;
+        }
+    };
+
+    // compute side: item A, row ri of it; where its rows are stored
+    unsigned ri = 0;
+    unsigned row = A.row_base + sub;
+    __amdgpu_buffer_rsrc_t zrsrc = __builtin_amdgcn_make_buffer_rsrc(p.z + (size_t)A.set * p.out_set_stride, 0, H * W * 8u, 0x00020000);
+    unsigned out_boff[2] = {out_lane[0] + A.row_base * W * 8u, out_lane[1] + A.row_base * W * 8u};
+    __amdgpu_buffer_rsrc_t prsrc = zrsrc;
+    unsigned pend_off[2] = {0xFFFFFFF0u, 0xFFFFFFF0u};
+    issue_phase();                                                 // row 0 of the first item
+    issue_gray();
+    for (unsigned s = 0;; s++) {
+        __builtin_amdgcn_s_setprio(1);                             // (slx_stream_kernel: priority up to the step's last DMA request)
+        unsigned next_raw;                                         // the ticket of the item after this one: a variable of this step alone (see slx_stream_kernel)
+        if (ri == 0) fetch_issue(next_raw);
+        // ---- chunk 0: the row's phase planes.  Behind their DMA only the row's Gray DMA has been issued
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NGR) : "memory");
+        if (s > 0) {                                               // last row's stores, one step late
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                const u32x4 v = *reinterpret_cast<const u32x4 *>(stage + k * 64 + lane);
+                __builtin_amdgcn_raw_buffer_store_b128(v, prsrc, pend_off[k], 0, 2 /* nt */);
+            }
+        }
+        // No divergent branch between the ticket's issue and its wait: rows past the tile run the phase arithmetic on the last row's
+        // bytes (their DMA is clamped to it) and are never stored.  (With `if (row < H)` around it hipcc carried the in-flight ticket
+        // through a VECTOR register across the branch -- a copy of the placeholder, which the compiler then could not even lower.)
+        float pix[SLX_QUAD];
+        {
+            const uint32_t *src = ring + lane;
+            const uint32_t w0 = src[0 * 64], w1 = src[1 * 64], w2 = src[2 * 64], w3 = src[3 * 64];
+            const f32x2 kUp = {0x1p126f, 0x1p126f};
+            const F32x2x2 px = wrapped_pix_from_diffs<true>(
+                F32x2x2{f32x2{byte_diff_denorm<0>(w0, w2), byte_diff_denorm<1>(w0, w2)} * kUp, f32x2{byte_diff_denorm<2>(w0, w2), byte_diff_denorm<3>(w0, w2)} * kUp},
+                F32x2x2{f32x2{byte_diff_denorm<0>(w1, w3), byte_diff_denorm<1>(w1, w3)} * kUp, f32x2{byte_diff_denorm<2>(w1, w3), byte_diff_denorm<3>(w1, w3)} * kUp}, Tf);
+            pix[0] = px.a.x;
+            pix[1] = px.a.y;
+            pix[2] = px.b.x;
+            pix[3] = px.b.y;
+        }
+        // slot 0 is free once it has been read -- and the ticket requested above has arrived with the same wait
+        if (ri == 0) {
+            fetch_wait(next_raw);
+            B = decode(next_raw);
+        } else {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        if (D.valid && dri == R) request_moves_to(B);
+        const unsigned more = uniform_u32(D.valid);                // is there a row after this one?
+        if (more) issue_phase();
+        // ---- chunk 1: the row's Gray planes.  Behind their DMA: the stores above and the phase DMA just issued
+        if (!more) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (s > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPH + NZ) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPH) : "memory");
+        uint32_t gw[NGR];
+        {
+            const uint32_t *src = ring + ROW_DW + lane;
+#pragma unroll
+            for (int k = 0; k < NGR; k++) gw[k] = src[k * 64];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // slot 1 is free once it has been read
+        if (more) issue_gray();
+        __builtin_amdgcn_s_setprio(0);
+        if (row < H) {
+            // a3 + the bit-pack of a4 on the whole quad (slx_strip_kernel)
+            uint32_t acc = 0u;
+#pragma unroll
+            for (int b = 0; b < GB; b++) acc = swar_push_bit7(acc, swar_ge_u8_bit7(gw[2 * b + 1], gw[2 * b]));
+            uint32_t code4 = swar_finish_code(acc, GB);
+            if (p.std_gray) code4 = swar_gray_to_binary_u8(code4);   // lut[gray] = bin is the reflected code's inverse (one uniform branch)
+            int bin[SLX_QUAD];
+#pragma unroll
+            for (int jx = 0; jx < SLX_QUAD; jx++) bin[jx] = (int)((code4 >> (8 * jx)) & 0xffu);
+            if (!p.std_gray) {
+#pragma unroll
+                for (int jx = 0; jx < SLX_QUAD; jx++) bin[jx] = (int)p.lut[bin[jx]];
+            }
+            const double Td = (double)p.period[0], Sd = (double)p.gray_stripe;
+            const double vc = (double)((int)row + p.row_offset) - p.cy;
+            const double vf = vc * p.fu;
+            const double tvC = vf * p.P01, tvD = vf * p.P21;
+            double z[SLX_QUAD];
+#pragma unroll
+            for (int jx = 0; jx < SLX_QUAD; jx++) {
+                // a5 as selects: the same operations and roundings as R/CCalculation.cpp:570-587 (slx_strip_kernel)
+                const double grayv = (double)bin[jx] * Sd;
+                const double phaseVal = (double)pix[jx];
+                const bool odd = (bin[jx] & 1) != 0;
+                const bool shift = odd ? (phaseVal < Td * 0.25) : (phaseVal > Td * 0.75);
+                const double tt = shift ? phaseVal + (odd ? Td : -Td) : phaseVal;
+                const double ph = odd ? tt - 0.5 * Td : tt;
+                const double Uv = grayv + ph;
+                const double cC = (aC[jx] + tvC) + kK1;
+                const double cD = (aD[jx] + tvD) + kK2;
+                z[jx] = tri_depth<true>(Uv, cC, cD, kcA, kcB, kfmin, kfmax, true);
+            }
+            stage[2 * lane + 0] = vec2{z[0], z[1]};
+            stage[2 * lane + 1] = vec2{z[2], z[3]};
+        }
+        // this row's stores go out at the top of the next step
+        prsrc = zrsrc;
+        pend_off[0] = out_boff[0];
+        pend_off[1] = out_boff[1];
+        __builtin_amdgcn_wave_barrier();
+        // next row of the item, or the next item
+        ri = uniform_u32(ri + 1u);
+        if (ri == R) {
+            if (!B.valid) break;
+            A = B;
+            ri = 0;
+            row = A.row_base + sub;
+            zrsrc = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(p.z + (size_t)A.set * p.out_set_stride), 0, H * W * 8u, 0x00020000);
+            out_boff[0] = out_lane[0] + A.row_base * W * 8u;
+            out_boff[1] = out_lane[1] + A.row_base * W * 8u;
+        } else {
+            row += il;
+            out_boff[0] += out_step;
+            out_boff[1] += out_step;
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        const u32x4 v = *reinterpret_cast<const u32x4 *>(stage + k * 64 + lane);
+        __builtin_amdgcn_raw_buffer_store_b128(v, prsrc, pend_off[k], 0, 2 /* nt */);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // The reference's decoder objects on the strip path: what CDecodePhase::Decode (R/CDecodePhase.cpp:83-96 -> CountResult :48-80:
 // four 8-bit planes in, the wrapped phase in projector pixels out as CV_64FC1) and CDecodeGray::Decode (R/CDecodeGray.cpp:108-139
 // -> Grey2Bin :150-176, CountResult :179-204: 2 G planes in, the stripe's left edge out as CV_64FC1) compute, for a host loop that
@@ -1877,7 +2151,7 @@ int slx_launch_fused(const SlxKParams &kp_in, int mode, bool aux, int n_sets, in
     if (plan.stream) {
         // the counters count for ONE geometry: zero them when it changes (or before they could wrap), else carry on from the last launch
         const unsigned long long key = ((unsigned long long)kp.sq_queues << 52) ^ ((unsigned long long)kp.sq_m << 44) ^ ((unsigned long long)kp.sq_groups_total << 12) ^
-                                       ((unsigned long long)plan.grid_x << 3) ^ ((unsigned long long)(plan.block / 64u) << 1) ^ 1ull;
+                                       ((unsigned long long)plan.grid_x << 3) ^ ((unsigned long long)(plan.block / 64u) << 1) ^ 1ull ^ ((unsigned long long)plan.stream << 62);
         const unsigned long long per_launch = (unsigned long long)kp.sq_groups_total / kp.sq_m + 2ull + ((unsigned long long)plan.grid_x * (plan.block / 64u)) / kp.sq_queues + 2ull;
         if (st->key != key || ((unsigned long long)st->epoch + 2ull) * per_launch >= (1ull << 31)) {
             const hipError_t e = hipMemsetAsync(st->counters, 0, (size_t)SLX_STREAM_MAX_QUEUES * 32u * sizeof(unsigned), (hipStream_t)stream);
@@ -1886,11 +2160,15 @@ int slx_launch_fused(const SlxKParams &kp_in, int mode, bool aux, int n_sets, in
             st->epoch = 0;
         }
         kp.sq_epoch = st->epoch++;
-        switch (kp.n_freq) {
-        case 1: fn = slx_stream_kernel<1>; break;
-        case 2: fn = slx_stream_kernel<2>; break;
-        case 3: fn = slx_stream_kernel<3>; break;
-        default: fn = slx_stream_kernel<4>; break;
+        if (plan.stream == 2) {
+            fn = slx_gstream_kernel;
+        } else {
+            switch (kp.n_freq) {
+            case 1: fn = slx_stream_kernel<1>; break;
+            case 2: fn = slx_stream_kernel<2>; break;
+            case 3: fn = slx_stream_kernel<3>; break;
+            default: fn = slx_stream_kernel<4>; break;
+            }
         }
     } else if (!plan.strip) {
         fn = pick(mode, kp.n_freq, kp.n_steps == 4, aux);
@@ -1905,7 +2183,7 @@ int slx_launch_fused(const SlxKParams &kp_in, int mode, bool aux, int n_sets, in
     }
     if (!fn) return (int)hipErrorInvalidValue;
     if (st) {
-        st->last_kind = plan.stream ? 3 : !plan.strip ? 1 : (mode == SLX_MODE_PHASE_ONLY || mode == SLX_MODE_GRAY_ONLY) ? 4 : 2;
+        st->last_kind = plan.stream == 2 ? 5 : plan.stream ? 3 : !plan.strip ? 1 : (mode == SLX_MODE_PHASE_ONLY || mode == SLX_MODE_GRAY_ONLY) ? 4 : 2;
         st->last_rows = plan.stream ? (int)kp.sq_rows : plan.strip ? (int)kp.tier_rows[0] : 0;
         st->last_weave = plan.strip ? (int)kp.interleave : 0;
         st->last_mode = mode;

@@ -291,6 +291,44 @@ int slx_plan_launch(const SlxKParams &kp_in, int mode, bool aux, int n_sets, int
             return 0;
         }
     }
+    // Stream kernel of the reference's own mode (slx_gstream_kernel, round 6): 6 Gray bits on the ring + one 4-step frequency, depth only.
+    // Same queues and counters as slx_stream_kernel; a row is two ring chunks there, an item ONE row (REF x 32: 164.3 us with 1-row
+    // items, 171.3 with 2, 177.6 with 3: profiles/r06_gstream_ab.log).  Taken from 8 items per resident wave on -- same-box against the
+    // strip kernel: 32 frame-sets of the reference's size -3.1 %, 16 -3.5 %, 8 -2.4 %, 4 (5 items per wave) +0.7 %.
+    if (!decoder && gb == 6 && mode == SLX_MODE_GRAY_PHASE && kp.n_steps == 4 && !aux && kp.sq_counters && tn.stream != 1 && tn.weave <= 1) {
+        const unsigned il = 64u / g, cpg = il * QR / 64u;
+        const unsigned R = (tn.stream_rows >= 1 && tn.stream_rows <= 16) ? (unsigned)tn.stream_rows : 1u;
+        const unsigned gps = ((unsigned)kp.height + R * il - 1u) / (R * il);
+        const unsigned long long groups_total = (unsigned long long)gps * (unsigned)n_sets;
+        const unsigned cus = kp.n_cus ? kp.n_cus : 256u;
+        const unsigned lds_w = 2u * 12u * 256u + 2048u;
+        const unsigned wpw = (tn.strip_waves >= 1 && tn.strip_waves <= 4) ? (unsigned)tn.strip_waves : 4u;
+        const unsigned long long waves = (unsigned long long)cus * 16u;                     // 4 per SIMD: <= 128 VGPRs (tests/test_kernel_resources.py)
+        const unsigned m = (cpg >= 1 && cpg <= 255u) ? (unsigned)std::min<unsigned long long>(255u / cpg, waves / cpg) : 0u;
+        const bool big = groups_total * cpg >= 8ull * waves;
+        if (m >= 1 && cpg * m <= SLX_STREAM_MAX_QUEUES && groups_total * gps < (1ull << 32) && groups_total < (1ull << 31) &&
+            (tn.stream == 2 ? groups_total * cpg >= 1 : big)) {
+            kp.interleave = il;
+            kp.chunks_per_group = cpg;
+            kp.sq_queues = cpg * m;
+            kp.sq_m = m;
+            kp.sq_rows = R;
+            kp.sq_groups_per_set = gps;
+            kp.sq_groups_total = (unsigned)groups_total;
+            kp.sq_magic = (unsigned)((1ull << 32) / gps) + 1u;
+            kp.n_tiers = 0;
+            const unsigned long long items = groups_total * cpg;
+            const unsigned long long want_waves = std::min<unsigned long long>(waves, items);
+            plan->strip = 1;
+            plan->stream = 2;
+            plan->gray_ring_bits = gb;
+            plan->block = 64u * wpw;
+            plan->grid_x = (unsigned)((want_waves + wpw - 1ull) / wpw);
+            plan->grid_y = 1;
+            plan->lds_bytes = wpw * lds_w;
+            return 0;
+        }
+    }
     // LDS per wave: 2 ring slots (max(4 n_freq, 2 gb) planes with 4 steps, 8 planes with 8 steps, 256 B each) + 2 KiB of depth staging
     const unsigned ring_planes = mode == SLX_MODE_GRAY_ONLY ? 12u : kp.n_steps == 4 ? std::max((unsigned)kp.n_freq * 4u, 2u * (unsigned)gb) : 8u;
     const unsigned lds_wave = 2u * ring_planes * 256u + 2048u + (aux ? 2048u : 0u);      // + the optional planes' staging area

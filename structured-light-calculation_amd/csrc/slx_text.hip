@@ -107,18 +107,22 @@ __device__ __forceinline__ unsigned g6_digits(double v, bool &ok)
     return neg | ((unsigned)(X + 16) << 24) | bcd;
 }
 
+// MSVC: the dialect of the reference as built (MSVC 2013 runtime, text-mode stream; include/slx.h, enum slx_text_dialect): three exponent
+// digits ("5e-005") and CR LF -- one more character per number in exponent notation, one more per line
+template <bool MSVC>
 __device__ __forceinline__ unsigned g6_length(unsigned g)
 {
     const unsigned n = (g & kG6Neg) ? 1u : 0u;
     if (g6_bcd(g) == 0u) return n + 1u;
     const int X = g6_X(g);
     const unsigned nd = g6_nd(g);
-    if (X < -4 || X >= 6) return n + (nd > 1 ? nd + 5u : 5u);        // d[.ddd]e+XX
+    if (X < -4 || X >= 6) return n + (nd > 1 ? nd + 5u : 5u) + (MSVC ? 1u : 0u);   // d[.ddd]e+XX, e+0XX
     if (X >= 0) return n + (unsigned)(X + 1) + (nd > (unsigned)(X + 1) ? 1u + nd - (unsigned)(X + 1) : 0u);
     return n + 2u + (unsigned)(-X - 1) + nd;                         // 0.000ddd
 }
 
 // the characters, at out[0 ..): returns the end.  d(i) = digit i of q, the most significant first.
+template <bool MSVC>
 __device__ __forceinline__ unsigned g6_put(unsigned g, unsigned char *out, unsigned o)
 {
     if (g & kG6Neg) out[o++] = '-';
@@ -143,6 +147,7 @@ __device__ __forceinline__ unsigned g6_put(unsigned g, unsigned char *out, unsig
         } else {
             out[o++] = '+';
         }
+        if (MSVC) out[o++] = '0';
         out[o++] = (unsigned char)('0' + e / 10);
         out[o++] = (unsigned char)('0' + e % 10);
     } else if (X >= 0) {
@@ -176,6 +181,7 @@ __device__ __forceinline__ unsigned long long wg_sum(unsigned long long v, unsig
 
 // flag: a word (pinned host memory) that receives `tag` when a number is outside the formatter's range -- tags differ from call to call,
 // so nothing has to be cleared
+template <bool MSVC>
 __global__ __launch_bounds__(kThreads) void slx_text_len_kernel(const double *__restrict__ xyz, unsigned long long n_points, unsigned *__restrict__ sums,
                                                                unsigned *__restrict__ flag, unsigned tag)
 {
@@ -197,7 +203,7 @@ __global__ __launch_bounds__(kThreads) void slx_text_len_kernel(const double *__
 #pragma unroll
         for (unsigned k = 1; k < kPerLane * 3u; k++) x = j == k ? v[k] : x;
         const unsigned g = g6_digits(x, ok);
-        len += j < mine_n ? g6_length(g) + 1u : 0u;                  // + the blank or the newline behind it
+        len += j < mine_n ? g6_length<MSVC>(g) + 1u + (MSVC && j % 3u == 2u ? 1u : 0u) : 0u;   // + the blank or the newline (CR LF) behind it
     }
     bad = !ok;
     if (bad) *flag = tag;
@@ -205,11 +211,12 @@ __global__ __launch_bounds__(kThreads) void slx_text_len_kernel(const double *__
     if (threadIdx.x == 0) sums[blockIdx.x] = (unsigned)total;
 }
 
+template <bool MSVC>
 __global__ __launch_bounds__(kThreads) void slx_text_emit_kernel(const double *__restrict__ xyz, unsigned long long n_points, const unsigned *__restrict__ sums,
                                                                 unsigned char *__restrict__ text, unsigned long long *__restrict__ total_dev,
                                                                 unsigned long long *__restrict__ total_host)
 {
-    __shared__ __attribute__((aligned(16))) unsigned char buf[SLX_TEXT_POINTS_PER_WG * SLX_TEXT_LINE_MAX + 128 + 16];
+    __shared__ __attribute__((aligned(16))) unsigned char buf[SLX_TEXT_POINTS_PER_WG * (MSVC ? SLX_TEXT_LINE_MAX_MSVC : SLX_TEXT_LINE_MAX) + 128 + 16];
     __shared__ unsigned long long scratch[kThreads / 64u];
     __shared__ unsigned wave_len[kThreads / 64u];
     __shared__ unsigned digested[kPerLane * 3][kThreads];
@@ -234,7 +241,7 @@ __global__ __launch_bounds__(kThreads) void slx_text_emit_kernel(const double *_
             for (unsigned k = 1; k < kPerLane * 3u; k++) x = j == k ? v[k] : x;
             const unsigned g = g6_digits(x, ok);
             digested[j][tid] = g;
-            const unsigned l = base + 64u * (j / 3u) < n_points ? g6_length(g) + 1u : 0u;
+            const unsigned l = base + 64u * (j / 3u) < n_points ? g6_length<MSVC>(g) + 1u + (MSVC && j % 3u == 2u ? 1u : 0u) : 0u;
 #pragma unroll
             for (unsigned i = 0; i < kPerLane; i++) plen[i] += j / 3u == i ? l : 0u;
         }
@@ -286,7 +293,8 @@ __global__ __launch_bounds__(kThreads) void slx_text_emit_kernel(const double *_
             for (unsigned k = 1; k < kPerLane; k++) ps = i == k ? pstart[k] : ps;
             o = mis + start + ps;
         }
-        o = g6_put(digested[j][tid], buf, o);
+        o = g6_put<MSVC>(digested[j][tid], buf, o);
+        if (MSVC && c == 2) buf[o++] = '\r';
         buf[o++] = c == 2 ? '\n' : ' ';
     }
     __syncthreads();
@@ -311,12 +319,17 @@ __global__ __launch_bounds__(kThreads) void slx_text_emit_kernel(const double *_
 }  // namespace
 
 int slx_launch_text(const double *xyz, unsigned long long n_points, unsigned *sums, unsigned *flag, unsigned tag, unsigned char *text,
-                    unsigned long long *total_dev, unsigned long long *total_host, void *stream)
+                    unsigned long long *total_dev, unsigned long long *total_host, int msvc, void *stream)
 {
     if (!xyz || n_points == 0 || !sums || !flag || !text || !total_dev || (reinterpret_cast<uintptr_t>(text) & 3u)) return (int)hipErrorInvalidValue;
     const unsigned long long wgs = (n_points + SLX_TEXT_POINTS_PER_WG - 1ull) / SLX_TEXT_POINTS_PER_WG;
     if (wgs >= (1ull << 31)) return (int)hipErrorInvalidValue;
-    hipLaunchKernelGGL(slx_text_len_kernel, dim3((unsigned)wgs), dim3(kThreads), 0, (hipStream_t)stream, xyz, n_points, sums, flag, tag);
-    hipLaunchKernelGGL(slx_text_emit_kernel, dim3((unsigned)wgs), dim3(kThreads), 0, (hipStream_t)stream, xyz, n_points, sums, text, total_dev, total_host);
+    if (msvc) {
+        hipLaunchKernelGGL(slx_text_len_kernel<true>, dim3((unsigned)wgs), dim3(kThreads), 0, (hipStream_t)stream, xyz, n_points, sums, flag, tag);
+        hipLaunchKernelGGL(slx_text_emit_kernel<true>, dim3((unsigned)wgs), dim3(kThreads), 0, (hipStream_t)stream, xyz, n_points, sums, text, total_dev, total_host);
+    } else {
+        hipLaunchKernelGGL(slx_text_len_kernel<false>, dim3((unsigned)wgs), dim3(kThreads), 0, (hipStream_t)stream, xyz, n_points, sums, flag, tag);
+        hipLaunchKernelGGL(slx_text_emit_kernel<false>, dim3((unsigned)wgs), dim3(kThreads), 0, (hipStream_t)stream, xyz, n_points, sums, text, total_dev, total_host);
+    }
     return (int)hipGetLastError();
 }

@@ -4,6 +4,8 @@
 // host_sanitize); no GPU, no device code.  Exit code 0 = every check held and no sanitizer report.
 //   usage: host_sanitize <scratch directory>
 #include <climits>
+#include <cmath>
+#include <cstdlib>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -99,6 +101,16 @@ static void test_bmp(const std::string &dir)
     std::vector<uint8_t> small(10);
     CHECK(slx_read_bmp_gray(p.c_str(), small.data(), small.size(), &r, &c) == SLX_ERR_INVALID_ARG);
     CHECK(slx_read_bmp_gray((dir + "/missing.bmp").c_str(), nullptr, 0, &r, &c) == SLX_ERR_UNAVAILABLE);
+    // a DIRECTORY where a file is expected (fopen succeeds on one, ftell then answers LONG_MAX): refused, no allocation attempted
+    CHECK(slx_read_bmp_gray(dir.c_str(), nullptr, 0, &r, &c) == SLX_ERR_UNAVAILABLE);
+    CHECK(slx_read_pgm_gray(dir.c_str(), nullptr, 0, &r, &c) == SLX_ERR_UNAVAILABLE);
+    CHECK(slx_read_bmp_gray("/", nullptr, 0, &r, &c) == SLX_ERR_UNAVAILABLE && !slx::ReadBmpGray("/tmp", px, r, c) && !slx::ReadPgmGray("/tmp", px, r, c));
+    {
+        double a[9], b[9], c9[9], t3[3];
+        CHECK(slx_read_calibration_yaml(dir.c_str(), a, b, c9, t3) == SLX_ERR_UNAVAILABLE);
+        std::vector<int16_t> lut;
+        CHECK(!slx::ReadGrayCodeFile(dir, 6, lut));
+    }
 }
 
 static void test_pgm(const std::string &dir)
@@ -198,6 +210,43 @@ static void test_point_cloud_text(const std::string &dir)
         }
         CHECK(slx_write_point_cloud_text(p.c_str(), n ? xyz.data() : nullptr, n) == SLX_OK);
         CHECK(file_bytes() == reference(xyz));
+    }
+    // SLX_TEXT_MSVC2013, the bytes of the reference as built (MSVC 2013 runtime, text-mode stream): the libstdc++ text with every exponent
+    // padded to three digits, that runtime's spellings of the non-finite values, CR LF.  The dialect's own reference, made from
+    // libstdc++'s by those three rewrites -- a second statement of the rule, not a third-party oracle (parity unpinned: the reference ships no output).
+    {
+        auto msvc = [&](const std::vector<double> &xyz) {
+            std::string out;
+            for (size_t k = 0; k < xyz.size(); k++) {
+                const double v = xyz[k];
+                std::string t;
+                if (std::isnan(v)) t = std::signbit(v) ? "-1.#IND" : "1.#QNAN";
+                else if (std::isinf(v)) t = v < 0 ? "-1.#INF" : "1.#INF";
+                else {
+                    std::ostringstream os;
+                    os << v;
+                    t = os.str();
+                    const size_t e = t.find('e');
+                    if (e != std::string::npos && t.size() - (e + 2) == 2) t.insert(e + 2, "0");       // e+05 -> e+005; e-300 stays
+                }
+                out += t;
+                out += k % 3 == 2 ? "\r\n" : " ";
+            }
+            return out;
+        };
+        CHECK(slx::WritePointCloudText(p, special.data(), special.size() / 3, SLX_TEXT_MSVC2013) && file_bytes() == msvc(special));
+        const std::vector<double> expo = {5e-5, -5e-5, 1.5e-5, 1e6, 1.25e15, -9.99999e-5, 1e-300, 1e300, 1e100, 2.5, 0.0, 100000.0};
+        CHECK(slx_write_point_cloud_text_ex(p.c_str(), expo.data(), expo.size() / 3, SLX_TEXT_MSVC2013) == SLX_OK);
+        CHECK(file_bytes() == "5e-005 -5e-005 1.5e-005\r\n1e+006 1.25e+015 -9.99999e-005\r\n1e-300 1e+300 1e+100\r\n2.5 0 100000\r\n");
+        CHECK(slx_write_point_cloud_text_ex(p.c_str(), expo.data(), expo.size() / 3, SLX_TEXT_LIBSTDCXX) == SLX_OK && file_bytes() == reference(expo));
+        std::vector<double> many(3 * 70001);
+        for (size_t i = 0; i < many.size(); i++) {
+            const uint64_t r = next();
+            if (i % 5 == 0) std::memcpy(&many[i], &r, sizeof r);
+            else many[i] = ((double)(r >> 11) / 9007199254740992.0 - 0.5) * ((i % 3) ? 1500.0 : 1e-3);
+        }
+        CHECK(slx_write_point_cloud_text_ex(p.c_str(), many.data(), many.size() / 3, SLX_TEXT_MSVC2013) == SLX_OK && file_bytes() == msvc(many));
+        CHECK(slx_write_point_cloud_text_ex(p.c_str(), expo.data(), 1, 7) == SLX_ERR_INVALID_ARG);
     }
     CHECK(slx_write_point_cloud_text(nullptr, nullptr, 0) == SLX_ERR_INVALID_ARG);
     CHECK(slx_write_point_cloud_text(p.c_str(), nullptr, 5) == SLX_ERR_INVALID_ARG);
@@ -351,8 +400,76 @@ static void check_stream_plan(int w, int h, int n_sets, int F, int rows, unsigne
     CHECK((unsigned long long)((unsigned)h + q.sq_rows * q.interleave) * (unsigned)w * 8ull < (1ull << 32));
 }
 
+// The same for slx_gstream_kernel (the reference's own mode: 6 Gray bits on the ring + one 4-step frequency): queues, exact division,
+// coverage, 32-bit offsets; taken by the planner itself only from 8 items per resident wave on.
+static int g_gstream_plans = 0;
+static void check_gstream_plan(int w, int h, int n_sets, int rows, int force, unsigned n_cus = 0)
+{
+    SlxKParams kp;
+    std::memset(&kp, 0, sizeof kp);
+    kp.width = w; kp.height = h; kp.quads_per_row = (unsigned)((w + 3) / 4); kp.n_quads = kp.quads_per_row * (unsigned)h;
+    kp.n_freq = 1; kp.n_steps = 4; kp.aligned = (w % 4) == 0; kp.row_stride = (size_t)w;
+    kp.period[0] = 40; kp.gray_bits = 6; kp.gray_stripe = 20; kp.std_gray = 1;
+    kp.cx = w / 2.0; kp.cy = h / 2.0; kp.fu = kp.fv = 1200; kp.P00 = 1; kp.P01 = .1; kp.P20 = .01; kp.P21 = .02; kp.K1 = 5; kp.K2 = 7; kp.cA = 3; kp.cB = 2;
+    kp.out_set_stride = (size_t)w * (size_t)h;
+    static uint8_t arena[1], garena[1];
+    static unsigned counters[1];
+    static double out_arena[2];
+    const size_t plane = (size_t)w * (size_t)h;
+    for (int i = 0; i < 4; i++) kp.phase[i] = arena + (size_t)i * plane;
+    for (int i = 0; i < 12; i++) kp.gray[i] = garena + (size_t)i * plane;
+    kp.phase_set_stride = 4 * plane;
+    kp.gray_set_stride = 12 * plane;
+    kp.z = out_arena;
+    kp.sq_counters = counters;
+    kp.n_cus = n_cus;
+    SlxTuning tn;
+    std::memset(&tn, 0, sizeof tn);
+    tn.stream = force ? 2 : 0;
+    tn.stream_rows = rows;
+    SlxLaunchPlan plan;
+    if (slx_plan_launch(kp, SLX_MODE_GRAY_PHASE, false, n_sets, SLX_VARIANT_AUTO, &tn, &plan) != 0) return;
+    const SlxKParams &q = plan.kp;
+    if (plan.stream != 2) {
+        CHECK(plan.stream == 0);                                      // never the Gray-free kernel
+        return;
+    }
+    g_gstream_plans++;
+    CHECK(plan.gray_ring_bits == 6 && q.sq_rows == (unsigned)(rows ? rows : 1) && q.sq_m >= 1 && q.sq_queues == q.chunks_per_group * q.sq_m && q.sq_queues <= SLX_STREAM_MAX_QUEUES);
+    CHECK(q.chunks_per_group * 64u == q.interleave * q.quads_per_row);
+    CHECK((unsigned long long)q.sq_groups_per_set * q.sq_rows * q.interleave >= (unsigned)h);
+    CHECK((unsigned long long)(q.sq_groups_per_set - 1) * q.sq_rows * q.interleave < (unsigned)h);
+    CHECK(q.sq_groups_total == q.sq_groups_per_set * (unsigned)n_sets);
+    CHECK(plan.block == 256 && plan.grid_x >= 1 && plan.grid_x <= 1024 && plan.lds_bytes == 4u * 8192u);
+    const unsigned long long launched = (unsigned long long)plan.grid_x * (plan.block / 64u);
+    CHECK(launched >= (unsigned long long)q.chunks_per_group * std::min(q.sq_m, q.sq_groups_total));
+    if (!force) CHECK((unsigned long long)q.sq_groups_total * q.chunks_per_group >= 8ull * (n_cus ? n_cus : 256u) * 16ull);   // the planner's own threshold
+    unsigned long long seen = 0;
+    for (unsigned j = 0; j < q.sq_m; j++) {
+        const unsigned Kq = q.sq_groups_total > j ? (q.sq_groups_total - j + q.sq_m - 1u) / q.sq_m : 0u;
+        for (unsigned k = 0; k < Kq; k += (Kq > 4096u ? 97u : 1u)) {
+            const unsigned G = k * q.sq_m + j;
+            const unsigned set = q.sq_groups_per_set == 1u ? G : (unsigned)(((unsigned long long)G * q.sq_magic) >> 32);
+            CHECK(G < q.sq_groups_total && set == G / q.sq_groups_per_set && set < (unsigned)n_sets);
+        }
+        seen += Kq;
+    }
+    CHECK(seen == q.sq_groups_total);
+    CHECK((unsigned long long)((unsigned)h + q.sq_rows * q.interleave) * (unsigned)w * 8ull < (1ull << 32));
+}
+
 static void test_plans()
 {
+    for (int w : {1280, 1920, 640, 4096, 516, 64, 252})
+        for (int h : {1024, 720, 150, 37, 7, 3000})
+            for (int n : {1, 2, 7, 9, 32, 256, 4000})
+                for (int rows : {0, 1, 2, 3, 16})
+                    for (int force : {0, 1})
+                        if ((unsigned long long)w * h * 16ull * (unsigned)n < (1ull << 40)) check_gstream_plan(w, h, n, rows, force);
+    for (unsigned cus : {1u, 4u, 15u, 64u, 128u})
+        for (int n : {2, 9, 256}) check_gstream_plan(1280, 1024, n, 0, 1, cus);
+    CHECK(g_gstream_plans > 300);
+
     for (int w : {1920, 1280, 640, 4096, 516, 64, 252})
         for (int h : {1200, 720, 150, 37, 7, 3000})
             for (int n : {1, 2, 9, 32, 256, 4000})
@@ -505,7 +622,12 @@ static void test_cloud_plans()
 
 int main(int argc, char **argv)
 {
-    const std::string dir = argc > 1 ? argv[1] : ".";
+    // the scratch directory: the caller's, or a fresh one under TMPDIR (never the source tree: a run used to leave cloud.txt etc. in tests/cpp)
+    std::string dir;
+    char tmpl[] = "/tmp/host_sanitize.XXXXXX";
+    if (argc > 1) dir = argv[1];
+    else if (const char *made = mkdtemp(tmpl)) dir = made;
+    else { std::perror("mkdtemp"); return 1; }
     test_bmp(dir);
     test_pgm(dir);
     test_yaml_and_gray_table(dir);

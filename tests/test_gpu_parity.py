@@ -164,6 +164,62 @@ def test_stream_kernel_geometries_and_repeated_launches(api, oracle, synth, torc
         assert np.array_equal(z[0].cpu().numpy(), refs[0], equal_nan=True)
 
 
+@pytest.mark.parametrize("shape,n_sets,row_offset,std_lut", [((320, 37), 7, 0, True), ((1280, 30), 3, 11, True), ((132, 65), 5, 0, True), ((320, 41), 4, 0, False),
+                                                             ((1280, 1024), 8, 0, True)])
+def test_gray_stream_kernel_geometries_and_repeated_launches(api, oracle, synth, torch_cuda, shape, n_sets, row_offset, std_lut):
+    """slx_gstream_kernel (round 6: the stream kernel of the reference's own mode, 6 Gray bits on the DMA ring + 4 steps; a row is two
+    ring chunks there): every rows-per-item choice (its default is ONE row) on ragged tiles against the oracle; queue counters carried
+    over three launches of a geometry and zeroed when it changes; a launch on a caller's stream in between; noise-free stripes, exact
+    ties and random bytes in the Gray planes; a table that is not the reflected code; the reference's real size, where the planner
+    takes the kernel by itself from 7 frame-sets on; slx_last_kernel names the kernel."""
+    torch = torch_cuda
+    spec = small_spec(synth, "REF", *shape) if shape != (1280, 1024) else dict(synth.make_spec("REF"))
+    spec["row_offset"] = row_offset
+    if not std_lut:
+        spec["gray_lut"] = ((np.arange(64) * 5 + 3) % 64).astype(np.int16)      # any table: lut[gray] = bin is looked up, not computed
+    H, W = spec["height"], spec["width"]
+    sets, grays = [], []
+    for s in range(n_sets):
+        ph, gr = synth.random_planes(spec, seed=8100 + s)
+        gr[:, :, : W // 3] = np.where(gr[:, :, : W // 3] > 127, 220, 20)          # clean patterns ...
+        gr[1::2, :, : W // 6] = gr[0::2, :, : W // 6]                              # ... and exact ties (pattern == inverse -> bit 0)
+        sets.append(ph)
+        grays.append(gr)
+    refs = [oracle.pipeline(spec, p, g, want=("z",), threads=8)["z"] for p, g in zip(sets, grays)]
+    ph = torch.from_numpy(np.stack(sets)).cuda()
+    gr = torch.from_numpy(np.stack(grays)).cuda()
+    side = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    with api.Context(spec) as ctx:
+        ctx.set_variant(2)
+        for rows, n in ((0, n_sets), (2, n_sets), (1, n_sets), (3, n_sets), (0, n_sets), (7, n_sets - 1), (16, 2), (4, n_sets)):
+            ctx.set_tuning(stream=2, stream_rows=rows)
+            for rep in range(3):
+                z = torch.full((n, H, W), -7.0, dtype=torch.float64, device="cuda")
+                torch.cuda.synchronize()
+                ctx.decode_batch(n, ph[:n], gr[:n], z, stream=side.cuda_stream if rep == 1 else None)
+                ctx.synchronize()
+                torch.cuda.synchronize()
+                assert ctx.last_kernel() == "slx_gstream_kernel: resident waves, %d-row items from queues" % (rows or 1), ctx.last_kernel()
+                for k in range(n):
+                    assert np.array_equal(z[k].cpu().numpy(), refs[k], equal_nan=True), (rows, n, rep, k)
+        # the planner's own choice: the stream kernel for a launch of >= 8 items per resident wave (the reference's size: 7 frame-sets), else the strip kernel
+        ctx.set_tuning(stream=0, stream_rows=0)
+        z = torch.full((n_sets, H, W), -7.0, dtype=torch.float64, device="cuda")
+        torch.cuda.synchronize()
+        ctx.decode_batch(n_sets, ph, gr, z)
+        ctx.synchronize()
+        assert ctx.last_kernel().startswith("slx_gstream_kernel:" if shape == (1280, 1024) else "slx_strip_kernel<2, 1, 6, 4, false>:"), ctx.last_kernel()
+        for k in range(n_sets):
+            assert np.array_equal(z[k].cpu().numpy(), refs[k], equal_nan=True), k
+        ctx.set_tuning(stream=1)
+        ctx.decode_batch(n_sets, ph, gr, z)
+        ctx.synchronize()
+        assert ctx.last_kernel().startswith("slx_strip_kernel<2, 1, 6, 4, false>:")
+        for k in range(n_sets):
+            assert np.array_equal(z[k].cpu().numpy(), refs[k], equal_nan=True), k
+
+
 def test_gray_and_phase_groups_far_apart_in_memory(api, oracle, synth, torch_cuda):
     """The two plane groups of a batch are separate allocations and may sit anywhere: here more than 2 GiB apart, in either order
     (the Gray planes ride the DMA ring through a descriptor of their own; round 3's single descriptor made such a launch fall back
@@ -1054,6 +1110,66 @@ def test_fused_point_cloud_geometries(api, oracle, synth, torch_cuda, shape):
             assert ctx.point_cloud_of_depth(z[1], out=tight) == len(ref) and np.array_equal(tight.cpu().numpy(), ref, equal_nan=True)
 
 
+@pytest.mark.parametrize("shape", [(700, 130), (1200, 1920)])
+def test_fused_point_cloud_gives_up_instead_of_hanging(api, oracle, synth, torch_cuda, shape):
+    """The look-back of slx_cloud_fused_kernel polls words other workgroups publish; its progress rests on how the dispatcher hands out
+    workgroups.  The spin is BOUNDED: a workgroup whose words do not arrive within the bound raises a flag and writes nothing, and the
+    host repeats the frame on the count + write launches.  Forced here through SLX_TUNE_CLOUD_SPIN = 1 (a single poll: on a map of
+    many column groups most workgroups give up): the cloud must still equal the oracle's, the call must still succeed, slx_last_error
+    says what happened, and the next frame with the default bound takes the fused launch again (the tagged words were re-zeroed)."""
+    torch = torch_cuda
+    h, w = shape
+    spec = small_spec(synth, "C4", w, h)
+    spec["fov_min"], spec["fov_max"] = 100.0, 900.0
+    rng = np.random.default_rng(h * 7 + w)
+    planes = [rng.uniform(50.0, 1200.0, size=(h, w)) for _ in range(2)]
+    z = torch.from_numpy(np.stack(planes)).cuda()
+    dev = torch.full((h * w, 3), -7.0, dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    with api.Context(spec) as ctx:
+        refs = [oracle.point_cloud(spec, pl) for pl in planes]
+        ctx.set_tuning(cloud_passes=1)
+        assert np.array_equal(ctx.point_cloud_of_depth(z[0]), refs[0])                  # the fused launch, default bound
+        assert "gave up" not in ctx.last_error()
+        ctx.set_tuning(cloud_passes=1, cloud_spin=1)
+        for k in (1, 0, 1):
+            got = ctx.point_cloud_of_depth(z[k])
+            assert got.shape == refs[k].shape and np.array_equal(got, refs[k]), (k, "host")
+            n = ctx.point_cloud_of_depth(z[k], out=dev)
+            assert n == len(refs[k]) and np.array_equal(dev[:n].cpu().numpy(), refs[k]), (k, "device")
+        assert "gave up" in ctx.last_error()                                             # (at least one of those frames fell back)
+        ctx.set_tuning(cloud_passes=1, cloud_spin=0)
+        for k in (0, 1):
+            assert np.array_equal(ctx.point_cloud_of_depth(z[k]), refs[k]), (k, "after the fallbacks")
+
+
+@pytest.mark.parametrize("shape", [(300, 70), (4500, 40)])
+def test_fused_point_cloud_with_focal_lengths_outside_the_cheap_division(api, oracle, synth, torch_cuda, shape):
+    """x = z (u - cx) / fu, y = z (v - cy) / fv (R/CCalculation.cpp:756-771) by the literal f64 division: the instantiations of
+    slx_cloud_fused_kernel for a focal length outside the range of the refined-reciprocal sequence (|f| >= 2^90 here) -- never a real
+    calibration, but the kernel has the code and it must be the oracle's.  Parts of 256 rows and the tall parts of a 4500-row map."""
+    torch = torch_cuda
+    h, w = shape
+    spec = small_spec(synth, "C4", w, h)
+    spec["fov_min"], spec["fov_max"] = 100.0, 900.0
+    cal = dict(spec["calib"])
+    cam = list(cal["cam"])
+    cam[0], cam[4] = 2.0 ** 95, -(2.0 ** 93)
+    cal["cam"] = cam
+    spec["calib"] = cal
+    rng = np.random.default_rng(h + w)
+    plane = rng.uniform(50.0, 1200.0, size=(h, w))
+    ref = oracle.point_cloud(spec, plane)
+    z = torch.from_numpy(plane).cuda()
+    torch.cuda.synchronize()
+    with api.Context(spec) as ctx:
+        for passes in (1, 2, 1):
+            ctx.set_tuning(cloud_passes=passes)
+            got = ctx.point_cloud_of_depth(z)
+            assert got.shape == ref.shape and len(ref) > 0 and np.array_equal(got, ref), passes
+    assert np.all(np.abs(ref[:, 0]) < 1e-20)                                             # (the division really ran against 2^95)
+
+
 # ------------------------------------------------------------------ dynamic frames (CCalculation::CalculateOther)
 def dyna_images(h, w, n, seed):
     """A moving stripe pattern seen by the camera, with noise: what the tracker's column-sum extrema follow."""
@@ -1233,6 +1349,50 @@ def test_point_cloud_text_formatted_on_the_device(api, oracle, synth, torch_cuda
             api.write_point_cloud_text(path, cloud)
             assert open(path, "rb").read() == text, step
             assert text[:200] == fmt(cloud[:40])[:200]
+
+
+def test_point_cloud_text_in_the_dialect_of_the_reference_as_built(api, oracle, synth, torch_cuda, tmp_path):
+    """`ostream << double` means different bytes on the two runtimes: libstdc++ / glibc print "5e-05" and '\\n', the reference AS BUILT
+    (MSVC 2013 runtime, text-mode stream; R/CCalculation.cpp:323-357) prints "5e-005" and CR LF.  SLX_TEXT_MSVC2013 on the device
+    (slx_set_text_dialect) and on the host (slx_write_point_cloud_text_ex) must give the libstdc++ text with every exponent padded to
+    three digits and CR LF line ends -- on values in exponent notation of both signs, at the notation borders, and on a decoded frame's
+    cloud, whose x next to cx is in exponent notation.  (Unpinned like the rest: the reference ships no output file.)"""
+    import re
+    torch = torch_cuda
+    rng = np.random.default_rng(23)
+
+    def msvc(a):
+        text = "".join("%g %g %g\r\n" % tuple(p) for p in a)
+        return re.sub(r"e([+-])(\d\d)(?!\d)", r"e\g<1>0\2", text).encode()
+
+    spec = synth.make_spec("C4")
+    with api.Context(spec) as ctx:
+        a = (rng.random((5000, 3)) - 0.5) * 10.0 ** rng.integers(-5, 15, size=(5000, 1))
+        a[np.abs(a) < 1e-5] = 0.0
+        a[:6] = [[5e-5, -5e-5, 1.5e-5], [1e6, 1.25e14, -9.99999e-5], [999999.5, 999999.4, 0.0001], [0.00009999995, 1e-5, 123456.5], [0.0, -0.0, 1.0], [9.999995e14, -1e6, 2.5]]
+        dev = torch.from_numpy(np.ascontiguousarray(a)).cuda()
+        torch.cuda.synchronize()
+        plain = ctx.format_points_text(dev)
+        assert plain == ("".join("%g %g %g\n" % tuple(p) for p in a)).encode()
+        ctx.set_text_dialect(api.TEXT_MSVC2013)
+        got = ctx.format_points_text(dev)
+        assert got == msvc(a), [(i, g, w) for i, (g, w) in enumerate(zip(got.split(b"\r\n"), msvc(a).split(b"\r\n"))) if g != w][:3]
+        assert got.startswith(b"5e-005 -5e-005 1.5e-005\r\n1e+006 1.25e+014 -9.99999e-005\r\n1e+006 999999 0.0001\r\n0.0001 1e-005 123456\r\n0 -0 1\r\n")
+        path = str(tmp_path / "msvc.txt")
+        api.write_point_cloud_text(path, a, dialect=api.TEXT_MSVC2013)
+        assert open(path, "rb").read() == got
+        # a decoded frame: the columns next to cx have |x| < 1e-4
+        ph, gr, _ = synth.render(spec, "sphere", noise_sigma=2.0)
+        ctx.set_frames(ph, gr)
+        ctx.decode()
+        text, n = ctx.get_point_cloud_text()
+        cloud = ctx.get_point_cloud()
+        assert n == len(cloud) and text == msvc(cloud) and b"e-00" in text
+        ctx.set_text_dialect(api.TEXT_LIBSTDCXX)
+        text2, _ = ctx.get_point_cloud_text()
+        assert text2 == text.replace(b"\r\n", b"\n").replace(b"e-00", b"e-0").replace(b"e+00", b"e+0")
+        with pytest.raises(api.SlxError):
+            ctx.set_text_dialect(5)
 
 
 def test_tracked_frame_cloud_full_size(api, oracle, synth, torch_cuda):
@@ -1814,6 +1974,47 @@ def test_north_star_row_tiles_at_full_size_against_the_oracle(api, oracle, synth
             assert np.array_equal(full[w][s].cpu().numpy(), refs[s][w], equal_nan=True), (s, w)
 
 
+def test_config_5_row_tiles_at_full_size_against_the_oracle(api, oracle, synth, shard, torch_cuda):
+    """BASELINE configuration 5 as north_star cuts it for 8 GPUs, at its real size: the eight 4096 x 375 row tiles (row_offset 0, 375 ...
+    2625 -- the (v - cy) term of R/CCalculation.cpp:155-166 must keep referring to the full-frame row) of 4096 x 3000, 4-frequency x
+    8-step frame-sets, on slx_strip_kernel<3, 4, 0, 8, *>.  (a) one frame-set, tile by tile: z and the fringe orders k of the eight
+    tiles concatenate to the oracle's full maps; (b) two frame-sets, every "rank" decoding its tile of both in ONE launch of
+    slx_decode_batch_ex straight into [set][3000][4096] (plane_stride = 3000 * 4096, what the gather's destination rank does).
+    Tolerance: 1e-5 mm RMS in the contract; bit-equal here (phase indices exactly)."""
+    torch = torch_cuda
+    spec = synth.make_spec("C5")
+    H, W, world = spec["height"], spec["width"], 8
+    assert (W, H, spec["n_freq"], spec["n_steps"]) == (4096, 3000, 4, 8)
+    scenes = [synth.render(spec, "tilted", seed=0x5EED + 55, noise_sigma=1.0)[0], synth.random_planes(spec, seed=56)[0]]
+    refs = [oracle.pipeline(spec, ph, None, want=("z", "k"), threads=8) for ph in scenes]
+    # (a) the tiles of frame-set 0, one call each, with the fringe orders beside the depth
+    parts = []
+    for rank in range(world):
+        tile, lo, hi = shard.row_tile_spec(spec, world, rank)
+        assert (tile["height"], tile["row_offset"], lo, hi) == (375, 375 * rank, 375 * rank, 375 * rank + 375)
+        info = {}
+        parts.append(api.decode_frameset(tile, scenes[0][:, lo:hi], None, want=("z", "k"), info=info))
+        assert info["kernel"].startswith("slx_strip_kernel<3, 4, 0, 8, true>:"), info
+    assert_same({w: np.concatenate([p[w] for p in parts], axis=-2) for w in ("z", "k")}, refs[0], ("z", "k"), RMS_TOL_MM_C5)
+    for w in ("z", "k"):
+        assert np.array_equal(np.concatenate([p[w] for p in parts], axis=-2), refs[0][w], equal_nan=True), w
+    # (b) both frame-sets, each rank's tile of both in one launch, in place in the full-height maps; depth only: the bench's launch
+    n_sets = len(scenes)
+    full = torch.full((n_sets, H, W), -7.0, dtype=torch.float64, device="cuda")
+    for rank in range(world):
+        tile, lo, hi = shard.row_tile_spec(spec, world, rank)
+        ph = torch.from_numpy(np.stack([sc[:, lo:hi] for sc in scenes])).cuda()
+        torch.cuda.synchronize()              # the context's stream does not order itself against torch's stream
+        with api.Context(tile) as ctx:
+            ctx.decode_batch_ex(n_sets, ph, None, z=full[0, lo:], plane_stride=H * W)
+            ctx.synchronize()
+            assert ctx.last_kernel().startswith("slx_strip_kernel<3, 4, 0, 8, false>:"), ctx.last_kernel()
+    for s_ in range(n_sets):
+        got = full[s_].cpu().numpy()
+        assert_same({"z": got}, refs[s_], ("z",), RMS_TOL_MM_C5)
+        assert np.array_equal(got, refs[s_]["z"], equal_nan=True), s_
+
+
 @pytest.mark.parametrize("name,shape,world,n_sets,chunk", [("C4", (128, 37), 3, 5, 2), ("C2", (64, 41), 8, 4, 3), ("C4", (1920, 1200), 8, 8, 8)])
 def test_staged_gather_row_scatter_on_one_gpu(api, oracle, synth, shard, torch_cuda, name, shape, world, n_sets, chunk):
     """The STAGED gather shape with every rank played on this one GPU: each "rank" decodes its row tile of all frame-sets into a dense
@@ -1992,6 +2193,12 @@ def test_bench_two_ranks_rehearsed_on_one_gpu():
         assert g["gather_shape"] == shape and g["gathered_equals_local_decodes"] is True and g["gathered_shape"] == [8, 1200, 1920]
         assert g["kernel_only"]["value"] > 0 and g["end_to_end"]["value"] > 0 and g["gather_only"]["ms_per_step"] > 0
         assert g["messages_at_root_per_step"] == msgs, g                # 2 ranks, 8 frame-sets, one chunk: per (peer, set) / per (peer, chunk)
+        assert g["gathered_equals_oracle"] is True, g                   # rank 0: frame-set 0 and one of the last chunk against the oracle
+    # N > 1: the line certifies itself -- gathered maps (every rank's tile in them) against the oracle, not only against the ranks' own decodes
+    assert d["parity_vs_oracle"] is True
+    checks = d["with_gather"]["oracle_checks"]
+    assert len(checks) == 6 and all(c["equal"] is True for c in checks) and {c["measurement"] for c in checks} == {"rows", "rows_staged", "framesets"}
+    assert {c["gathered_set"] for c in checks} == {0, 4}               # 8 gathered sets in one chunk of 8: set 0 and the middle of the last chunk
     assert d["with_gather"]["rows_staged"]["root_staging_bytes"] == 2 * 8 * 600 * 1920 * 8 and d["with_gather"]["rows"]["root_staging_bytes"] == 0
 
 
@@ -2018,7 +2225,9 @@ def test_bench_gather_code_path_on_rccl_with_one_rank():
         assert "error" not in g, g
         assert g["gather_shape"] == shape and g["gathered_equals_local_decodes"] is True and g["gathered_shape"] == [8, 1200, 1920]
         assert g["messages_at_root_per_step"] == 0 and g["bytes_into_root_per_step"] == 0
+        assert g["gathered_equals_oracle"] is True, g
         assert g["end_to_end"]["value"] > 0 and g["kernel_only"]["value"] > 0 and g["gather_only"]["ms_per_step"] >= 0
+    assert d["parity_vs_oracle"] is True and len(d["with_gather"]["oracle_checks"]) == 6
 
 
 @pytest.mark.parametrize("bits", [1, 3, 6, 7, 8, 10, 12])

@@ -58,6 +58,12 @@ def kernels(tmp_path_factory):
                                                                   for f in ("vgpr_count", "vgpr_spill_count", "sgpr_spill_count", "private_segment_fixed_size",
                                                                             "group_segment_fixed_size")}
     assert all((3, F, 9, 4, 0) in found for F in (1, 2, 3, 4))
+    # the stream kernel of the reference's own mode (round 6): mode 2, one frequency, keyed with GB = 8
+    for blk in re.split(r"\n  - \.agpr_count:", meta):
+        if re.search(r"\.name:\s+\S*slx_gstream_kernelE", blk):
+            found[(2, 1, 8, 4, 0)] = {f: int(re.search(r"\.%s:\s+(\d+)" % f, blk).group(1))
+                                      for f in ("vgpr_count", "vgpr_spill_count", "sgpr_spill_count", "private_segment_fixed_size", "group_segment_fixed_size")}
+    assert (2, 1, 8, 4, 0) in found
     return found
 
 
@@ -91,8 +97,8 @@ def test_planner_occupancy_matches_compiled_register_counts(kernels):
     for (mode, F, GB, NS, AUX), v in sorted(kernels.items()):
         if mode == MODE_GRAY_PHASE and F != 1:
             continue                                   # instantiated by the template switch, never launched
-        if GB == 9:
-            continue                                   # the stream kernel: planned for 4 waves per SIMD, checked by the <= 128 test above
+        if GB in (8, 9):
+            continue                                   # the stream kernels: planned for 4 waves per SIMD, checked by the <= 128 test above
         alloc = (v["vgpr_count"] + 7) // 8 * 8
         allowed = min(8, 512 // alloc)
         claimed = lib.slx_strip_waves_per_simd(mode, F, GB, NS, AUX)
@@ -130,9 +136,10 @@ def test_stream_kernel_ticket_register_is_untouched_between_issue_and_wait(tmp_p
                            "-I" + CSRC, "-S", "--cuda-device-only", os.path.join(CSRC, "slx_kernels.hip"), "-o", out], stderr=subprocess.DEVNULL)
     lines = open(out).read().split("\n")
     ticket_reads = 0
-    for F in (1, 2, 3, 4):
-        who = F
-        start = next(i for i, ln in enumerate(lines) if re.match(r"^_ZN\S*slx_stream_kernelILi%dEEEv10SlxKParams:" % F, ln))
+    instantiations = [("slx_stream_kernelILi%dEEEv10SlxKParams" % F, "slx_stream_kernel<%d>" % F) for F in (1, 2, 3, 4)]
+    instantiations += [("slx_gstream_kernelE10SlxKParams", "slx_gstream_kernel")]
+    for mangled, who in instantiations:
+        start = next(i for i, ln in enumerate(lines) if re.match(r"^_ZN\S*%s:" % mangled, ln))
         end = next(i for i in range(start, len(lines)) if lines[i].startswith(".Lfunc_end"))
         body = [ln.split(";")[0].rstrip() for ln in lines[start + 1:end]]
         # basic blocks: a label starts one, a branch / s_endpgm ends one
@@ -223,7 +230,7 @@ def test_stream_kernel_ticket_register_is_untouched_between_issue_and_wait(tmp_p
                                 break
                         ticket_reads += 1 if consumed else 0
                     state = step(t, state)
-    assert ticket_reads >= 8                                          # the entry ticket's and the loop ticket's consumption, all 4 instantiations
+    assert ticket_reads >= 10                                         # the entry ticket's and the loop ticket's consumption, all 5 kernels
 
 
 def test_fused_cloud_kernel_registers_match_the_plan(tmp_path):

@@ -63,7 +63,7 @@ def make_case(rng):
             "plane_pad": int(rng.choice([0, 0, 0, 2, 16, 1000])), "variant": int(rng.choice([0, 2] if strip else [0, 0, 0, 2, 3, 1])),
             "tune": {}, "aux": []}
     if rng.random() < 0.6:
-        for key, choices in (("strip_rows", [0, 1, 2, 3, 5, 8, 16, 20]), ("weave", [0, 1, 2, 4, 8]), ("stream", [0, 1, 2, 2]), ("stream_rows", [0, 2, 3, 5, 16]),
+        for key, choices in (("strip_rows", [0, 1, 2, 3, 5, 8, 16, 20]), ("weave", [0, 1, 2, 4, 8]), ("stream", [0, 1, 2, 2]), ("stream_rows", [0, 1, 2, 3, 5, 16]),
                              ("tiers", [0, 1, 2, 3]), ("tail_pct", [0, 10, 30]), ("strip_waves", [0, 1, 2, 4]), ("gray_plain", [0, 0, 1]), ("plain_order", [0, 1])):
             if rng.random() < 0.4:
                 case["tune"][key] = int(rng.choice(choices))
