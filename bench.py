@@ -205,7 +205,7 @@ ROTATE = 12
 OTHER_WORKLOADS = [("C3", "C3", OTHER_SETS["C3"], (), 1), ("C5", "C5", OTHER_SETS["C5"], (), 1), ("REF", "REF", OTHER_SETS["REF"], (), 1),
                    ("C2", "C2", OTHER_SETS["C2"], (), 1), ("C4+xyUk", "C4", 16, ("x", "y", "U", "k"), 1), ("C4x1", "C4", 1, (), ROTATE),
                    ("REFx1", "REF", 1, (), ROTATE), ("PHASEx32", "REFPHASE", 32, (), 1), ("GRAYx32", "REFGRAY", 32, (), 1)]
-DECODE_KERNELS = ("slx_strip_kernel", "slx_stream_kernel", "slx_decoder_strip_kernel", "slx_fused_kernel")
+DECODE_KERNELS = ("slx_strip_kernel", "slx_stream_kernel", "slx_gstream_kernel", "slx_decoder_strip_kernel", "slx_fused_kernel")
 PROBE_LAUNCHES = 8               # launches of every workload in a traffic-probe child run (ROTATE for the one-frame-set workloads)
 
 
@@ -266,7 +266,10 @@ def around_the_path(torch, np, api, synth, O, dev_index, device):
             ctx.synchronize()
             track_us = (time.perf_counter() - t0) / 400 * 1e6
         cloud_bytes = 8 * H * W + 24 * n.value
-        out["dynamic_frame"] = {"what": "slx_track_next, image resident in HBM, 1920x1200, window 21 (CCalculation::CalculateOther)", "us_per_frame": track_us,
+        clock = ("host clock over back-to-back calls; for dependent launches of this length it equals the rocprofv3 kernel-trace average and the HIP-event "
+                 "figure on one box (the profiler's interval of a launch begins where the previous one ends: it is the start-to-start period), and the kernel's "
+                 "own first-start-to-last-end span (s_memrealtime) is 2-3 us shorter: profiles/r06_short_kernels.json, tools/short_kernels.py")
+        out["dynamic_frame"] = {"what": "slx_track_next, image resident in HBM, 1920x1200, window 21 (CCalculation::CalculateOther)", "us_per_frame": track_us, "clock": clock,
                                 "bytes_per_pixel": 77, "roofline": {"bound": "hbm", "achieved": 77 * H * W / track_us / 1e3, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                                                      "frac": 77 * H * W / track_us / 1e3 / HBM_PEAK_GBPS}, "parity_vs_oracle": track_ok}
         out["point_cloud"] = {"what": "slx_get_point_cloud into device memory, the host's wait for the count included (CCalculation::Result's points)",

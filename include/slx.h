@@ -152,7 +152,15 @@ int slx_set_frame(slx_ctx *ctx, int group, int idx, const uint8_t *data, size_t 
  * ordered on the device behind the context's previous launch, whichever streams the two ran on -- also two batch decodes
  * on two caller streams whose buffers have nothing in common.  A context is one in-order queue of work; a host that wants
  * two decodes to overlap uses two contexts (they share nothing).  The library keeps no handle of a caller's stream beyond
- * the call: the stream may be destroyed as soon as the call has returned. */
+ * the call: the stream may be destroyed as soon as the call has returned.
+ * Capture into a hipGraph (this call and slx_decode_batch / slx_decode_batch_ex, on a CALLER's stream between hipStreamBeginCapture and
+ * hipStreamEndCapture): the launch becomes a kernel node and the context records nothing for it -- the graph orders it.  Call
+ * slx_synchronize before the capture begins (a graph cannot depend on work queued outside it: SLX_ERR_INVALID_ARG otherwise), keep
+ * slx_enable_timing off, and keep the frames and output buffers of the captured calls alive and in place for every replay.  A captured
+ * batch never takes a stream kernel (their queue counters advance from launch to launch; a replay would repeat them).  The getters
+ * below (slx_get_output, slx_get_depth, slx_get_point_cloud*) know nothing of a graph's replays: after a captured decode the CALLER
+ * synchronizes the replay stream before calling them -- they read the context's output planes as the last completed replay left them.
+ * Worked example and timings: INTEGRATION.md, "A fixed sequence of decodes as a hipGraph". */
 int slx_decode(slx_ctx *ctx, void *stream);
 
 /* n_sets frame-sets resident in device memory, one launch.  Plane p of set s starts at
@@ -189,15 +197,6 @@ int slx_synchronize(slx_ctx *ctx);
  * record its own events on it or make other streams wait for it.  Launches on this stream need no completion event of the
  * library's own (a launch on a caller's stream records one: about 2 us between dependent launches). */
 int slx_get_stream(slx_ctx *ctx, void **stream);
-
-/* hipGraphs.  slx_decode / slx_decode_batch(_ex) on a CALLER's stream may be captured (hipStreamBeginCapture on that stream): the launch
- * becomes a kernel node and the context records nothing for it -- the graph orders it.  Call slx_synchronize before the capture begins
- * (a graph cannot depend on work queued outside it: SLX_ERR_INVALID_ARG otherwise), keep slx_enable_timing off, and keep the frames
- * and output buffers of the captured calls alive and in place for every replay.  One frame-set per launch, twelve launches per
- * graph: 12.7 us per launch against 16.3 us for the same launches issued one by one on that stream (each then carries a
- * completion event) and 13.0 us on the context's own stream (tools/graph_single_set.py).  A captured batch never takes the stream
- * kernel (its queue counters advance from launch to launch, a replay would repeat them): it runs on the strip kernel. */
-
 
 /* Copies an output of the last slx_decode (waits for it).  dst_bytes must be at least the
  * size listed at enum slx_output. */
@@ -293,7 +292,9 @@ int slx_enable_timing(slx_ctx *ctx, int on);
 int slx_last_decode_ms(slx_ctx *ctx, float *ms);
 
 /* Diagnostics: when set (device buffer of >= 32768 u64 words, or NULL to stop), the first n_words / 4 work items
- * (waves) of the fast kernel record s_memtime / s_memrealtime at entry and exit into words [4*item .. 4*item+3]. */
+ * (waves) of the strip kernel -- and the first n_words / 4 workgroups of the tracker's and the fused point cloud's launches -- record
+ * s_memtime / s_memrealtime (100 MHz) at entry and exit into words [4*item .. 4*item+3]: first start to last end is the launch as the
+ * shader sees it, without the dispatch and completion handling a profiler's kernel interval includes (tools/short_kernels.py). */
 int slx_debug_stamps(slx_ctx *ctx, unsigned long long *device_words, size_t n_words);
 
 /* Selects the kernel variant (0 = default); tuning / A-B benchmarking only. */
@@ -317,7 +318,9 @@ enum slx_tuning_key {
     SLX_TUNE_CLOUD_PASSES = 11,/* point cloud: 0 automatic, 1 the single fused launch (SLX_ERR_UNAVAILABLE where its plan refuses), 2 the count + write launches */
     SLX_TUNE_CLOUD_SPIN = 12,  /* fused point cloud: rounds of polls a look-back wait may last before the workgroup gives up and the frame is
                                   repeated on the count + write launches, + 1 (1 = a single poll: tests force the fallback with it)     */
-    SLX_TUNE_COUNT = 13
+    SLX_TUNE_TEXT_PIECES = 13, /* slx_get_point_cloud_text: pieces the text is formatted and copied in (piece k crosses PCIe while k + 1 is
+                                  formatted), 2..16; 1 = cloud, text and copy one after the other                                     */
+    SLX_TUNE_COUNT = 14
 };
 int slx_set_tuning(slx_ctx *ctx, int key, int value);
 /* Which kernel the context's last decode launch was -- the instantiation, spelled as rocprofv3's kernel trace prints it -- and how
@@ -422,7 +425,10 @@ int slx_scatter_rows(slx_ctx *ctx, const slx_scatter *scatter, int n, const doub
  * (NULL: the context's) and every finished chunk is gathered on the comm's stream while the next one decodes.  Inputs as
  * slx_decode_batch (this rank's shards[rank].n_sets frame-sets, tile height shards[rank].rows = the context's height).
  * Destination ranks decode in place into `full`; the others into `scratch` (f64 [n_sets][rows][width], may be NULL on
- * destination ranks).  Every rank must pass the same shards / chunk_sets / root.  Asynchronous: slx_comm_synchronize. */
+ * destination ranks).  Every rank must pass the same shards / chunk_sets / root.  Asynchronous: slx_comm_synchronize.
+ * An error return on ANY rank (a failed decode of a chunk, a failed RCCL call) leaves the other ranks inside RCCL, waiting for messages
+ * that rank will never post -- as with every collective.  The communicator is then unusable: destroy it on every rank (slx_comm_destroy,
+ * or ncclCommAbort on an adopted one) and create a new one before the next gather; do not retry on the old communicator. */
 int slx_decode_gather(slx_comm *comm, slx_ctx *ctx, const slx_shard *shards, int full_height, int chunk_sets,
                       const uint8_t *phase_base, size_t phase_set_stride,
                       const uint8_t *gray_base, size_t gray_set_stride, size_t row_stride,

@@ -516,7 +516,7 @@ class Context:
 
 
 VARIANT_AUTO, VARIANT_GENERIC, VARIANT_STRIP, VARIANT_GENERIC_FAST = range(4)
-TUNE_KEYS = {"strip_rows": 0, "tail_pct": 1, "tail_rows": 2, "gray_plain": 3, "strip_waves": 4, "lds_pad_kib": 5, "plain_order": 6, "tiers": 7, "weave": 8, "stream": 9, "stream_rows": 10, "cloud_passes": 11, "cloud_spin": 12}
+TUNE_KEYS = {"strip_rows": 0, "tail_pct": 1, "tail_rows": 2, "gray_plain": 3, "strip_waves": 4, "lds_pad_kib": 5, "plain_order": 6, "tiers": 7, "weave": 8, "stream": 9, "stream_rows": 10, "cloud_passes": 11, "cloud_spin": 12, "text_pieces": 13}
 
 
 class Pipe:

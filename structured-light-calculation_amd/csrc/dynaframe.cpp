@@ -299,6 +299,13 @@ std::vector<double> CCalculation::GetPointCloud()
     return pts;
 }
 
+bool CCalculation::SetTextDialect(int dialect)
+{
+    if (dialect != SLX_TEXT_LIBSTDCXX && dialect != SLX_TEXT_MSVC2013) return false;
+    m_textDialect = dialect;
+    return !m_ctx || slx_set_text_dialect(m_ctx, dialect) == SLX_OK;
+}
+
 bool CCalculation::Result(std::string fileName, int i)
 {
     if (i != m_frame || !m_ctx || !m_done) return false;        // only the current frame's maps exist on the device
@@ -307,8 +314,9 @@ bool CCalculation::Result(std::string fileName, int i)
     // device formatter does not take (NaN, infinity, 0 < |v| < 1e-5, |v| >= 1e15) goes through the host formatter below.
     const char *text = nullptr;
     size_t n_bytes = 0;
+    (void)slx_set_text_dialect(m_ctx, m_textDialect);
     if (slx_get_point_cloud_text(m_ctx, &text, &n_bytes, nullptr) == SLX_OK) {
-        std::FILE *f = std::fopen(fileName.c_str(), "w");
+        std::FILE *f = std::fopen(fileName.c_str(), "wb");           // the line ends are in the text (CR LF in the MSVC dialect)
         const bool ok = f && (n_bytes == 0 || std::fwrite(text, 1, n_bytes, f) == n_bytes);
         if (!(f && std::fclose(f) == 0 && ok)) {
             m_err = "CCalculation::Result() OpenFile Error:" + fileName;
@@ -319,7 +327,7 @@ bool CCalculation::Result(std::string fileName, int i)
     const double *pts = nullptr;                                   // pinned memory of the context: no vector to size and zero first
     size_t n = 0;
     if (slx_get_point_cloud_view(m_ctx, &pts, &n) != SLX_OK) n = 0;      // (as before: a cloud that cannot be had is an empty file)
-    if (slx_write_point_cloud_text(fileName.c_str(), pts, n) != SLX_OK) {
+    if (slx_write_point_cloud_text_ex(fileName.c_str(), pts, n, m_textDialect) != SLX_OK) {
         m_err = "CCalculation::Result() OpenFile Error:" + fileName;
         return false;
     }

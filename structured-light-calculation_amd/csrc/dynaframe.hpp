@@ -118,6 +118,9 @@ public:
     // R/CCalculation.cpp:323: text point cloud "x y z\n" of the depths inside the FOV, column outer / row inner,
     // default ostream formatting.  Only frame 0 (the static reconstruction) exists here.
     bool Result(std::string fileName, int i = 0);
+    // Which bytes `ostream << double` + endl mean (enum slx_text_dialect, include/slx.h): SLX_TEXT_LIBSTDCXX (default: "5e-05", LF -- the
+    // reference's loop compiled on Linux) or SLX_TEXT_MSVC2013 (the reference as built: "5e-005", CR LF).  False for another value.
+    bool SetTextDialect(int dialect);
     // Dynamic frames, R/CCalculation.cpp:208-320.  StripRegression(0) is what CalculateFirst ends with in the reference
     // (:203); here the camera image comes in explicitly.  CalculateOtherFrame(fN, image) = StripRegression(fN) +
     // FillOtherDeltaProU(fN) + FillCoordinate(fN); afterwards GetZ/GetX/GetY/GetProjectorU/GetDeltaZ/Result refer to frame fN.
@@ -143,6 +146,7 @@ private:
     slx_ctx *m_ctx = nullptr;
     bool m_done = false;
     int m_frame = 0;               // the frame GetZ etc. refer to
+    int m_textDialect = SLX_TEXT_LIBSTDCXX;
     std::string m_err;
 };
 

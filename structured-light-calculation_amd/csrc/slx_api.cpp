@@ -32,6 +32,8 @@ struct Plane {
 
 }  // namespace
 
+constexpr size_t kTextInfoWords = 2 + SLX_TEXT_MAX_PIECES + 1;
+
 struct slx_ctx {
     slx_config cfg;
     SlxKParams kp;
@@ -68,9 +70,11 @@ struct slx_ctx {
     size_t d_text_sums_capacity = 0;
     char *h_text = nullptr;
     size_t h_text_capacity = 0;
-    unsigned long long *h_text_info = nullptr;                        // pinned: [0] the length of the text, [1] the range flag (a tag)
+    unsigned long long *h_text_info = nullptr;                        // pinned: [0] the length of the text, [1] the range flag (a tag), [2 ..] the pieces' offsets
     unsigned text_tag = 0;
     int text_dialect = SLX_TEXT_LIBSTDCXX;                            // slx_set_text_dialect
+    hipStream_t text_stream = nullptr;                                // the text's pieces cross PCIe on it while the next piece is formatted
+    hipEvent_t ev_text[SLX_TEXT_MAX_PIECES] = {};
     size_t cloud_capacity = 0;
     // dynamic-frame tracker: previous frame's strips, unblurred deltaP, staged camera image
     float *d_stripW_prev = nullptr, *d_stripB_prev = nullptr, *d_deltaP_raw = nullptr;
@@ -326,6 +330,7 @@ void slx_destroy(slx_ctx *ctx)
     if (ctx->ev_pending) (void)hipEventSynchronize(ctx->ev_done);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
+    if (ctx->text_stream) (void)hipStreamSynchronize(ctx->text_stream);
     if (ctx->phase_slab) (void)hipFree(ctx->phase_slab);
     if (ctx->gray_slab) (void)hipFree(ctx->gray_slab);
     for (void *o : ctx->out)
@@ -352,6 +357,9 @@ void slx_destroy(slx_ctx *ctx)
     for (hipEvent_t e : {ctx->ev0, ctx->ev1, ctx->ev_done, ctx->ev_track_copied[0], ctx->ev_track_copied[1], ctx->ev_track_used[0], ctx->ev_track_used[1]})
         if (e) (void)hipEventDestroy(e);
     if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
+    if (ctx->text_stream) (void)hipStreamDestroy(ctx->text_stream);
+    for (hipEvent_t ev : ctx->ev_text)
+        if (ev) (void)hipEventDestroy(ev);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -728,6 +736,95 @@ int slx_get_point_cloud(slx_ctx *ctx, double *xyz, size_t capacity_points, size_
     return slx_point_cloud_of_depth(ctx, (const double *)ctx->out[SLX_OUT_Z], xyz, capacity_points, n_points, mem_kind);
 }
 
+// The fused point-cloud launch (slx_cloud.hip), queued on the context's stream; nothing is waited for.  fq: the plan (groups, parts,
+// rows_per_part filled in).  *tag receives what the launch's "gave up" flag (h_cloud_total[1]) would carry.
+static int launch_cloud_fused_async(slx_ctx *ctx, SlxCloudFused fq, const double *z, double *target, unsigned *total_dev, unsigned *tag)
+{
+    const slx_config &c = ctx->cfg;
+    const size_t n_words = slx_cloud_fused_words(fq.groups, fq.parts);
+    if (!ctx->d_cloud_words || ctx->cloud_epoch >= (1u << 30)) {
+        // first use, or before the epoch tags could repeat: the ticket counter and every tagged word start from zero
+        if (!ctx->d_cloud_words) SLX_HIP(ctx, hipMalloc((void **)&ctx->d_cloud_words, n_words * sizeof(unsigned long long)));
+        SLX_HIP(ctx, hipMemsetAsync(ctx->d_cloud_words, 0, n_words * sizeof(unsigned long long), ctx->stream));
+        ctx->cloud_epoch = 0;
+    }
+    fq.z = z;
+    fq.xyz = target;
+    fq.words = ctx->d_cloud_words;
+    fq.total_dev = total_dev;
+    fq.total_host = ctx->h_cloud_total;
+    fq.W = c.width;
+    fq.H = c.height;
+    fq.epoch = ctx->cloud_epoch++;
+    *tag = fq.epoch + 1u;
+    fq.spin_limit = ctx->tune.cloud_spin > 0 ? (unsigned)ctx->tune.cloud_spin - 1u : SLX_CLOUD_SPIN_LIMIT;
+    fq.gave_up_host = ctx->h_cloud_total + 1;
+    fq.stamps = ctx->kp.stamps;
+    fq.stamp_items = ctx->kp.stamp_items;
+    ctx->h_cloud_total[1] = 0u;                                     // (no cloud launch of this context is in flight here: every cloud call ends with its launches drained)
+    fq.row_offset = ctx->kp.row_offset;
+    fq.fov_min = ctx->kp.fov_min;
+    fq.fov_max = ctx->kp.fov_max;
+    fq.cx = ctx->kp.cx;
+    fq.cy = ctx->kp.cy;
+    fq.fu = ctx->kp.fu;
+    fq.fv = ctx->kp.fv;
+    const int e2 = slx_launch_cloud_fused(fq, ctx->stream);
+    if (e2 != 0) {
+        ctx->cloud_epoch = 1u << 30;                                // whatever a failed launch left in the words is not trusted: zero them next time
+        return hip_fail(ctx, (hipError_t)e2, "point-cloud launch");
+    }
+    return SLX_OK;
+}
+
+// Device / pinned buffers of the text of up to max_points points in the context's dialect.
+static int ensure_text_buffers(slx_ctx *ctx, size_t max_points)
+{
+    const size_t line_max = ctx->text_dialect == SLX_TEXT_MSVC2013 ? SLX_TEXT_LINE_MAX_MSVC : SLX_TEXT_LINE_MAX;
+    const size_t need = max_points * line_max + 16, wgs = (size_t)slx_text_workgroups(max_points);
+    if (ctx->d_text_capacity < need) {
+        SLX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->d_text) (void)hipFree(ctx->d_text);
+        ctx->d_text = nullptr;
+        ctx->d_text_capacity = 0;
+        SLX_HIP(ctx, hipMalloc((void **)&ctx->d_text, need));
+        ctx->d_text_capacity = need;
+    }
+    if (ctx->d_text_sums_capacity < wgs) {
+        SLX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->d_text_sums) (void)hipFree(ctx->d_text_sums);
+        ctx->d_text_sums = nullptr;
+        ctx->d_text_sums_capacity = 0;
+        // + the length of the text (8-byte aligned) + the run bases of a very large cloud (slx_text_bases_kernel)
+        SLX_HIP(ctx, hipMalloc((void **)&ctx->d_text_sums, (wgs + 4) * sizeof(unsigned) + (wgs / SLX_TEXT_BASE_RUN + 2) * sizeof(unsigned long long)));
+        ctx->d_text_sums_capacity = wgs;
+    }
+    if (!ctx->h_text_info) {
+        SLX_HIP(ctx, hipHostMalloc((void **)&ctx->h_text_info, kTextInfoWords * sizeof(unsigned long long), hipHostMallocDefault));
+        for (size_t k = 0; k < kTextInfoWords; k++) ctx->h_text_info[k] = 0;
+    }
+    return SLX_OK;
+}
+
+// the 8-byte words behind the workgroup lengths: [0] the length of the text, [1 ..] the run bases (null below SLX_TEXT_BASES_FROM workgroups)
+static unsigned long long *text_total_word(slx_ctx *ctx) { return (unsigned long long *)(ctx->d_text_sums + ((ctx->d_text_sums_capacity + 1) & ~(size_t)1)); }
+static unsigned long long *text_bases(slx_ctx *ctx, size_t max_points)
+{
+    return slx_text_workgroups(max_points) > SLX_TEXT_BASES_FROM ? text_total_word(ctx) + 1 : nullptr;
+}
+
+static int ensure_host_text(slx_ctx *ctx, size_t total)
+{
+    if (ctx->h_text_capacity >= total) return SLX_OK;
+    if (ctx->h_text) (void)hipHostFree(ctx->h_text);
+    ctx->h_text = nullptr;
+    ctx->h_text_capacity = 0;
+    const size_t cap = total + total / 8 + 4096;                      // successive frames differ by a few per cent
+    SLX_HIP(ctx, hipHostMalloc((void **)&ctx->h_text, cap, hipHostMallocDefault));
+    ctx->h_text_capacity = cap;
+    return SLX_OK;
+}
+
 int slx_point_cloud_of_depth(slx_ctx *ctx, const double *depth, double *xyz, size_t capacity_points, size_t *n_points, int mem_kind)
 {
     if (!ctx || !n_points) return SLX_ERR_INVALID_ARG;
@@ -761,38 +858,7 @@ int slx_point_cloud_of_depth(slx_ctx *ctx, const double *depth, double *xyz, siz
             if (e2 != 0) return hip_fail(ctx, (hipError_t)e2, "point-cloud write");
             return SLX_OK;
         }
-        const size_t n_words = slx_cloud_fused_words(fq.groups, fq.parts);
-        if (!ctx->d_cloud_words || ctx->cloud_epoch >= (1u << 30)) {
-            // first use, or before the epoch tags could repeat: the ticket counter and every tagged word start from zero
-            if (!ctx->d_cloud_words) SLX_HIP(ctx, hipMalloc((void **)&ctx->d_cloud_words, n_words * sizeof(unsigned long long)));
-            SLX_HIP(ctx, hipMemsetAsync(ctx->d_cloud_words, 0, n_words * sizeof(unsigned long long), ctx->stream));
-            ctx->cloud_epoch = 0;
-        }
-        fq.z = z;
-        fq.xyz = target;
-        fq.words = ctx->d_cloud_words;
-        fq.total_dev = total_dev;
-        fq.total_host = ctx->h_cloud_total;
-        fq.W = c.width;
-        fq.H = c.height;
-        fq.epoch = ctx->cloud_epoch++;
-        fused_tag = fq.epoch + 1u;
-        fq.spin_limit = ctx->tune.cloud_spin > 0 ? (unsigned)ctx->tune.cloud_spin - 1u : SLX_CLOUD_SPIN_LIMIT;
-        fq.gave_up_host = ctx->h_cloud_total + 1;
-        ctx->h_cloud_total[1] = 0u;                                 // (no launch of this context is in flight here: every cloud call ends with the stream drained ... the decode before it does not touch the word)
-        fq.row_offset = ctx->kp.row_offset;
-        fq.fov_min = ctx->kp.fov_min;
-        fq.fov_max = ctx->kp.fov_max;
-        fq.cx = ctx->kp.cx;
-        fq.cy = ctx->kp.cy;
-        fq.fu = ctx->kp.fu;
-        fq.fv = ctx->kp.fv;
-        const int e2 = slx_launch_cloud_fused(fq, ctx->stream);
-        if (e2 != 0) {
-            ctx->cloud_epoch = 1u << 30;                            // whatever a failed launch left in the words is not trusted: zero them next time
-            return hip_fail(ctx, (hipError_t)e2, "point-cloud launch");
-        }
-        return SLX_OK;
+        return launch_cloud_fused_async(ctx, fq, z, target, total_dev, &fused_tag);
     };
     // The points can be written at once when the target cannot overflow (a device buffer for every pixel, or the
     // context's own staging buffer, which is sized for every pixel): one pass over the GPU, one wait.
@@ -853,48 +919,22 @@ int slx_format_points_text(slx_ctx *ctx, const double *xyz_dev, size_t n_points,
     const size_t line_max = ctx->text_dialect == SLX_TEXT_MSVC2013 ? SLX_TEXT_LINE_MAX_MSVC : SLX_TEXT_LINE_MAX;
     if (n_points >= (1ull << 40) / line_max) return fail(ctx, SLX_ERR_INVALID_ARG, "%zu points: too many for one text", n_points);
     SLX_HIP(ctx, hipSetDevice(ctx->device));
-    const size_t need = n_points * line_max + 16, wgs = (size_t)slx_text_workgroups(n_points);
-    if (ctx->d_text_capacity < need) {
-        SLX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        if (ctx->d_text) (void)hipFree(ctx->d_text);
-        ctx->d_text = nullptr;
-        ctx->d_text_capacity = 0;
-        SLX_HIP(ctx, hipMalloc((void **)&ctx->d_text, need));
-        ctx->d_text_capacity = need;
-    }
-    if (ctx->d_text_sums_capacity < wgs) {
-        SLX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        if (ctx->d_text_sums) (void)hipFree(ctx->d_text_sums);
-        ctx->d_text_sums = nullptr;
-        ctx->d_text_sums_capacity = 0;
-        SLX_HIP(ctx, hipMalloc((void **)&ctx->d_text_sums, (wgs + 4) * sizeof(unsigned)));   // + the length of the text, 8-byte aligned
-        ctx->d_text_sums_capacity = wgs;
-    }
-    if (!ctx->h_text_info) {
-        SLX_HIP(ctx, hipHostMalloc((void **)&ctx->h_text_info, 2 * sizeof(unsigned long long), hipHostMallocDefault));
-        ctx->h_text_info[0] = ctx->h_text_info[1] = 0;
-    }
+    const size_t need = n_points * line_max + 16;
+    if (int rc = ensure_text_buffers(ctx, n_points)) return rc;
     if (int rc = order_after_done(ctx, ctx->stream)) return rc;       // the points may come from a launch on a caller's stream
-    unsigned long long *total_dev = (unsigned long long *)(ctx->d_text_sums + ((ctx->d_text_sums_capacity + 1) & ~(size_t)1));
+    unsigned long long *total_dev = text_total_word(ctx);
     if (++ctx->text_tag == 0) ctx->text_tag = 1;                       // (the flag word starts as 0 and keeps the last raised tag)
     // (The emit kernel storing straight into pinned host memory instead -- no device text, no copy, one wait fewer -- was measured: 1.38 ms
     // against 1.18 ms per 56 MB text; the kernel's stores cross PCIe slower than the copy engine.)
     const int e = slx_launch_text(xyz_dev, n_points, ctx->d_text_sums, (unsigned *)&ctx->h_text_info[1], ctx->text_tag, ctx->d_text, total_dev,
-                                  &ctx->h_text_info[0], ctx->text_dialect, ctx->stream);
+                                  &ctx->h_text_info[0], ctx->text_dialect, text_bases(ctx, n_points), ctx->stream);
     if (e != 0) return hip_fail(ctx, (hipError_t)e, "point-cloud text launch");
     SLX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (*(volatile unsigned *)&ctx->h_text_info[1] == ctx->text_tag)
         return fail(ctx, SLX_ERR_UNAVAILABLE, "a coordinate outside the device formatter's range (|v| < 1e-5, |v| >= 1e15, NaN or infinity): format this cloud on the host");
     const size_t total = (size_t)*(volatile unsigned long long *)&ctx->h_text_info[0];
     if (total > need) return fail(ctx, SLX_ERR_HIP, "the device reports %zu bytes of text for %zu points", total, n_points);
-    if (ctx->h_text_capacity < total) {
-        if (ctx->h_text) (void)hipHostFree(ctx->h_text);
-        ctx->h_text = nullptr;
-        ctx->h_text_capacity = 0;
-        const size_t cap = total + total / 8 + 4096;                  // successive frames differ by a few per cent
-        SLX_HIP(ctx, hipHostMalloc((void **)&ctx->h_text, cap, hipHostMallocDefault));
-        ctx->h_text_capacity = cap;
-    }
+    if (int rc = ensure_host_text(ctx, total)) return rc;
     SLX_HIP(ctx, hipMemcpyAsync(ctx->h_text, ctx->d_text, total, hipMemcpyDeviceToHost, ctx->stream));
     SLX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     *text = ctx->h_text;
@@ -927,6 +967,69 @@ int slx_get_point_cloud_text(slx_ctx *ctx, const char **text, size_t *n_bytes, s
         ctx->cloud_capacity = 0;
         SLX_HIP(ctx, hipMalloc((void **)&ctx->d_cloud, all * 3 * sizeof(double)));
         ctx->cloud_capacity = all;
+    }
+    // The pipeline (where the fused cloud launch has a plan): cloud -> text lengths -> piece offsets are queued back to back -- the
+    // length kernel takes the number of points from the device word the cloud kernel leaves -- and the host waits ONCE for all three;
+    // then the characters are formatted piece by piece and every piece crosses PCIe (its own stream) while the next one is formatted.
+    // Before: cloud | wait | lengths, characters | wait | copy | wait, i.e. the kernels (0.15 ms) in front of the copy (1.05 ms) instead of beside it.
+    const slx_config &c = ctx->cfg;
+    SlxCloudFused fq{};
+    const unsigned pieces = ctx->tune.text_pieces > 0 ? (unsigned)ctx->tune.text_pieces : 2u;   // measured: 1 piece 1.174 ms, 2 1.167, 4 1.168, 8 1.211, 16 1.297 (every copy costs ~20 us to set up)
+    if (pieces >= 2 && all >= 65536 && slx_cloud_fused_plan(c.width, c.height, ctx->kp.n_cus, &fq.groups, &fq.parts, &fq.rows_per_part) && ctx->tune.cloud_passes != 2) {
+        const int msvc = ctx->text_dialect == SLX_TEXT_MSVC2013 ? 1 : 0;
+        if (int rc = ensure_text_buffers(ctx, all)) return rc;
+        const int n_tiles = slx_cloud_tiles(c.width, c.height);
+        if (!ctx->d_cloud_tiles) SLX_HIP(ctx, hipMalloc((void **)&ctx->d_cloud_tiles, ((size_t)n_tiles + 1) * sizeof(unsigned)));
+        if (!ctx->h_cloud_total) {
+            SLX_HIP(ctx, hipHostMalloc((void **)&ctx->h_cloud_total, 2 * sizeof(unsigned), hipHostMallocDefault));
+            ctx->h_cloud_total[0] = ctx->h_cloud_total[1] = 0u;
+        }
+        if (!ctx->text_stream) SLX_HIP(ctx, hipStreamCreateWithFlags(&ctx->text_stream, hipStreamNonBlocking));
+        for (unsigned k = 0; k < pieces; k++)
+            if (!ctx->ev_text[k]) SLX_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_text[k], hipEventDisableTiming));
+        if (int rc = order_after_done(ctx, ctx->stream)) return rc;
+        unsigned *n_dev = ctx->d_cloud_tiles + n_tiles;
+        unsigned long long *total_dev = text_total_word(ctx);
+        unsigned long long *bases = text_bases(ctx, all);
+        unsigned fused_tag = 0;
+        if (int rc = launch_cloud_fused_async(ctx, fq, (const double *)ctx->out[SLX_OUT_Z], ctx->d_cloud, n_dev, &fused_tag)) return rc;
+        if (++ctx->text_tag == 0) ctx->text_tag = 1;
+        int e = slx_launch_text_lengths(ctx->d_cloud, n_dev, all, ctx->d_text_sums, (unsigned *)&ctx->h_text_info[1], ctx->text_tag, pieces, &ctx->h_text_info[2], total_dev,
+                                        msvc, bases, ctx->stream);
+        if (e != 0) return hip_fail(ctx, (hipError_t)e, "point-cloud text launch");
+        SLX_HIP(ctx, hipStreamSynchronize(ctx->stream));                // the one wait in front of the copy
+        if (*(volatile unsigned *)(ctx->h_cloud_total + 1) != fused_tag) {
+            const size_t n = *(volatile unsigned *)ctx->h_cloud_total;
+            if (n_points) *n_points = n;
+            if (n == 0) return SLX_OK;
+            if (*(volatile unsigned *)&ctx->h_text_info[1] == ctx->text_tag)
+                return fail(ctx, SLX_ERR_UNAVAILABLE, "a coordinate outside the device formatter's range (|v| < 1e-5, |v| >= 1e15, NaN or infinity): format this cloud on the host");
+            const unsigned long long *off = ctx->h_text_info + 2;
+            const size_t total = (size_t)off[pieces];
+            const size_t line_max = msvc ? SLX_TEXT_LINE_MAX_MSVC : SLX_TEXT_LINE_MAX;
+            if (total > n * line_max || total < n * 6) return fail(ctx, SLX_ERR_HIP, "the device reports %zu bytes of text for %zu points", total, n);
+            if (int rc = ensure_host_text(ctx, total)) return rc;
+            const unsigned wgs = (unsigned)slx_text_workgroups(n), per = (wgs + pieces - 1u) / pieces;   // the cut slx_text_bounds_kernel made
+            for (unsigned k = 0; k < pieces; k++) {
+                const unsigned a0 = std::min(k * per, wgs), b0 = std::min(a0 + per, wgs);
+                if (b0 == a0) continue;
+                e = slx_launch_text_piece(ctx->d_cloud, n, ctx->d_text_sums, ctx->d_text, total_dev, a0, b0 - a0, msvc, bases, ctx->stream);
+                if (e != 0) return hip_fail(ctx, (hipError_t)e, "point-cloud text launch");
+                SLX_HIP(ctx, hipEventRecord(ctx->ev_text[k], ctx->stream));
+                SLX_HIP(ctx, hipStreamWaitEvent(ctx->text_stream, ctx->ev_text[k], 0));
+                // a piece's first and last dword are shared with its neighbours (the kernels write those bytes one by one): the copy takes
+                // whole bytes [off[k], off[k + 1]) -- exactly what this piece's workgroups wrote
+                if (off[k + 1] > off[k])
+                    SLX_HIP(ctx, hipMemcpyAsync(ctx->h_text + off[k], ctx->d_text + off[k], (size_t)(off[k + 1] - off[k]), hipMemcpyDeviceToHost, ctx->text_stream));
+            }
+            SLX_HIP(ctx, hipStreamSynchronize(ctx->text_stream));       // ... and the one behind it (the pieces' kernels ended before their copies)
+            *text = ctx->h_text;
+            *n_bytes = total;
+            return SLX_OK;
+        }
+        // a workgroup of the fused cloud launch gave up its look-back (slx_cloud.hip): this frame the slow way, on the count + write launches
+        ctx->cloud_epoch = 1u << 30;
+        ctx->cloud_fallbacks++;
     }
     size_t n = 0;
     int rc = slx_point_cloud_of_depth(ctx, (const double *)ctx->out[SLX_OUT_Z], ctx->d_cloud, all, &n, SLX_MEM_DEVICE);
@@ -1549,7 +1652,7 @@ int slx_set_tuning(slx_ctx *ctx, int key, int value)
     SlxTuning &t = ctx->tune;
     const Range r[SLX_TUNE_COUNT] = {{&t.strip_rows, 0, 32}, {&t.tail_pct, -1, 99}, {&t.tail_rows, 0, 32}, {&t.gray_plain, 0, 1},
                                      {&t.strip_waves, 0, 4}, {&t.lds_pad_kib, 0, 128}, {&t.plain_order, 0, 1}, {&t.tiers, 0, SLX_MAX_TIERS},
-                                     {&t.weave, 0, 64}, {&t.stream, 0, 2}, {&t.stream_rows, 0, 16}, {&t.cloud_passes, 0, 2}, {&t.cloud_spin, 0, 1 << 30}};
+                                     {&t.weave, 0, 64}, {&t.stream, 0, 2}, {&t.stream_rows, 0, 16}, {&t.cloud_passes, 0, 2}, {&t.cloud_spin, 0, 1 << 30}, {&t.text_pieces, 0, SLX_TEXT_MAX_PIECES}};
     if (key < 0 || key >= SLX_TUNE_COUNT) return fail(ctx, SLX_ERR_INVALID_ARG, "unknown tuning key %d", key);
     if (value < r[key].lo || value > r[key].hi) return fail(ctx, SLX_ERR_INVALID_ARG, "tuning key %d takes values in [%d,%d] (got %d)", key, r[key].lo, r[key].hi, value);
     *r[key].field = value;

@@ -95,6 +95,10 @@ __global__ __launch_bounds__(kThreads) void slx_cloud_fused_kernel(const SlxClou
     extern __shared__ __attribute__((aligned(16))) double lds[];    // [R][16] tile, swizzled | [kWaves][192] runs
     __shared__ unsigned s_ticket, s_gave_up, col_cnt[16], col_off[16], sib[16][16], part_sum[kWaves];
     const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    if (q.stamps && tid == 0 && blockIdx.x < q.stamp_items) {       // diagnostics only (slx_debug_stamps)
+        q.stamps[4 * (size_t)blockIdx.x + 0] = __builtin_amdgcn_s_memtime();
+        q.stamps[4 * (size_t)blockIdx.x + 2] = __builtin_amdgcn_s_memrealtime();
+    }
     const unsigned P = (unsigned)q.parts, R = (unsigned)q.rows_per_part, n_slots = (unsigned)q.groups * P;
     double *tile = lds, *run = lds + (size_t)R * 16u + (size_t)wave * 192u;
     unsigned long long *totals = q.words + SLX_CLOUD_COUNTERS * 16u, *cols = totals + n_slots;
@@ -304,6 +308,13 @@ __global__ __launch_bounds__(kThreads) void slx_cloud_fused_kernel(const SlxClou
             }
             dst += words;
             __builtin_amdgcn_wave_barrier();
+        }
+    }
+    if (q.stamps && blockIdx.x < q.stamp_items) {                   // diagnostics: after every wave of the workgroup has issued its last store
+        __syncthreads();
+        if (tid == 0) {
+            q.stamps[4 * (size_t)blockIdx.x + 1] = __builtin_amdgcn_s_memtime();
+            q.stamps[4 * (size_t)blockIdx.x + 3] = __builtin_amdgcn_s_memrealtime();
         }
     }
 }

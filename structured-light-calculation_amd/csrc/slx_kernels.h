@@ -113,6 +113,8 @@ struct SlxCloudFused {
     double fov_min, fov_max, cx, cy, fu, fv;
     unsigned spin_limit;                       // rounds of polls a look-back wait may last before the workgroup gives up (slx_cloud.hip)
     unsigned *gave_up_host;                    // pinned host word: receives epoch + 1 when a workgroup gave up (the cloud of that launch is void)
+    unsigned long long *stamps;                // diagnostics (slx_debug_stamps): 4 words per workgroup, or null
+    unsigned long long stamp_items;
 };
 #define SLX_CLOUD_SPIN_LIMIT 16384u            /* ~15 ms of polling: three orders of magnitude above a wait when all is well */
 // Plan of the fused cloud for a W x H map on a device of n_cus compute units (0: 256): false when the shape or the device is
@@ -131,8 +133,16 @@ int slx_launch_cloud_fused(const SlxCloudFused &q, void *stream);
 #define SLX_TEXT_LINE_MAX 39         /* three numbers of at most 12 characters ("-1.23457e-05"), two blanks, the newline */
 #define SLX_TEXT_LINE_MAX_MSVC 43    /* SLX_TEXT_MSVC2013: "-1.23457e-005" is 13 characters, the line ends CR LF */
 inline unsigned long long slx_text_workgroups(unsigned long long n_points) { return (n_points + SLX_TEXT_POINTS_PER_WG - 1ull) / SLX_TEXT_POINTS_PER_WG; }
+#define SLX_TEXT_MAX_PIECES 16       /* pieces the text leaves in (slx_get_point_cloud_text: piece k crosses PCIe while piece k + 1 is formatted) */
+#define SLX_TEXT_BASE_RUN 1024u      /* workgroups per run of `bases` (clouds of more than SLX_TEXT_BASES_FROM workgroups: the emit kernel's prefix stays linear) */
+#define SLX_TEXT_BASES_FROM 4096u    /* 4 Mi points */
+// bases: device, slx_text_workgroups(n) / SLX_TEXT_BASE_RUN + 1 words, or null for clouds below SLX_TEXT_BASES_FROM workgroups
+int slx_launch_text_lengths(const double *xyz, const unsigned *n_dev, unsigned long long max_points, unsigned *sums, unsigned *flag, unsigned tag, unsigned pieces,
+                            unsigned long long *offsets_host, unsigned long long *total_dev, int msvc, unsigned long long *bases, void *stream);
+int slx_launch_text_piece(const double *xyz, unsigned long long n_points, const unsigned *sums, unsigned char *text, unsigned long long *total_dev, unsigned wg_base,
+                          unsigned n_wgs, int msvc, const unsigned long long *bases, void *stream);
 int slx_launch_text(const double *xyz, unsigned long long n_points, unsigned *sums, unsigned *flag, unsigned tag, unsigned char *text,
-                    unsigned long long *total_dev, unsigned long long *total_host, int msvc, void *stream);   // msvc: enum slx_text_dialect
+                    unsigned long long *total_dev, unsigned long long *total_host, int msvc, unsigned long long *bases, void *stream);   // msvc: enum slx_text_dialect
 
 // Dynamic-frame tracker (slx_track.hip).  Device pointers; 0 or a hipError_t.
 // prevW / prevB / raw non-null: also raw = the deltaP selection between the previous frame's strips and the new ones
@@ -172,6 +182,7 @@ struct SlxTuning {
     int stream;          // stream kernel: 0 automatic, 1 never, 2 whenever it can run
     int stream_rows;     // its rows per item, 2..16
     int cloud_passes;    // point cloud: 0 automatic (one launch where its plan allows), 1 the fused launch or an error, 2 the two-launch path
+    int text_pieces;     // slx_get_point_cloud_text: pieces the text is formatted and copied in, 2..16 (1: no pipeline: cloud, text, copy one after the other); 0 = 2
     int cloud_spin;      // fused point cloud: rounds of polls a look-back wait may last, + 1 (1: a single poll); 0 = SLX_CLOUD_SPIN_LIMIT
 };
 

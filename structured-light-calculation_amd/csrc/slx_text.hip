@@ -183,8 +183,12 @@ __device__ __forceinline__ unsigned long long wg_sum(unsigned long long v, unsig
 // so nothing has to be cleared
 template <bool MSVC>
 __global__ __launch_bounds__(kThreads) void slx_text_len_kernel(const double *__restrict__ xyz, unsigned long long n_points, unsigned *__restrict__ sums,
-                                                               unsigned *__restrict__ flag, unsigned tag)
+                                                               unsigned *__restrict__ flag, unsigned tag, const unsigned *__restrict__ n_dev)
 {
+    // n_dev: the number of points is still on its way when this launch is queued (the cloud kernel before it on the stream leaves it
+    // there): the grid then covers every pixel and the workgroups beyond the cloud have nothing to do
+    if (n_dev) n_points = *n_dev;
+    if ((unsigned long long)blockIdx.x * SLX_TEXT_POINTS_PER_WG >= n_points) return;
     __shared__ unsigned long long scratch[kThreads / 64u];
     // a wave takes 256 consecutive points, a lane every 64th of them: the lanes of a load stand 24 bytes apart
     const unsigned long long base = (unsigned long long)blockIdx.x * SLX_TEXT_POINTS_PER_WG + (threadIdx.x >> 6) * (64u * kPerLane) + (threadIdx.x & 63u);
@@ -214,8 +218,12 @@ __global__ __launch_bounds__(kThreads) void slx_text_len_kernel(const double *__
 template <bool MSVC>
 __global__ __launch_bounds__(kThreads) void slx_text_emit_kernel(const double *__restrict__ xyz, unsigned long long n_points, const unsigned *__restrict__ sums,
                                                                 unsigned char *__restrict__ text, unsigned long long *__restrict__ total_dev,
-                                                                unsigned long long *__restrict__ total_host)
+                                                                unsigned long long *__restrict__ total_host, unsigned wg_base, unsigned wgs_total,
+                                                                const unsigned long long *__restrict__ bases)
 {
+    // wg_base / wgs_total: this launch emits the workgroups [wg_base, wg_base + gridDim.x) of the text's wgs_total -- the text leaves
+    // in pieces, each copied to the host while the next one is formatted (slx_get_point_cloud_text)
+    const unsigned bid = blockIdx.x + wg_base;
     __shared__ __attribute__((aligned(16))) unsigned char buf[SLX_TEXT_POINTS_PER_WG * (MSVC ? SLX_TEXT_LINE_MAX_MSVC : SLX_TEXT_LINE_MAX) + 128 + 16];
     __shared__ unsigned long long scratch[kThreads / 64u];
     __shared__ unsigned wave_len[kThreads / 64u];
@@ -223,7 +231,7 @@ __global__ __launch_bounds__(kThreads) void slx_text_emit_kernel(const double *_
     const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     // the numbers first: their loads are what everything waits for.  A wave takes 256 consecutive points, a lane every 64th of them
     // (the lanes of a load stand 24 bytes apart); part i of a wave is its points 64 i .. 64 i + 63.
-    const unsigned long long base = (unsigned long long)blockIdx.x * SLX_TEXT_POINTS_PER_WG + wave * (64u * kPerLane) + lane;
+    const unsigned long long base = (unsigned long long)bid * SLX_TEXT_POINTS_PER_WG + wave * (64u * kPerLane) + lane;
     double v[kPerLane * 3];
 #pragma unroll
     for (unsigned i = 0; i < kPerLane; i++)
@@ -246,16 +254,18 @@ __global__ __launch_bounds__(kThreads) void slx_text_emit_kernel(const double *_
             for (unsigned i = 0; i < kPerLane; i++) plen[i] += j / 3u == i ? l : 0u;
         }
     }
-    // where this workgroup's text starts: the lengths of all workgroups before it
-    unsigned long long before = 0;
+    // where this workgroup's text starts: the lengths of all workgroups before it -- every workgroup adds them up itself (a few thousand
+    // words for a frame's cloud); for clouds of more than SLX_TEXT_BASES_FROM workgroups a small launch in between has left the sum in front
+    // of every run of SLX_TEXT_BASE_RUN workgroups in `bases`, and only the rest of the run is added here (the work stays linear in the points)
+    unsigned long long before = (bases && tid == 0) ? bases[bid / SLX_TEXT_BASE_RUN] : 0ull;
     {
         constexpr unsigned UNROLL = 8;                               // all of a lane's loads in flight (2 220 workgroups for a 1920 x 1200 cloud: 9 per lane)
-        for (unsigned i = tid; i < blockIdx.x; i += kThreads * UNROLL) {
+        for (unsigned i = (bases ? bid / SLX_TEXT_BASE_RUN * SLX_TEXT_BASE_RUN : 0u) + tid; i < bid; i += kThreads * UNROLL) {
             unsigned t[UNROLL];
 #pragma unroll
-            for (unsigned k = 0; k < UNROLL; k++) t[k] = sums[i + kThreads * k < blockIdx.x ? i + kThreads * k : i];
+            for (unsigned k = 0; k < UNROLL; k++) t[k] = sums[i + kThreads * k < bid ? i + kThreads * k : i];
 #pragma unroll
-            for (unsigned k = 0; k < UNROLL; k++) before += i + kThreads * k < blockIdx.x ? t[k] : 0u;
+            for (unsigned k = 0; k < UNROLL; k++) before += i + kThreads * k < bid ? t[k] : 0u;
         }
     }
     before = wg_sum(before, scratch);
@@ -310,26 +320,112 @@ __global__ __launch_bounds__(kThreads) void slx_text_emit_kernel(const double *_
                 if (b >= mis && b < end) dst[b] = buf[b];
         }
     }
-    if (blockIdx.x + 1u == gridDim.x && tid == 0) {                  // the last workgroup knows the length of the text
+    if (bid + 1u == wgs_total && tid == 0) {                  // the last workgroup knows the length of the text
         *total_dev = before + mine;
         if (total_host) *total_host = before + mine;
     }
 }
 
+// bases[r] = the text bytes in front of workgroup r * SLX_TEXT_BASE_RUN, for the clouds of very many workgroups (see slx_text_emit_kernel).
+// One workgroup walks the runs in order; a run is a block-wide sum.
+__global__ __launch_bounds__(1024) void slx_text_bases_kernel(const unsigned *__restrict__ sums, unsigned long long n_points, const unsigned *__restrict__ n_dev,
+                                                             unsigned long long *__restrict__ bases)
+{
+    __shared__ unsigned long long part[16];
+    if (n_dev) n_points = *n_dev;
+    const unsigned wgs = (unsigned)((n_points + SLX_TEXT_POINTS_PER_WG - 1ull) / SLX_TEXT_POINTS_PER_WG);
+    const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    unsigned long long carry = 0;
+    for (unsigned r = 0; r * SLX_TEXT_BASE_RUN < wgs; r++) {
+        if (threadIdx.x == 0) bases[r] = carry;
+        unsigned long long sum = 0;
+        for (unsigned i = r * SLX_TEXT_BASE_RUN + threadIdx.x; i < (r + 1u) * SLX_TEXT_BASE_RUN && i < wgs; i += 1024u) sum += sums[i];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) sum += __shfl_xor(sum, d);
+        if (lane == 0) part[wave] = sum;
+        __syncthreads();
+        unsigned long long t = 0;
+#pragma unroll
+        for (unsigned k = 0; k < 16u; k++) t += part[k];
+        carry += t;
+        __syncthreads();
+    }
+}
+
+// Where the pieces of the text begin: the workgroups are cut into K runs of ceil(wgs / K) (the host cuts them the same way once it
+// knows the number of points) and offsets[k] receives the text bytes in front of run k, offsets[K] the length of the text -- pinned
+// host words, read after ONE wait for cloud + lengths + this.  One wave per run.
+__global__ __launch_bounds__(64 * SLX_TEXT_MAX_PIECES) void slx_text_bounds_kernel(const unsigned *__restrict__ sums, const unsigned *__restrict__ n_dev, unsigned K,
+                                                                                  unsigned long long *__restrict__ offsets_host, unsigned long long *__restrict__ total_dev)
+{
+    __shared__ unsigned long long part[SLX_TEXT_MAX_PIECES];
+    const unsigned wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const unsigned long long n = *n_dev;
+    const unsigned wgs = (unsigned)((n + SLX_TEXT_POINTS_PER_WG - 1ull) / SLX_TEXT_POINTS_PER_WG), per = (wgs + K - 1u) / K;
+    unsigned long long sum = 0;
+    if (wave < K) {
+        const unsigned a = wave * per < wgs ? wave * per : wgs, b = a + per < wgs ? a + per : wgs;
+        for (unsigned i = a + lane; i < b; i += 64u) sum += sums[i];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) sum += __shfl_xor(sum, d);
+        if (lane == 0) part[wave] = sum;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long acc = 0;
+        offsets_host[0] = 0;
+        for (unsigned k = 0; k < K; k++) {
+            acc += part[k];
+            offsets_host[k + 1u] = acc;
+        }
+        *total_dev = acc;
+    }
+}
+
 }  // namespace
 
+// The pieces of slx_get_point_cloud_text's pipeline.  (1) lengths + piece offsets of a cloud whose size is still a device word;
+// (2) the characters of the workgroups [wg_base, wg_base + n_wgs).
+int slx_launch_text_lengths(const double *xyz, const unsigned *n_dev, unsigned long long max_points, unsigned *sums, unsigned *flag, unsigned tag, unsigned pieces,
+                            unsigned long long *offsets_host, unsigned long long *total_dev, int msvc, unsigned long long *bases, void *stream)
+{
+    if (!xyz || !n_dev || max_points == 0 || !sums || !flag || !offsets_host || !total_dev || pieces < 1 || pieces > SLX_TEXT_MAX_PIECES) return (int)hipErrorInvalidValue;
+    const unsigned long long wgs = (max_points + SLX_TEXT_POINTS_PER_WG - 1ull) / SLX_TEXT_POINTS_PER_WG;
+    if (wgs >= (1ull << 31)) return (int)hipErrorInvalidValue;
+    if (msvc) hipLaunchKernelGGL(slx_text_len_kernel<true>, dim3((unsigned)wgs), dim3(kThreads), 0, (hipStream_t)stream, xyz, max_points, sums, flag, tag, n_dev);
+    else hipLaunchKernelGGL(slx_text_len_kernel<false>, dim3((unsigned)wgs), dim3(kThreads), 0, (hipStream_t)stream, xyz, max_points, sums, flag, tag, n_dev);
+    hipLaunchKernelGGL(slx_text_bounds_kernel, dim3(1), dim3(64u * pieces), 0, (hipStream_t)stream, sums, n_dev, pieces, offsets_host, total_dev);
+    if (bases) hipLaunchKernelGGL(slx_text_bases_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, sums, max_points, n_dev, bases);
+    return (int)hipGetLastError();
+}
+
+int slx_launch_text_piece(const double *xyz, unsigned long long n_points, const unsigned *sums, unsigned char *text, unsigned long long *total_dev, unsigned wg_base,
+                          unsigned n_wgs, int msvc, const unsigned long long *bases, void *stream)
+{
+    if (!xyz || n_points == 0 || !sums || !text || !total_dev || n_wgs == 0 || (reinterpret_cast<uintptr_t>(text) & 3u)) return (int)hipErrorInvalidValue;
+    const unsigned long long wgs = (n_points + SLX_TEXT_POINTS_PER_WG - 1ull) / SLX_TEXT_POINTS_PER_WG;
+    if (wgs >= (1ull << 31) || (unsigned long long)wg_base + n_wgs > wgs) return (int)hipErrorInvalidValue;
+    if (msvc) hipLaunchKernelGGL(slx_text_emit_kernel<true>, dim3(n_wgs), dim3(kThreads), 0, (hipStream_t)stream, xyz, n_points, sums, text, total_dev, (unsigned long long *)nullptr, wg_base, (unsigned)wgs, bases);
+    else hipLaunchKernelGGL(slx_text_emit_kernel<false>, dim3(n_wgs), dim3(kThreads), 0, (hipStream_t)stream, xyz, n_points, sums, text, total_dev, (unsigned long long *)nullptr, wg_base, (unsigned)wgs, bases);
+    return (int)hipGetLastError();
+}
+
 int slx_launch_text(const double *xyz, unsigned long long n_points, unsigned *sums, unsigned *flag, unsigned tag, unsigned char *text,
-                    unsigned long long *total_dev, unsigned long long *total_host, int msvc, void *stream)
+                    unsigned long long *total_dev, unsigned long long *total_host, int msvc, unsigned long long *bases, void *stream)
 {
     if (!xyz || n_points == 0 || !sums || !flag || !text || !total_dev || (reinterpret_cast<uintptr_t>(text) & 3u)) return (int)hipErrorInvalidValue;
     const unsigned long long wgs = (n_points + SLX_TEXT_POINTS_PER_WG - 1ull) / SLX_TEXT_POINTS_PER_WG;
     if (wgs >= (1ull << 31)) return (int)hipErrorInvalidValue;
     if (msvc) {
-        hipLaunchKernelGGL(slx_text_len_kernel<true>, dim3((unsigned)wgs), dim3(kThreads), 0, (hipStream_t)stream, xyz, n_points, sums, flag, tag);
-        hipLaunchKernelGGL(slx_text_emit_kernel<true>, dim3((unsigned)wgs), dim3(kThreads), 0, (hipStream_t)stream, xyz, n_points, sums, text, total_dev, total_host);
+        hipLaunchKernelGGL(slx_text_len_kernel<true>, dim3((unsigned)wgs), dim3(kThreads), 0, (hipStream_t)stream, xyz, n_points, sums, flag, tag, (const unsigned *)nullptr);
+        if (bases) hipLaunchKernelGGL(slx_text_bases_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, sums, n_points, (const unsigned *)nullptr, bases);
+        hipLaunchKernelGGL(slx_text_emit_kernel<true>, dim3((unsigned)wgs), dim3(kThreads), 0, (hipStream_t)stream, xyz, n_points, sums, text, total_dev, total_host, 0u, (unsigned)wgs,
+                           (const unsigned long long *)bases);
     } else {
-        hipLaunchKernelGGL(slx_text_len_kernel<false>, dim3((unsigned)wgs), dim3(kThreads), 0, (hipStream_t)stream, xyz, n_points, sums, flag, tag);
-        hipLaunchKernelGGL(slx_text_emit_kernel<false>, dim3((unsigned)wgs), dim3(kThreads), 0, (hipStream_t)stream, xyz, n_points, sums, text, total_dev, total_host);
+        hipLaunchKernelGGL(slx_text_len_kernel<false>, dim3((unsigned)wgs), dim3(kThreads), 0, (hipStream_t)stream, xyz, n_points, sums, flag, tag, (const unsigned *)nullptr);
+        if (bases) hipLaunchKernelGGL(slx_text_bases_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, sums, n_points, (const unsigned *)nullptr, bases);
+        hipLaunchKernelGGL(slx_text_emit_kernel<false>, dim3((unsigned)wgs), dim3(kThreads), 0, (hipStream_t)stream, xyz, n_points, sums, text, total_dev, total_host, 0u, (unsigned)wgs,
+                           (const unsigned long long *)bases);
     }
     return (int)hipGetLastError();
 }

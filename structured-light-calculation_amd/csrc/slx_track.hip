@@ -230,6 +230,11 @@ __global__ __launch_bounds__(kTile) void slx_track_fused_kernel(const uint8_t *c
     __shared__ float rawt[RR][kTile];                                // rawt column tx holds image column c0 - 1 + tx: lane tx's own
     const int W = p.width, H = p.height;
     const int tx = threadIdx.x;
+    // diagnostics only (slx_debug_stamps): when this workgroup started and ended, by the shader clock and the 100 MHz real-time clock
+    if (p.stamps && tx == 0 && blockIdx.x < p.stamp_items) {
+        p.stamps[4 * (size_t)blockIdx.x + 0] = __builtin_amdgcn_s_memtime();
+        p.stamps[4 * (size_t)blockIdx.x + 2] = __builtin_amdgcn_s_memrealtime();
+    }
     // XCD-aware tile order (round 5).  The dispatcher deals workgroups round-robin over the 8 XCDs, each with its own L2; a band shares 22
     // of its 30 image rows and 2 of its 10 rows of the previous frame's strips with the bands above and below it, and in plain order
     // those neighbours sit on other XCDs: the shared rows came from HBM once per band (74.9 MB read per frame for 57.6 algorithmic,
@@ -366,6 +371,13 @@ __global__ __launch_bounds__(kTile) void slx_track_fused_kernel(const uint8_t *c
         z[i] = zz;
         if (x) x[i] = slx_div_item_const(zz * uc, p.fu, rfu);        // :766
         if (y) y[i] = slx_div_item_const(zz * vc, p.fv, rfv);        // :767
+    }
+    if (p.stamps && blockIdx.x < p.stamp_items) {                    // diagnostics: after every wave of the workgroup has issued its last store
+        __syncthreads();
+        if (tx == 0) {
+            p.stamps[4 * (size_t)blockIdx.x + 1] = __builtin_amdgcn_s_memtime();
+            p.stamps[4 * (size_t)blockIdx.x + 3] = __builtin_amdgcn_s_memrealtime();
+        }
     }
 }
 

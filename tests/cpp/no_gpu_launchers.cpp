@@ -17,6 +17,8 @@ int slx_launch_track_update(const SlxKParams &, const float *, float *, double *
 bool slx_track_fusable(int, int, int) { return false; }
 int slx_launch_track_fused(const SlxKParams &, const uint8_t *, size_t, float *, float *, const float *, const float *, float *, double *, double *, double *,
                            double *, double *, void *) { return kNoDevice; }
-int slx_launch_text(const double *, unsigned long long, unsigned *, unsigned *, unsigned, unsigned char *, unsigned long long *, unsigned long long *, int, void *) { return kNoDevice; }
+int slx_launch_text(const double *, unsigned long long, unsigned *, unsigned *, unsigned, unsigned char *, unsigned long long *, unsigned long long *, int, unsigned long long *, void *) { return kNoDevice; }
 int slx_launch_row_scatter(const SlxScatterSegs &, const double *, double *, void *) { return kNoDevice; }
 int slx_launch_cloud_fused(const SlxCloudFused &, void *) { return kNoDevice; }
+int slx_launch_text_lengths(const double *, const unsigned *, unsigned long long, unsigned *, unsigned *, unsigned, unsigned, unsigned long long *, unsigned long long *, int, unsigned long long *, void *) { return kNoDevice; }
+int slx_launch_text_piece(const double *, unsigned long long, const unsigned *, unsigned char *, unsigned long long *, unsigned, unsigned, int, const unsigned long long *, void *) { return kNoDevice; }

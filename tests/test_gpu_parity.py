@@ -1324,6 +1324,17 @@ def test_point_cloud_text_formatted_on_the_device(api, oracle, synth, torch_cuda
             api.write_point_cloud_text(path, a)
             assert open(path, "rb").read() == got, k
         assert ctx.format_points_text(torch.empty((0, 3), dtype=torch.float64, device="cuda")) == b""
+        # a cloud of more than 4 Mi points (4 096 workgroups): the characters' launch then takes the bytes in front of every run of 1 024
+        # workgroups from a small launch in between instead of adding up all lengths before it (linear, not quadratic, in the points)
+        big = (rng.random((4_400_000, 3)) - 0.4) * 10.0 ** rng.integers(-3, 7, size=(4_400_000, 1))
+        big[np.abs(big) < 1e-5] = 0.0
+        dev = torch.from_numpy(big).cuda()
+        torch.cuda.synchronize()
+        got = ctx.format_points_text(dev)
+        path = str(tmp_path / "big.txt")
+        api.write_point_cloud_text(path, big)
+        assert open(path, "rb").read() == got
+        del dev, big, got
         for bad in (1e-7, -3e-6, 1e15, -2.5e200, np.nan, np.inf, -np.inf, 5e-324):
             a = np.ones((2050, 3))
             a[2049, 1] = bad
@@ -1349,6 +1360,13 @@ def test_point_cloud_text_formatted_on_the_device(api, oracle, synth, torch_cuda
             api.write_point_cloud_text(path, cloud)
             assert open(path, "rb").read() == text, step
             assert text[:200] == fmt(cloud[:40])[:200]
+            # the pipeline (cloud -> lengths -> piece offsets, one wait, then the characters piece by piece beside their copies) in
+            # every number of pieces, against the plain sequence (1 piece); also with the count + write launches in front
+            for pieces, passes in ((1, 0), (2, 0), (3, 0), (16, 0), (8, 2), (0, 0)):
+                ctx.set_tuning(text_pieces=pieces, cloud_passes=passes)
+                t2, n2 = ctx.get_point_cloud_text()
+                assert n2 == n and t2 == text, (step, pieces, passes)
+            ctx.set_tuning(text_pieces=0, cloud_passes=0)
 
 
 def test_point_cloud_text_in_the_dialect_of_the_reference_as_built(api, oracle, synth, torch_cuda, tmp_path):
@@ -1381,18 +1399,26 @@ def test_point_cloud_text_in_the_dialect_of_the_reference_as_built(api, oracle, 
         path = str(tmp_path / "msvc.txt")
         api.write_point_cloud_text(path, a, dialect=api.TEXT_MSVC2013)
         assert open(path, "rb").read() == got
-        # a decoded frame: the columns next to cx have |x| < 1e-4
-        ph, gr, _ = synth.render(spec, "sphere", noise_sigma=2.0)
+        with pytest.raises(api.SlxError):
+            ctx.set_text_dialect(5)
+    # a decoded frame whose principal point lies 2e-4 px from a pixel column: that column's x = z (u - cx) / fu is ~4e-5, exponent notation
+    spec2 = dict(spec)
+    cal = dict(spec["calib"])
+    cam = list(cal["cam"])
+    cam[2] = 960.0002
+    cal["cam"] = cam
+    spec2["calib"] = cal
+    ph, gr, _ = synth.render(spec2, "sphere", noise_sigma=2.0)
+    with api.Context(spec2) as ctx:
+        ctx.set_text_dialect(api.TEXT_MSVC2013)
         ctx.set_frames(ph, gr)
         ctx.decode()
         text, n = ctx.get_point_cloud_text()
         cloud = ctx.get_point_cloud()
-        assert n == len(cloud) and text == msvc(cloud) and b"e-00" in text
+        assert n == len(cloud) and text == msvc(cloud) and text.count(b"e-005") > 500
         ctx.set_text_dialect(api.TEXT_LIBSTDCXX)
         text2, _ = ctx.get_point_cloud_text()
-        assert text2 == text.replace(b"\r\n", b"\n").replace(b"e-00", b"e-0").replace(b"e+00", b"e+0")
-        with pytest.raises(api.SlxError):
-            ctx.set_text_dialect(5)
+        assert text2 == text.replace(b"\r\n", b"\n").replace(b"e-005", b"e-05")
 
 
 def test_tracked_frame_cloud_full_size(api, oracle, synth, torch_cuda):

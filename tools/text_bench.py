@@ -51,4 +51,28 @@ with api.Context(spec) as ctx:
         out["points"], out["text_bytes"] = npts.value, nb.value
         if target != "/dev/null":
             os.remove(target)
+    # the call alone, by the number of pieces the text is formatted and copied in (1 = cloud, text, copy one after the other), beside the
+    # time the same number of bytes takes from device to pinned host memory on a copy engine
+    import statistics
+    sweep = {}
+    for pieces in (1, 2, 4, 8, 16, 0):
+        ctx.set_tuning(text_pieces=pieces)
+        ts = []
+        for rep in range(24):
+            t0 = time.perf_counter()
+            tp, nb, npts = C.c_void_p(), C.c_size_t(0), C.c_size_t(0)
+            assert L.slx_get_point_cloud_text(ctx._h, C.byref(tp), C.byref(nb), C.byref(npts)) == 0
+            ts.append(time.perf_counter() - t0)
+        sweep["default (2)" if pieces == 0 else str(pieces)] = {"median_ms": round(statistics.median(ts[4:]) * 1e3, 4), "min_ms": round(min(ts[4:]) * 1e3, 4)}
+    out["call_ms_by_pieces"] = sweep
+    src = torch.empty(out["text_bytes"], dtype=torch.uint8, device="cuda")
+    dst = torch.empty(out["text_bytes"], dtype=torch.uint8).pin_memory()
+    ts = []
+    for rep in range(24):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        dst.copy_(src, non_blocking=True)
+        torch.cuda.synchronize()
+        ts.append(time.perf_counter() - t0)
+    out["pcie_copy_of_the_text_ms"] = {"median": round(statistics.median(ts[4:]) * 1e3, 4), "min": round(min(ts[4:]) * 1e3, 4)}
 print(json.dumps(out))
