@@ -2,7 +2,7 @@
 the GPU suite: random shapes, modes, strides, optional planes, launch plans, call sequences, tracker feeds and calibrations against
 the oracle.  Every leg runs `--cases N`: the case list is a function of (profile, seed, N) alone -- not of the box's speed or of the
 oracle's CPU time -- so two GPUTEST records ran the same cases; the count each leg reports is asserted.  The long runs are recorded
-under profiles/ (r04_fuzz_parity.log, r05_fuzz_parity.log); these keep the fuzzers themselves alive and catch a regression that the
+under profiles/ (r04_fuzz_parity.log, r05_fuzz_parity.log, r06_fuzz_parity.log); these keep the fuzzers themselves alive and catch a regression that the
 pinned geometries of test_gpu_parity.py would step over."""
 import os
 import re
@@ -33,7 +33,7 @@ def _count(out, what):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("profile,seed,cases", [(None, 11, 800), ("strip", 12, 80), ("big", 13, 250), ("bigstrip", 14, 350), ("calib", 15, 300)])
+@pytest.mark.parametrize("profile,seed,cases", [(None, 11, 800), ("strip", 12, 80), ("big", 13, 250), ("bigstrip", 14, 350), ("calib", 15, 300), ("refstream", 16, 120)])
 def test_decode_fuzz(profile, seed, cases):
     out = _run("fuzz_parity.py", cases, seed, profile)
     assert " 0 failures" in out, out[-2000:]

@@ -8,5 +8,6 @@ FUZZ_PROFILE=strip python tools/fuzz_parity.py 0 $((S+2)) --cases 1500 2>&1 | gr
 FUZZ_PROFILE=big python tools/fuzz_parity.py 0 $((S+3)) --cases 5000 2>&1 | grep -v amdgpu.ids
 FUZZ_PROFILE=bigstrip python tools/fuzz_parity.py 0 $((S+4)) --cases 6000 2>&1 | grep -v amdgpu.ids
 FUZZ_PROFILE=calib python tools/fuzz_parity.py 0 $((S+5)) --cases 15000 2>&1 | grep -v amdgpu.ids
+FUZZ_PROFILE=refstream python tools/fuzz_parity.py 0 $((S+8)) --cases 400 2>&1 | grep -v amdgpu.ids
 python tools/fuzz_track.py 0 $((S+6)) --cases 5000 2>&1 | grep -v amdgpu.ids
 python tools/fuzz_api.py 0 $((S+7)) --cases 8000 2>&1 | grep -v amdgpu.ids

@@ -169,6 +169,57 @@ def run_big(seed):
     return "big: " + " / ".join(kernels), bad, {"W": W, "H": H, "F": F, "n_sets": n, "periods": periods}
 
 
+def run_refstream(seed):
+    """FUZZ_PROFILE=refstream: the reference's own mode (6 Gray bits on the ring + one 4-step frequency, R/CCalculation.cpp:525-592) on
+    random widths / heights / frame-set counts / row offsets / Gray tables: the automatic plan (slx_gstream_kernel from 8 items per
+    resident wave on, else the strip kernel), the strip kernel (stream=1) and the stream kernel forced with a random item length must
+    agree bit for bit on every frame-set -- twice in a row (the queue counters carry over) -- and three frame-sets are compared with the
+    oracle."""
+    rng = np.random.default_rng(seed)
+    W = int(rng.integers(16, 513)) * 4
+    H = int(rng.integers(20, 1301))
+    n = int(max(2, min(40, rng.integers(4, 90) * 1000000 // (W * H))))
+    pw = int(rng.choice([W, 1280, 1920]))
+    std = rng.random() < 0.75
+    lut = synth.standard_gray_lut(6) if std else rng.permutation(64).astype(np.int16)
+    spec = {"name": "fuzz", "width": W, "height": H, "row_offset": int(rng.integers(0, 2000)) if rng.random() < 0.3 else 0, "proj_width": pw, "mode": 2,
+            "n_freq": 1, "n_steps": 4, "periods": [max(2, pw // 32)], "gray_bits": 6, "gray_stripe": max(1, pw // 64), "gray_lut": lut,
+            "fov_min": 100.0, "fov_max": 1000.0, "calib": synth.scaled_calibration(W, H, pw)}
+    g = torch.Generator(device="cuda")
+    g.manual_seed(seed)
+    ph = torch.randint(0, 256, (n, 4, H, W), dtype=torch.uint8, device="cuda", generator=g)
+    gr = torch.randint(0, 256, (n, 12, H, W), dtype=torch.uint8, device="cuda", generator=g)
+    if rng.random() < 0.5:                                           # clean stripes and exact ties in a part of the Gray planes
+        gr[:, :, :, : W // 2] = torch.where(gr[:, :, :, : W // 2] > 127, 220, 20).to(torch.uint8)
+        gr[:, 1::2, :, : W // 5] = gr[:, 0::2, :, : W // 5]
+    outs, kernels = [], []
+    rows = int(rng.choice([0, 1, 1, 2, 3, 5, 8, 16]))
+    torch.cuda.synchronize()
+    with api.Context(spec) as ctx:
+        for tune in ({}, {"stream": 1}, {"stream": 2, "stream_rows": rows}):
+            ctx.set_tuning(stream=0, stream_rows=0)
+            if tune:
+                ctx.set_tuning(**tune)
+            z = torch.full((n, H, W), -7.0, dtype=torch.float64, device="cuda")
+            torch.cuda.synchronize()
+            for rep in range(2):
+                ctx.decode_batch(n, ph, gr, z)
+            ctx.synchronize()
+            torch.cuda.synchronize()
+            outs.append(z)
+            kernels.append(ctx.last_kernel().split(":")[0])
+    bad = []
+    # (a width whose quads per row share no factor with 64 makes more chunk columns than there are queues: the plan then keeps the strip kernel)
+    for a in (1, 2):
+        if not torch.equal(outs[0].view(torch.int64), outs[a].view(torch.int64)):
+            bad.append(("plan %d differs from the automatic plan" % a, kernels))
+    for s_ in sorted({0, n - 1, int(rng.integers(0, n))}):
+        ref = O.pipeline(spec, ph[s_].cpu().numpy(), gr[s_].cpu().numpy(), want=("z",), threads=16)["z"]
+        if not np.array_equal(outs[0][s_].cpu().numpy(), ref, equal_nan=True):
+            bad.append(("frame-set %d differs from the oracle" % s_, kernels))
+    return "refstream: " + " / ".join(kernels), bad, {"W": W, "H": H, "n_sets": n, "rows": rows, "std_lut": bool(std), "row_offset": spec["row_offset"]}
+
+
 def run_calib(seed):
     """FUZZ_PROFILE=calib: the triangulation's exactness arguments under calibrations nobody would ship -- entries of the camera /
     projector matrices, the rotation and the translation scaled by powers of two up to 2^+-40, negated, zeroed; FOV windows that
@@ -310,6 +361,19 @@ while PROFILE == "bigstrip" and more(i):
     i += 1
     try:
         label, bad, what = run_bigstrip(seed)
+        if bad:
+            failures += 1
+            print(json.dumps({"MISMATCH": str(bad[:4]), "seed": seed, "case": what}), flush=True)
+    except Exception as e:
+        failures += 1
+        label = "error"
+        print(json.dumps({"ERROR": "%s: %s" % (type(e).__name__, e), "seed": seed}), flush=True)
+    stats[label] = stats.get(label, 0) + 1
+while PROFILE == "refstream" and more(i):
+    seed = seed0 * 100003 + i
+    i += 1
+    try:
+        label, bad, what = run_refstream(seed)
         if bad:
             failures += 1
             print(json.dumps({"MISMATCH": str(bad[:4]), "seed": seed, "case": what}), flush=True)
