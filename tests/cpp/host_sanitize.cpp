@@ -625,8 +625,9 @@ int main(int argc, char **argv)
     // the scratch directory: the caller's, or a fresh one under TMPDIR (never the source tree: a run used to leave cloud.txt etc. in tests/cpp)
     std::string dir;
     char tmpl[] = "/tmp/host_sanitize.XXXXXX";
+    bool own_dir = false;
     if (argc > 1) dir = argv[1];
-    else if (const char *made = mkdtemp(tmpl)) dir = made;
+    else if (const char *made = mkdtemp(tmpl)) { dir = made; own_dir = true; }
     else { std::perror("mkdtemp"); return 1; }
     test_bmp(dir);
     test_pgm(dir);
@@ -636,6 +637,10 @@ int main(int argc, char **argv)
     test_plans();
     test_gather_plans();
     test_cloud_plans();
+    if (own_dir) {                                                    // leave nothing behind in /tmp
+        for (const char *f : {"/t.bmp", "/t.pgm", "/c.yml", "/g.txt", "/cloud.txt"}) std::remove((dir + f).c_str());
+        std::remove(dir.c_str());
+    }
     if (g_fail) { std::fprintf(stderr, "host_sanitize: %d check(s) failed\n", g_fail); return 1; }
     CHECK(g_strip_plans > 5000 && g_generic_plans > 1000);
     if (g_fail) return 1;
