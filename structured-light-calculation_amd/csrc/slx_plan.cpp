@@ -44,8 +44,12 @@ bool slx_cloud_fused_plan(int W, int H, unsigned n_cus, int *groups, int *parts,
     // workgroups of 8 waves a CU keeps: by LDS, and by registers (74 VGPRs with 4 chunks per part: 6 waves per SIMD = 3 workgroups; 98 with
     // 7 chunks: 5 waves per SIMD = 2 workgroups)
     const unsigned long long by_regs = R > 256 ? 2u : 3u;
-    const unsigned long long resident = cus * std::min<unsigned long long>(by_regs, 160u * 1024u / lds);
-    if (resident < (unsigned long long)P) return false;
+    // ... PER XCD: the kernel numbers its workgroups in start order within classes of indices, and what the dispatcher keeps in index order is
+    // each XCD's share of them (an eighth of the compute units; a device of fewer than 8 counts as one) -- the sibling parts of a column
+    // group must fit into ONE XCD's resident set whichever XCD they land on.  (Should the assumption fail all the same, the look-back's
+    // polls are bounded and the host repeats the frame on the two-launch path: slx_cloud.hip.)
+    const unsigned long long per_xcd = std::max<unsigned long long>(1ull, cus / 8ull) * std::min<unsigned long long>(by_regs, 160u * 1024u / lds);
+    if (per_xcd < (unsigned long long)P) return false;
     const long long G = ((long long)W + 15) / 16;
     if (G * P >= (1ll << 24)) return false;
     *groups = (int)G;
