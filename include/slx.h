@@ -157,7 +157,8 @@ int slx_set_frame(slx_ctx *ctx, int group, int idx, const uint8_t *data, size_t 
  * hipStreamEndCapture): the launch becomes a kernel node and the context records nothing for it -- the graph orders it.  Call
  * slx_synchronize before the capture begins (a graph cannot depend on work queued outside it: SLX_ERR_INVALID_ARG otherwise), keep
  * slx_enable_timing off, and keep the frames and output buffers of the captured calls alive and in place for every replay.  A captured
- * batch never takes a stream kernel (their queue counters advance from launch to launch; a replay would repeat them).  The getters
+ * batch takes the same kernel a plain launch would (the stream kernels leave their queue counters at zero, so a replay starts like
+ * any launch) once the context has decoded a batch outside a capture (its counters are allocated then).  The getters
  * below (slx_get_output, slx_get_depth, slx_get_point_cloud*) know nothing of a graph's replays: after a captured decode the CALLER
  * synchronizes the replay stream before calling them -- they read the context's output planes as the last completed replay left them.
  * Worked example and timings: INTEGRATION.md, "A fixed sequence of decodes as a hipGraph". */

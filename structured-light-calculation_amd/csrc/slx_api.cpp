@@ -563,16 +563,17 @@ static int launch(slx_ctx *ctx, SlxKParams &kp, int n_sets, bool aux, void *stre
     }
     if (ctx->timed) SLX_HIP(ctx, hipEventRecord(ctx->ev0, s));
     if (!captured && !ctx->stream_state.counters && n_sets > 1 && (c.mode == SLX_MODE_MULTIFREQ || c.mode == SLX_MODE_GRAY_PHASE)) {
-        // queue counters of the stream kernel: zeroed by the launcher whenever the geometry they count for changes
+        // queue counters of the stream kernels, zeroed here once: the kernels leave them at zero (the wave that draws a queue's last ticket
+        // of a launch resets it), so a launch -- also one captured into a hipGraph and replayed -- always starts from zero.  (A capture
+        // that meets a context without counters -- no batch decoded outside a capture yet -- keeps the strip kernel: no allocation inside a capture.)
         SLX_HIP(ctx, hipMalloc((void **)&ctx->stream_state.counters, (size_t)SLX_STREAM_MAX_QUEUES * 32u * sizeof(unsigned)));
-        ctx->stream_state.key = 0;
+        SLX_HIP(ctx, hipMemset(ctx->stream_state.counters, 0, (size_t)SLX_STREAM_MAX_QUEUES * 32u * sizeof(unsigned)));
+        ctx->stream_state.key = 1;
     }
-    // (a replayed graph repeats its kernel arguments: the stream kernel, whose queue counters advance from launch to launch, stays out of it)
     SlxTuning tune = ctx->tune;
-    if (captured) tune.stream = 1;
-    // (captured: tune.stream = 1 keeps the planner off the queue counters; the state is passed all the same, so that slx_last_kernel names a captured launch too)
+    if (captured && ctx->stream_state.key == 0) tune.stream = 1;      // counters that a failed launch left dirty are not zeroed inside a capture
     int e = slx_launch_fused(kp, c.mode, aux, n_sets, ctx->variant, s, &tune, &ctx->stream_state);
-    if (e != 0 && !captured) ctx->stream_state.key = 0;      // whatever a failed launch left in the counters is not trusted
+    if (e != 0) ctx->stream_state.key = 0;                   // whatever a failed launch left in the counters is not trusted: zeroed before the next one
     if (e != 0) return hip_fail(ctx, (hipError_t)e, "kernel launch");
     if (ctx->timed) SLX_HIP(ctx, hipEventRecord(ctx->ev1, s));
     return captured ? SLX_OK : mark_done(ctx, s);

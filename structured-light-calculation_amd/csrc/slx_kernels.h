@@ -68,7 +68,6 @@ struct SlxKParams {
     unsigned sq_groups_per_set, sq_groups_total;// row groups (sq_rows * interleave rows each) per frame-set, and in the launch
     unsigned sq_rows;                           // rows per item, >= 2
     unsigned sq_magic;                          // floor(2^32 / sq_groups_per_set) + 1: G / groups_per_set = mulhi(G, magic) for every G of the launch
-    unsigned sq_epoch;                          // launches of this geometry since the counters were zeroed
     unsigned n_cus;                             // compute units of the context's device (0: 256, an unpartitioned MI355X); sizes "one round of items"
     unsigned long long *stamps;                 // diagnostics: 4 words per work item (s_memtime / s_memrealtime at start, end) or null
     unsigned long long stamp_items;             // items the stamp buffer has room for
@@ -200,7 +199,7 @@ struct SlxLaunchPlan {
     SlxKParams kp;
     int mode, aux;
     int strip;               // 1: slx_strip_kernel, 0: slx_fused_kernel
-    int stream;              // 1: slx_stream_kernel, 2: slx_gstream_kernel (the reference's own mode) -- kp.sq_* filled in except sq_epoch
+    int stream;              // 1: slx_stream_kernel, 2: slx_gstream_kernel (the reference's own mode) -- kp.sq_* filled in
     int gray_ring_bits;      // strip kernel: 6 when the Gray planes ride the DMA ring, else 0
     unsigned grid_x, grid_y, block;
     size_t lds_bytes;
@@ -213,8 +212,7 @@ int slx_plan_launch(const SlxKParams &kp, int mode, bool aux, int n_sets, int va
 #define SLX_STREAM_MAX_QUEUES 256
 struct SlxStreamState {
     unsigned *counters = nullptr;               // device, SLX_STREAM_MAX_QUEUES * 32 words
-    unsigned long long key = 0;                 // geometry the counters count for (0: none yet)
-    unsigned epoch = 0;
+    unsigned long long key = 0;                 // 0: the counters must be zeroed before the next launch (never used yet, or a launch failed); the kernels leave them at zero
     // what the last launch was (slx_last_kernel): 0 none, 1 slx_fused_kernel, 2 slx_strip_kernel, 3 slx_stream_kernel, 4 slx_decoder_strip_kernel,
     // 5 slx_gstream_kernel
     int last_kind = 0, last_rows = 0, last_weave = 0;

@@ -1266,9 +1266,10 @@ __global__ __launch_bounds__(256) void slx_strip_kernel(const SlxKParams p)
 //     fewer items) -- the footprint of short items with the start-up cost of one item per wave;
 //   * the DMA ring (two chunks ahead), the counted waits, the staged lane-contiguous stores are the strip kernel's, carried
 //     across item boundaries: the request side runs two rows ahead of the compute side and crosses into the next item first.
-// Counters: one 32-bit word per queue, 128 bytes apart (p.sq_counters); a launch adds exactly K_q + W_q to counter q (K_q items,
-// one failing ticket per wave), so launch number e of a geometry starts at e (K_q + W_q) and nothing is reset between launches
-// (the host zeroes them when the geometry changes, slx_launch_fused).
+// Counters: one 32-bit word per queue, 128 bytes apart (p.sq_counters); a launch draws exactly K_q + W_q tickets from counter q (K_q
+// items, one failing ticket per wave), and the wave that draws the last one puts the counter back to zero (round 6; rounds 4-5 let
+// the counters run on and told the kernel the launch's number): every launch starts from zero, the host zeroes the words once when
+// it allocates them and after a failed launch, and a captured launch can be replayed.
 template <int F>
 __global__ __launch_bounds__(256) void slx_stream_kernel(const SlxKParams p)
 {
@@ -1293,12 +1294,19 @@ __global__ __launch_bounds__(256) void slx_stream_kernel(const SlxKParams p)
     const unsigned c = q % cpg, j = q / cpg;
     const unsigned Kq = p.sq_groups_total > j ? (p.sq_groups_total - j + m - 1u) / m : 0u;     // items of this queue
     const unsigned Wq = (total_waves - q + NQ - 1u) / NQ;                                       // waves that poll it
-    const unsigned ticket0 = p.sq_epoch * (Kq + Wq);                                            // this launch's first ticket
+    const unsigned last_ticket = Kq + Wq - 1u;                                                  // a launch draws exactly K_q + W_q tickets from queue q
     unsigned *ctr = p.sq_counters + (size_t)q * 32u;
     auto fetch_issue = [&](unsigned &raw) {        // the ticket arrives with the next s_waitcnt lgkmcnt(0)
         asm volatile("s_mov_b32 %0, 1\n\ts_atomic_add %0, %1, 0x0 glc" : "=&s"(raw) : "s"(ctr) : "memory");
     };
     auto fetch_wait = [&](unsigned &raw) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(raw)::"memory"); };
+    // The wave that draws a queue's LAST ticket of the launch (every wave draws until its first failing one: K_q + W_q draws in all, and
+    // nobody draws after the last) puts the counter back to zero -- a scalar atomic without return, outside the vmcnt sequence.  Every
+    // launch therefore finds its counters at zero, whatever ran before it: nothing to reset from the host between launches or
+    // geometries, and a launch captured into a hipGraph can be replayed (rounds 4-5 kept an epoch on the host, which a replay repeats).
+    auto reset_behind_last = [&](unsigned raw) {
+        if (raw == last_ticket) asm volatile("s_atomic_and %0, %1, 0x0" ::"s"(0u), "s"(ctr) : "memory");
+    };
 
     // ---- per-column state, once per launch
     const unsigned W = (unsigned)p.width, H = (unsigned)p.height;
@@ -1337,7 +1345,7 @@ __global__ __launch_bounds__(256) void slx_stream_kernel(const SlxKParams p)
     struct Item { unsigned valid, set, row_base; };
     auto decode = [&](unsigned raw) {
         Item it;
-        const unsigned k = raw - ticket0;
+        const unsigned k = raw;
         it.valid = k < Kq ? 1u : 0u;
         const unsigned G = it.valid ? k * m + j : 0u;
         it.set = p.sq_groups_per_set == 1u ? G : __umulhi(G, p.sq_magic);   // G / groups_per_set (exact for G * groups_per_set < 2^32: slx_plan.cpp)
@@ -1347,6 +1355,7 @@ __global__ __launch_bounds__(256) void slx_stream_kernel(const SlxKParams p)
     unsigned raw;
     fetch_issue(raw);
     fetch_wait(raw);
+    reset_behind_last(raw);
     Item A = decode(raw), B{0u, 0u, 0u};
     if (!A.valid) return;
 
@@ -1441,6 +1450,7 @@ __global__ __launch_bounds__(256) void slx_stream_kernel(const SlxKParams p)
         // the slot is free once it has been read -- and the ticket requested above has arrived with the same wait
         if (ri == 0) {
             fetch_wait(next_raw);
+            reset_behind_last(next_raw);
             B = decode(next_raw);
         } else {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1553,12 +1563,15 @@ __global__ __launch_bounds__(256) void slx_gstream_kernel(const SlxKParams p)
     const unsigned c = q % cpg, j = q / cpg;
     const unsigned Kq = p.sq_groups_total > j ? (p.sq_groups_total - j + m - 1u) / m : 0u;
     const unsigned Wq = (total_waves - q + NQ - 1u) / NQ;
-    const unsigned ticket0 = p.sq_epoch * (Kq + Wq);
+    const unsigned last_ticket = Kq + Wq - 1u;
     unsigned *ctr = p.sq_counters + (size_t)q * 32u;
     auto fetch_issue = [&](unsigned &raw) {
         asm volatile("s_mov_b32 %0, 1\n\ts_atomic_add %0, %1, 0x0 glc" : "=&s"(raw) : "s"(ctr) : "memory");
     };
     auto fetch_wait = [&](unsigned &raw) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(raw)::"memory"); };
+    auto reset_behind_last = [&](unsigned raw) {   // the queue's last ticket of the launch: the counter goes back to zero (slx_stream_kernel)
+        if (raw == last_ticket) asm volatile("s_atomic_and %0, %1, 0x0" ::"s"(0u), "s"(ctr) : "memory");
+    };
 
     // ---- per-column state, once per launch
     const unsigned W = (unsigned)p.width, H = (unsigned)p.height;
@@ -1592,7 +1605,7 @@ __global__ __launch_bounds__(256) void slx_gstream_kernel(const SlxKParams p)
     struct Item { unsigned valid, set, row_base; };
     auto decode = [&](unsigned raw) {
         Item it;
-        const unsigned k = raw - ticket0;
+        const unsigned k = raw;
         it.valid = k < Kq ? 1u : 0u;
         const unsigned G = it.valid ? k * m + j : 0u;
         it.set = p.sq_groups_per_set == 1u ? G : __umulhi(G, p.sq_magic);
@@ -1602,6 +1615,7 @@ __global__ __launch_bounds__(256) void slx_gstream_kernel(const SlxKParams p)
     unsigned raw;
     fetch_issue(raw);
     fetch_wait(raw);
+    reset_behind_last(raw);
     Item A = decode(raw), B{0u, 0u, 0u};
     if (!A.valid) return;
 
@@ -1699,6 +1713,7 @@ __global__ __launch_bounds__(256) void slx_gstream_kernel(const SlxKParams p)
         // slot 0 is free once it has been read -- and the ticket requested above has arrived with the same wait
         if (ri == 0) {
             fetch_wait(next_raw);
+            reset_behind_last(next_raw);
             B = decode(next_raw);
         } else {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -2149,17 +2164,13 @@ int slx_launch_fused(const SlxKParams &kp_in, int mode, bool aux, int n_sets, in
     SlxKParams &kp = plan.kp;
     kernel_fn fn;
     if (plan.stream) {
-        // the counters count for ONE geometry: zero them when it changes (or before they could wrap), else carry on from the last launch
-        const unsigned long long key = ((unsigned long long)kp.sq_queues << 52) ^ ((unsigned long long)kp.sq_m << 44) ^ ((unsigned long long)kp.sq_groups_total << 12) ^
-                                       ((unsigned long long)plan.grid_x << 3) ^ ((unsigned long long)(plan.block / 64u) << 1) ^ 1ull ^ ((unsigned long long)plan.stream << 62);
-        const unsigned long long per_launch = (unsigned long long)kp.sq_groups_total / kp.sq_m + 2ull + ((unsigned long long)plan.grid_x * (plan.block / 64u)) / kp.sq_queues + 2ull;
-        if (st->key != key || ((unsigned long long)st->epoch + 2ull) * per_launch >= (1ull << 31)) {
+        // the kernels leave their counters at zero (the wave that draws a queue's last ticket resets it): the words are zeroed here only
+        // before their first use and after a launch that failed (st->key == 0)
+        if (st->key == 0) {
             const hipError_t e = hipMemsetAsync(st->counters, 0, (size_t)SLX_STREAM_MAX_QUEUES * 32u * sizeof(unsigned), (hipStream_t)stream);
             if (e != hipSuccess) return (int)e;
-            st->key = key;
-            st->epoch = 0;
+            st->key = 1;
         }
-        kp.sq_epoch = st->epoch++;
         if (plan.stream == 2) {
             fn = slx_gstream_kernel;
         } else {

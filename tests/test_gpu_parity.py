@@ -1233,10 +1233,11 @@ def test_dynamic_frames(api, oracle, synth, shape, window):
 
 @pytest.mark.filterwarnings("ignore:The CUDA Graph is empty")       # (the capture this test expects to be refused)
 def test_decodes_captured_into_a_hip_graph(api, oracle, synth, torch_cuda):
-    """slx_decode_batch_ex on a caller's stream inside a stream capture (include/slx.h, "hipGraphs"): four single-frame-set launches and a
-    32-set batch (the planner's stream kernel must stay out of a graph: its queue counters advance from launch to launch) become one
-    graph; three replays over changing inputs give what plain launches give, frame-set 0 also against the oracle; a capture that
-    begins while work of the context is in flight is refused, not mis-ordered."""
+    """slx_decode_batch_ex on a caller's stream inside a stream capture (include/slx.h, at slx_decode): four single-frame-set launches and a
+    32-set batch -- on the STREAM kernel, whose queue counters return to zero at the end of every launch (round 6; before, a captured
+    batch had to fall back to the strip kernel) -- become one graph; three replays over changing inputs, with plain launches of the
+    same context in between, give what plain launches give, frame-set 0 also against the oracle; a capture that begins while work of
+    the context is in flight is refused, not mis-ordered."""
     torch = torch_cuda
     spec = small_spec(synth, "C4", 1920, 304)
     H, W = spec["height"], spec["width"]
@@ -1267,6 +1268,7 @@ def test_decodes_captured_into_a_hip_graph(api, oracle, synth, torch_cuda):
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g, stream=s):
             launches(z, stream=s.cuda_stream)
+        assert ctx.last_kernel().startswith("slx_stream_kernel<3>"), ctx.last_kernel()   # the captured batch is a stream-kernel launch
         for rep in range(3):
             z.fill_(-1.0)
             if rep:
