@@ -1136,8 +1136,9 @@ def run_rank(args):
             gather[key] = res
         gather["value_is"] = ("rows_staged" if headline_shape[0] == "staged" else "rows") if headline is not None else None
         gather["oracle_checks"] = oracle_checks
-        if rank == 0 and oracle_checks:
-            gather_parity[0] = all(c.get("equal") is True for c in oracle_checks)
+        compared = [c for c in oracle_checks if "equal" in c]      # (an oracle that could not be loaded leaves an error entry and parity null, not false)
+        if rank == 0 and compared:
+            gather_parity[0] = all(c["equal"] is True for c in compared)
         if comm is not None:
             try:
                 comm.close()
