@@ -312,6 +312,22 @@ __device__ __forceinline__ double tri_depth(double Uv, double cC, double cD, dou
     return drop ? 0.0 : zz;
 }
 
+// a5 (R/CCalculation.cpp:570-587) for one pixel, cheaply and bit-identically.  The reference:
+//   even stripe:  phase > 0.75 T ? phase - T : phase            odd stripe:  (phase < 0.25 T ? phase + T : phase) - 0.5 T;      U = gray + that
+// with gray = (double)bin * S and phase the float pix widened to double.  Every one of those double operations is EXACT except the last
+// (pix is a multiple of 2^-24 below 2^15, T an integer < 2^22: phase +- T and - T/2 need < 40 bits), so U = RN(gray + phase + c) with
+// c in {0, -T, +T/2, -T/2} -- ONE rounding of an exact real.  Here: the two comparisons in f32 (0.25 T and 0.75 T are exact floats, pix IS a
+// float), c chosen by 32-bit selects, base = gray + c formed exactly in double (|gray| < 2^48: bin is 16-bit, S 32-bit), U = RN(base + phase):
+// the same real, the same rounding.  Saves the two f64 compares and three 64-bit selects per pixel of the literal select chain.
+__device__ __forceinline__ double merge_gray_phase(int bin, float pix, float q25, float q75, float Tf, float hTf, double Sd)
+{
+    const bool odd = (bin & 1) != 0;
+    const bool shift = odd ? (pix < q25) : (pix > q75);
+    const float c = odd ? (shift ? hTf : -hTf) : (shift ? -Tf : 0.0f);
+    const double base = (double)bin * Sd + (double)c;
+    return base + (double)pix;
+}
+
 // x2 for one pixel and one stage: k = (int)floor((Uprev - pf)/T + 0.5), U = pf + k*T.
 // FASTK: d = Uprev - pf is exact and a multiple of 2^-24 (every pix is), so the real value
 // d/T + 0.5 is either an integer or at least 2^-24/T away from one, while both the oracle's
@@ -1119,19 +1135,11 @@ __global__ __launch_bounds__(256) void slx_strip_kernel(const SlxKParams p)
                 }
             }
             if constexpr (MODE == SLX_MODE_GRAY_PHASE) {
-                const double Td = (double)p.period[0], Sd = (double)p.gray_stripe;
+                // a5 (merge_gray_phase: one rounding of the same exact real as the reference's chain of exact double operations)
+                const double Sd = (double)p.gray_stripe;
+                const float Tm = Tf[0], q25 = 0.25f * Tm, q75 = 0.75f * Tm, hT = 0.5f * Tm;
 #pragma unroll
-                for (int j = 0; j < SLX_QUAD; j++) {
-                    // a5 without divergent branches: even stripe: phase > 3T/4 ? phase - T : phase;
-                    // odd stripe: (phase < T/4 ? phase + T : phase) - T/2.  Same operations, same roundings, as selects.
-                    const double grayv = (double)bin[j] * Sd;
-                    const double phaseVal = (double)pix[0][j];
-                    const bool odd = (bin[j] & 1) != 0;
-                    const bool shift = odd ? (phaseVal < Td * 0.25) : (phaseVal > Td * 0.75);
-                    const double t = shift ? phaseVal + (odd ? Td : -Td) : phaseVal;
-                    const double ph = odd ? t - 0.5 * Td : t;
-                    U[j] = grayv + ph;
-                }
+                for (int j = 0; j < SLX_QUAD; j++) U[j] = merge_gray_phase(bin[j], pix[0][j], q25, q75, Tm, hT, Sd);
             } else {
 #pragma unroll
                 for (int j = 0; j < SLX_QUAD; j++) {
@@ -1748,21 +1756,15 @@ __global__ __launch_bounds__(256) void slx_gstream_kernel(const SlxKParams p)
 #pragma unroll
                 for (int jx = 0; jx < SLX_QUAD; jx++) bin[jx] = (int)p.lut[bin[jx]];
             }
-            const double Td = (double)p.period[0], Sd = (double)p.gray_stripe;
+            const double Sd = (double)p.gray_stripe;
+            const float q25 = 0.25f * Tf, q75 = 0.75f * Tf, hT = 0.5f * Tf;
             const double vc = (double)((int)row + p.row_offset) - p.cy;
             const double vf = vc * p.fu;
             const double tvC = vf * p.P01, tvD = vf * p.P21;
             double z[SLX_QUAD];
 #pragma unroll
             for (int jx = 0; jx < SLX_QUAD; jx++) {
-                // a5 as selects: the same operations and roundings as R/CCalculation.cpp:570-587 (slx_strip_kernel)
-                const double grayv = (double)bin[jx] * Sd;
-                const double phaseVal = (double)pix[jx];
-                const bool odd = (bin[jx] & 1) != 0;
-                const bool shift = odd ? (phaseVal < Td * 0.25) : (phaseVal > Td * 0.75);
-                const double tt = shift ? phaseVal + (odd ? Td : -Td) : phaseVal;
-                const double ph = odd ? tt - 0.5 * Td : tt;
-                const double Uv = grayv + ph;
+                const double Uv = merge_gray_phase(bin[jx], pix[jx], q25, q75, Tf, hT, Sd);   // a5, R/CCalculation.cpp:570-587
                 const double cC = (aC[jx] + tvC) + kK1;
                 const double cD = (aD[jx] + tvD) + kK2;
                 z[jx] = tri_depth<true>(Uv, cC, cD, kcA, kcB, kfmin, kfmax, true);

@@ -463,6 +463,45 @@ def test_variants_exhaustive_wrapped_phase_through_depth(api, oracle, synth, var
         assert len(np.unique(np.round(zr, 12))) >= len(np.unique(pr)) * 0.99
 
 
+@pytest.mark.parametrize("T,S", [(40, 20), (30, 15), (37, 18), (16384, 8192), (2, 1), (1001, 3)])
+def test_gray_phase_merge_exhaustive(api, oracle, synth, torch_cuda, T, S):
+    """The Gray / phase merge (a5, R/CCalculation.cpp:570-587) of the fast kernels is ONE rounding of the exact sum gray + phase + c
+    (merge_gray_phase, csrc/slx_kernels.hip) where the reference chains exact double operations behind two comparisons against 0.25 T and
+    0.75 T: every wrapped phase the 511 x 511 byte differences can produce, on even and on odd stripes (all 64 bins), for even / odd /
+    large periods (odd T: the thresholds and T / 2 are not integers) -- projector column U and depth (unbounded FOV) against the oracle,
+    from the strip kernel, the generic kernels and, as a batch, the stream kernel of this mode."""
+    torch = torch_cuda
+    spec = small_spec(synth, "C1x4", 512, 511)
+    spec["periods"], spec["gray_stripe"] = [T], S
+    spec["fov_min"], spec["fov_max"] = -1e300, 1e300
+    ph = exhaustive_planes(512)
+    rows, cols = np.meshgrid(np.arange(511), np.arange(512), indexing="ij")
+    bins = (rows * 7 + cols // 8) % 64
+    gray_code = bins ^ (bins >> 1)
+    gr = np.empty((12, 511, 512), dtype=np.uint8)
+    for b in range(6):
+        bit = (gray_code >> b) & 1
+        gr[2 * b] = np.where(bit == 1, 220, 20)
+        gr[2 * b + 1] = np.where(bit == 1, 20, 220)
+    ref = oracle.pipeline(spec, ph, gr, want=("z", "U"), threads=8)
+    assert len(np.unique(ref["U"])) > 100000
+    for variant in (api.VARIANT_STRIP, api.VARIANT_AUTO, api.VARIANT_GENERIC, api.VARIANT_GENERIC_FAST):
+        got = api.decode_frameset(spec, ph, gr, want=("z", "U"), variant=variant)
+        for w in ("U", "z"):
+            assert np.array_equal(got[w], ref[w], equal_nan=True), (variant, w, int((got[w] != ref[w]).sum()))
+    dph, dgr = torch.from_numpy(np.stack([ph, ph[:, ::-1].copy()])).cuda(), torch.from_numpy(np.stack([gr, gr[:, ::-1].copy()])).cuda()
+    z = torch.full((2, 511, 512), -7.0, dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    with api.Context(spec) as ctx:
+        ctx.set_tuning(stream=2)
+        ctx.decode_batch(2, dph, dgr, z)
+        ctx.synchronize()
+        assert ctx.last_kernel().startswith("slx_gstream_kernel:"), ctx.last_kernel()
+    assert np.array_equal(z[0].cpu().numpy(), ref["z"], equal_nan=True)
+    ref2 = oracle.pipeline(spec, np.ascontiguousarray(ph[:, ::-1]), np.ascontiguousarray(gr[:, ::-1]), want=("z",), threads=8)["z"]   # set 1: the rows in reverse
+    assert np.array_equal(z[1].cpu().numpy(), ref2, equal_nan=True)
+
+
 @pytest.mark.parametrize("name,scene", [("C1", "sphere"), ("C1x4", "tilted"), ("REF", "tilted"), ("C2", "tilted"), ("C3", "sphere"), ("C4", "sphere")])
 @pytest.mark.parametrize("variant", [1, 2, 3])
 def test_variants_full_size(api, oracle, synth, name, scene, variant):
