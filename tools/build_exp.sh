@@ -8,6 +8,6 @@ mkdir -p ../../tmp_ab
 for N in "$@"; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-result -Wno-format-security -I../../include -I. \
       -DSLX_EXP=$N -c slx_kernels.hip -o /tmp/slx_kernels_exp$N.o
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../tmp_ab/libslx_exp$N.so /tmp/slx_kernels_exp$N.o slx_plan.o slx_track.o slx_api.o slx_comm.o dynaframe.o sensor.o -L/opt/rocm/lib -lrccl
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../tmp_ab/libslx_exp$N.so /tmp/slx_kernels_exp$N.o slx_plan.o slx_track.o slx_gather.o slx_cloud.o slx_text.o slx_api.o slx_comm.o dynaframe.o sensor.o -L/opt/rocm/lib -lrccl
   echo built tmp_ab/libslx_exp$N.so
 done
