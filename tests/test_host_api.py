@@ -248,3 +248,15 @@ def test_point_cloud_text_writer(api, tmp_path):
         api.write_point_cloud_text(path, np.zeros((4, 2)))
     with pytest.raises(api.SlxError):
         api.write_point_cloud_text(str(tmp_path / "no" / "such" / "dir" / "cloud.txt"), xyz[:1])
+    # SLX_TEXT_MSVC2013: the bytes of the reference as built (MSVC 2013 runtime, `fstream` in text mode): the same digits, at least
+    # three exponent digits, that runtime's spellings of the non-finite values, CR LF
+    import re
+    api.write_point_cloud_text(path, xyz, dialect=api.TEXT_MSVC2013)
+    got = open(path, "rb").read().decode()
+    finite = "".join("%g %g %g\r\n" % tuple(p) for p in xyz).replace("-inf", "-1.#INF").replace("inf", "1.#INF")
+    assert got == re.sub(r"e([+-])(\d\d)(?!\d)", r"e\g<1>0\2", finite)
+    assert got.startswith("0 -0 1\r\n1e+006 999999 0.0001\r\n0.0001 123456 1.23456e+006\r\n1e-300 -1e+300 4.94066e-324\r\n1.#INF -1.#INF 2.5\r\n")
+    api.write_point_cloud_text(path, np.array([[np.nan, -np.nan, 5e-5]]), dialect=api.TEXT_MSVC2013)
+    assert open(path, "rb").read() in (b"1.#QNAN -1.#IND 5e-005\r\n", b"-1.#IND 1.#QNAN 5e-005\r\n")   # (numpy may flip the sign bit of its NaN constant)
+    with pytest.raises(api.SlxError):
+        api.write_point_cloud_text(path, xyz[:2], dialect=9)
