@@ -318,7 +318,7 @@ enum slx_tuning_key {
     SLX_TUNE_STREAM_ROWS = 10, /* their rows per work item, 2..16 (1..16 for the reference's own mode)   */
     SLX_TUNE_CLOUD_PASSES = 11,/* point cloud: 0 automatic, 1 the single fused launch (SLX_ERR_UNAVAILABLE where its plan refuses), 2 the count + write launches */
     SLX_TUNE_CLOUD_SPIN = 12,  /* fused point cloud: rounds of polls a look-back wait may last before the workgroup gives up and the frame is
-                                  repeated on the count + write launches, + 1 (1 = a single poll: tests force the fallback with it)     */
+                                  repeated on the count + write launches, + 1 (1 = no poll at all: tests force the fallback with it)     */
     SLX_TUNE_TEXT_PIECES = 13, /* slx_get_point_cloud_text: pieces the text is formatted and copied in (piece k crosses PCIe while k + 1 is
                                   formatted), 2..16; 1 = cloud, text and copy one after the other                                     */
     SLX_TUNE_COUNT = 14

@@ -65,6 +65,12 @@ __device__ __forceinline__ bool await_words(const unsigned long long *const (&wo
     bool ready[N];
 #pragma unroll
     for (int k = 0; k < N; k++) ready[k] = !want[k], value[k] = 0u;
+    if (limit == 0u) {                                              // tests only (SLX_TUNE_CLOUD_SPIN = 1): whoever needs a word gives up, deterministically
+        bool none = true;
+#pragma unroll
+        for (int k = 0; k < N; k++) none = none && ready[k];
+        return none;
+    }
     for (unsigned round = 0;; round++) {
 #pragma unroll
         for (int k = 0; k < N; k++)

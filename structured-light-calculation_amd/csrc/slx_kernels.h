@@ -182,7 +182,7 @@ struct SlxTuning {
     int stream_rows;     // its rows per item, 2..16
     int cloud_passes;    // point cloud: 0 automatic (one launch where its plan allows), 1 the fused launch or an error, 2 the two-launch path
     int text_pieces;     // slx_get_point_cloud_text: pieces the text is formatted and copied in, 2..16 (1: no pipeline: cloud, text, copy one after the other); 0 = 2
-    int cloud_spin;      // fused point cloud: rounds of polls a look-back wait may last, + 1 (1: a single poll); 0 = SLX_CLOUD_SPIN_LIMIT
+    int cloud_spin;      // fused point cloud: rounds of polls a look-back wait may last, + 1 (1: none -- every workgroup that needs a word gives up); 0 = SLX_CLOUD_SPIN_LIMIT
 };
 
 // Waves per SIMD the VGPR count of a strip-kernel instantiation allows (host-side table, checked against the compiled kernels

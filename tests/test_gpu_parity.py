@@ -1153,8 +1153,8 @@ def test_fused_point_cloud_geometries(api, oracle, synth, torch_cuda, shape):
 def test_fused_point_cloud_gives_up_instead_of_hanging(api, oracle, synth, torch_cuda, shape):
     """The look-back of slx_cloud_fused_kernel polls words other workgroups publish; its progress rests on how the dispatcher hands out
     workgroups.  The spin is BOUNDED: a workgroup whose words do not arrive within the bound raises a flag and writes nothing, and the
-    host repeats the frame on the count + write launches.  Forced here through SLX_TUNE_CLOUD_SPIN = 1 (a single poll: on a map of
-    many column groups most workgroups give up): the cloud must still equal the oracle's, the call must still succeed, slx_last_error
+    host repeats the frame on the count + write launches.  Forced here through SLX_TUNE_CLOUD_SPIN = 1 (no poll at all: every workgroup
+    that needs a word of another one gives up): the cloud must still equal the oracle's, the call must still succeed, slx_last_error
     says what happened, and the next frame with the default bound takes the fused launch again (the tagged words were re-zeroed)."""
     torch = torch_cuda
     h, w = shape
